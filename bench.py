@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — mel-frames/s of ONE full Glow-TTS training step (BASELINE.json metric) on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = zero_grad + FlowGenerator.forward (text encoder, 12-block flow decoder, device-resident MAS) + mle_loss +
+duration_loss + backward + (N>1: bucketed RCCL gradient all-reduce overlapped with backward) + clip_grad_value_ +
+Adam/Noam, on a synthetic batch already resident in HBM.  Workload = BASELINE.json configs[1]: per-GPU B=32,
+T_text=160, T_mel=800, 80 mels, 12 flow blocks, n_split=4, fp32, ModelConfig defaults (dropout 0.1 / 0.05 active),
+random-init weights, data-dependent ActNorm init done before timing.  Weak scaling: every rank gets its own B=32.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  "roofline"     : the dominant hand-written HIP kernel of the step — algorithmic bytes per launch
+                   / its mean launch duration measured with HIP events on the launch stream in an instrumented
+                   pass after the timed region — against the 8 TB/s HBM peak; plus the SURVEY.md §8d(i)
+                   invertible-subset fraction and the per-kernel table;
+  "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "glow-tts-train_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config 2: 32)")
+    ap.add_argument("--t-mel", type=int, default=800)
+    ap.add_argument("--t-text", type=int, default=0, help="default T_mel / 5 (SURVEY.md §8)")
+    ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(B, C, H, Ts, T_text, n_params_padded):
+    """Ideal-fusion HBM bytes per LAUNCH of each hand-written kernel at this shape (fp32; N = B*Ts squeezed columns).
+    Every operand read once, every result written once; masks / parameters (KB) ignored.  DESIGN.md §Kernels."""
+    N, e = B * Ts, 4
+    X = C * N * e            # one squeezed flow tensor
+    Hb = H * N * e           # one hidden tensor
+    return {
+        "glowtts_actnorm_fwd": 2 * X,
+        "glowtts_actnorm_bwd": 3 * X,
+        "glowtts_invconv_fwd": 2 * X,
+        "glowtts_invconv_bwd": 3 * X,
+        "glowtts_coupling_fwd": 3 * X,
+        "glowtts_coupling_bwd": 4 * X,          # reads x1, logs (0.5 X each) + dz (X); writes dx, dout (X each)
+        "glowtts_gate_fwd": 3 * Hb,
+        "glowtts_gate_bwd": 5 * Hb,
+        "glowtts_res_skip_fwd": 5.25 * Hb,       # 3 x (5..6 Hb) non-last + 1 x 3 Hb last, mean over the 4 layers
+        "glowtts_res_skip_bwd": 3.5 * Hb,        # 3 x 4 Hb + 1 x 2 Hb
+        "glowtts_squeeze": 2 * X,
+        "glowtts_unsqueeze": 2 * X,
+        "glowtts_mle_fwd": 3 * X,
+        "glowtts_mle_bwd": 6 * X,
+        "glowtts_clip_grad_value": 2 * n_params_padded * e,
+        "glowtts_adam_noam": 7 * n_params_padded * e,
+        "glowtts_mas_path": B * T_text * (Ts * 2) * 8,
+    }
+
+
+INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invconv_fwd", "glowtts_invconv_bwd",
+                     "glowtts_coupling_fwd", "glowtts_coupling_bwd")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from glow_tts_train import _hip, config, models, parallel
+    from glow_tts_train.train import train_batch
+
+    _hip.load()
+    B, T_mel = args.batch, args.t_mel
+    T_text = args.t_text or T_mel // 5
+    cfg = config.TrainingConfig()
+    cfg.model.num_symbols = 148
+    cfg.model.n_blocks_dec = args.blocks
+    torch.manual_seed(cfg.seed)
+    model, opt = models.setup_model(cfg, use_cuda=True)
+    # non-degenerate couplings for the benchmark: the zero-initialised end convs would make logs == 0 everywhere
+    with torch.no_grad():
+        for f in model.decoder.flows:
+            if hasattr(f, "end"):
+                f.end.weight.normal_(0, 0.01)
+    model.train()
+
+    gen = torch.Generator().manual_seed(cfg.seed + rank)
+    x = torch.randint(1, 148, (B, T_text), generator=gen).to(dev)
+    x_lengths = torch.full((B,), T_text, dtype=torch.long, device=dev)
+    y = torch.randn(B, cfg.audio.mel_channels, T_mel, generator=gen).to(dev)
+    y_lengths = torch.full((B,), T_mel, dtype=torch.long, device=dev)
+    batch = (x, x_lengths, y, y_lengths, None)
+
+    # data-dependent ActNorm initialisation on the first batch (ddi.py:20-39), untimed; rank 0's result wins (Q10)
+    for f in model.decoder.flows:
+        if getattr(f, "set_ddi", False):
+            f.set_ddi(True)
+    with torch.no_grad():
+        model(x, x_lengths, y, y_lengths)
+    reducer = parallel.FlowBlockReducer(model, opt) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters(0)
+
+    for _ in range(args.warmup):
+        train_batch(model, opt, batch, cfg.grad_clip, reducer)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = train_batch(model, opt, batch, cfg.grad_clip, reducer)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    loss_val = float(loss)
+    frames = world * B * T_mel * args.steps
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = {
+        "metric": "mel_frames_per_sec", "value": frames / dt, "unit": "mel-frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: full training step, per-GPU B={B}, T_text={T_text}, T_mel={T_mel}, "
+                               f"80 mels, {args.blocks} flow blocks, n_split=4, n_sqz=2, H=192, fp32, dropout 0.1/0.05, "
+                               "random-init weights, synthetic resident batch",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": loss_val},
+    }
+
+    # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
+    if rank == 0 and not args.no_roofline:
+        C = cfg.audio.mel_channels * cfg.model.n_sqz
+        H = cfg.model.hidden_channels_dec
+        Ts = T_mel // cfg.model.n_sqz
+        alg = algorithmic_bytes(B, C, H, Ts, T_text, opt._optim.numel_padded)
+        n_inst = 3
+        _hip.enable_timing()
+        for _ in range(n_inst):
+            train_batch(model, opt, batch, cfg.grad_clip, None)
+        times = _hip.disable_timing()
+        table = {}
+        for name, ms in times.items():
+            if name not in alg:
+                continue
+            mean_ms = sum(ms) / len(ms)
+            table[name] = {"launches_per_step": len(ms) // n_inst, "mean_us": 1e3 * mean_ms,
+                           "total_ms_per_step": sum(ms) / n_inst, "alg_MB": alg[name] / 1e6,
+                           "GBps": alg[name] / (mean_ms * 1e-3) / 1e9}
+        dom = max(table, key=lambda k: table[k]["total_ms_per_step"])
+        sub_ms = sum(table[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in table)
+        sub_bytes = sum(alg[k] * table[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in table)
+        hip_ms = sum(v["total_ms_per_step"] for v in table.values())
+        out["roofline"] = {
+            "bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": table[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "invertible_subset": {"ms_per_step": sub_ms, "alg_GB": sub_bytes / 1e9,
+                                  "GBps": sub_bytes / (sub_ms * 1e-3) / 1e9 if sub_ms else None,
+                                  "frac": sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sub_ms else None},
+            "hip_kernels_ms_per_step": hip_ms, "step_ms": ms_per_step,
+            "kernels": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                        for k, v in sorted(table.items())},
+        }
+
+    # ---- CPU baseline leg: the oracle (a port of the reference path) on this host's cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import glow_oracle as O
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        hp = O.HParams(n_vocab=148, n_blocks_dec=args.blocks)
+        sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict(hp, seed=cfg.seed).items()}
+        oopt = O.AdamNoam(sd, dim_model=hp.hidden_channels)
+        cb = (x.cpu(), x_lengths.cpu(), y.cpu(), y_lengths.cpu(), None)
+        O.train_step(sd, hp, oopt, cb, cfg.grad_clip)                    # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_steps):
+            O.train_step(sd, hp, oopt, cb, cfg.grad_clip)
+        cdt = (time.perf_counter() - t0) / args.cpu_steps
+        out["cpu_baseline"] = {"value": B * T_mel / cdt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+                               "sample": f"{args.cpu_steps} full training steps of the same B={B}, T_mel={T_mel}, "
+                                         f"{args.blocks}-block batch (oracle/glow_oracle.py, torch CPU fp32 + C MAS), "
+                                         f"{cdt:.2f} s/step after 1 warm-up"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+// common.hpp — shared device/host helpers for libglowtts_hip.so (gfx950 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <initializer_list>
+
+#include "glowtts_hip.h"
+
+namespace glowtts {
+
+constexpr int kWave = 64;
+
+void set_error(const char *fmt, ...);
+
+// Every entry point funnels launch errors through here (no sync: hipGetLastError only sees launch-time errors).
+#define GLOWTTS_CHECK_ARG(cond, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::glowtts::set_error(__VA_ARGS__);  \
+            return 1;                           \
+        }                                       \
+    } while (0)
+
+#define GLOWTTS_LAUNCH_CHECK(name)                                                   \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            ::glowtts::set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return (int)e_;                                                          \
+        }                                                                            \
+        return 0;                                                                    \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread workgroup; result valid in thread 0.  `red` = 4 floats of LDS per call site.
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+
+// 16-byte (V = 4) or scalar (V = 1) access along the contiguous T axis.
+template <int V> struct Vec;
+template <> struct Vec<4> {
+    float4 d;
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.d = *reinterpret_cast<const float4 *>(p); return r; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.d = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = d; }
+    __device__ __forceinline__ float &operator[](int i) { return (&d.x)[i]; }
+    __device__ __forceinline__ float operator[](int i) const { return (&d.x)[i]; }
+};
+template <> struct Vec<1> {
+    float d;
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.d = *p; return r; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.d = 0.f; return r; }
+    __device__ __forceinline__ void store(float *p) const { *p = d; }
+    __device__ __forceinline__ float &operator[](int) { return d; }
+    __device__ __forceinline__ float operator[](int) const { return d; }
+};
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// 16-byte path is legal when every row start is 16-B aligned: T % 4 == 0 and all bases aligned.
+static inline bool can_vec4(int T, std::initializer_list<const void *> ptrs) {
+    if (T & 3) return false;
+    for (const void *p : ptrs)
+        if (p && !aligned16(p)) return false;
+    return true;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace glowtts

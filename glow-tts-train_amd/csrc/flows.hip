@@ -1,0 +1,549 @@
+// flows.hip — the invertible, HBM-bound operators of FlowSpecDecoder for gfx950:
+//   ActNorm        (layers.py:182-221)      z = (bias + exp(logs) x) mask
+//   InvConvNear    (layers.py:238-275)      grouped n x n channel mix + log|det W|
+//   affine coupling apply (attentions.py:128-142)
+//
+// All tensors are (B, C, T) fp32 with T contiguous; every kernel reads each input once and writes each output
+// once with 16-byte accesses along T (scalar fall-back when T % 4 != 0 or a pointer is not 16-B aligned).
+// Algorithmic bytes per squeezed column (e = 4): ActNorm 2C e, InvConvNear 2C e, coupling 3C e
+// (2.5C e once z_0 aliases x_0), backward = read grad + input, write grad.
+// Per-channel / per-matrix reductions are wave-shuffle + LDS partial sums followed by ONE float atomic per
+// workgroup and output element (global_atomic_add_f32, executed at the memory side: MI355X_MICROARCH.md).
+#include "common.hpp"
+
+namespace glowtts {
+
+// ------------------------------------------------------------------------------------------------------------
+// mask_len: x_len[b] = sum_t mask[b,t]      one wave per utterance
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mask_len_kernel(const float *__restrict__ mask, float *__restrict__ x_len, int T) {
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 64) s += mask[(size_t)b * T + t];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) x_len[b] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ActNorm
+// ------------------------------------------------------------------------------------------------------------
+template <int V, bool REV>
+__global__ __launch_bounds__(256) void actnorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                          const float *__restrict__ logs, const float *__restrict__ bias,
+                                                          const float *__restrict__ x_len, float *__restrict__ z,
+                                                          float *__restrict__ logdet, int B, int C, int T) {
+    __shared__ float red[4];
+    const int TV = T / V;
+    const long n = (long)B * C * TV;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int tv = (int)(i % TV);
+        const long row = i / TV;
+        const int c = (int)(row % C);
+        const int b = (int)(row / C);
+        const float l = logs[c], bi = bias[c];
+        const float e = expf(REV ? -l : l);
+        Vec<V> xv = Vec<V>::load(x + row * T + (long)tv * V);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = REV ? (xv[j] - bi) * e * mv[j] : (bi + e * xv[j]) * mv[j];
+        o.store(z + row * T + (long)tv * V);
+    }
+    if (!REV && logdet != nullptr && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += logs[c];
+        s = block_sum_256(s, red);
+        for (int b = threadIdx.x; b < B; b += 256) logdet[b] = s * x_len[b];
+    }
+}
+
+// grid (C, NB): workgroup = one channel x a slab of utterances.  dx elementwise + the two per-channel sums.
+template <int V>
+__global__ __launch_bounds__(256) void actnorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                          const float *__restrict__ logs, const float *__restrict__ dz,
+                                                          const float *__restrict__ dlogdet, const float *__restrict__ x_len,
+                                                          float *__restrict__ dx, float *__restrict__ dlogs,
+                                                          float *__restrict__ dbias, int B, int C, int T, int nb) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * nb;
+    const int b1 = min(B, b0 + nb);
+    const int TV = T / V;
+    const float e = expf(logs[c]);
+    float s_logs = 0.f, s_bias = 0.f;
+    const int items = (b1 - b0) * TV;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int b = b0 + i / TV;
+        const int tv = i % TV;
+        const long off = ((long)b * C + c) * T + (long)tv * V;
+        Vec<V> xv = Vec<V>::load(x + off);
+        Vec<V> gv = Vec<V>::load(dz + off);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gm = gv[j] * mv[j];
+            o[j] = gm * e;
+            s_logs += gm * e * xv[j];
+            s_bias += gm;
+        }
+        o.store(dx + off);
+    }
+    if (blockIdx.y == 0 && dlogdet != nullptr) {
+        for (int b = threadIdx.x; b < B; b += 256) s_logs += dlogdet[b] * x_len[b];
+    }
+    s_logs = block_sum_256(s_logs, red);
+    s_bias = block_sum_256(s_bias, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(dlogs + c, s_logs);
+        atomicAdd(dbias + c, s_bias);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void actnorm_stats_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                            float *__restrict__ sum_x, float *__restrict__ sum_x2, int B,
+                                                            int C, int T, int nb) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int b0 = blockIdx.y * nb;
+    const int b1 = min(B, b0 + nb);
+    const int TV = T / V;
+    float s1 = 0.f, s2 = 0.f;
+    const int items = (b1 - b0) * TV;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const int b = b0 + i / TV;
+        const int tv = i % TV;
+        Vec<V> xv = Vec<V>::load(x + ((long)b * C + c) * T + (long)tv * V);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            s1 += xv[j] * mv[j];
+            s2 += xv[j] * xv[j] * mv[j];
+        }
+    }
+    s1 = block_sum_256(s1, red);
+    s2 = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(sum_x + c, s1);
+        atomicAdd(sum_x2 + c, s2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// InvConvNear
+// ------------------------------------------------------------------------------------------------------------
+// One wavefront: lane (r, c) = (lane >> 3, lane & 7) holds A[r][c] and Inv[r][c] of an 8x8 frame whose top-left
+// n x n block is W (identity elsewhere).  Gauss-Jordan with partial pivoting, rows exchanged by lane shuffles;
+// fp64 internally (a few hundred flops), so log|det| and W^-1 are at least as accurate as torch's fp32 LU.
+__global__ __launch_bounds__(64) void invconv_prepare_kernel(const float *__restrict__ w, float *__restrict__ w_inv,
+                                                             float *__restrict__ logdet_w, int n) {
+    const int lane = threadIdx.x;
+    const int r = lane >> 3, c = lane & 7;
+    double a = (r < n && c < n) ? (double)w[r * n + c] : (r == c ? 1.0 : 0.0);
+    double inv = (r == c) ? 1.0 : 0.0;
+    double logabs = 0.0;
+    int neg = 0;
+    for (int k = 0; k < n; ++k) {
+        // pivot: row p >= k maximising |A[p][k]|
+        double colv = __shfl(a, (r << 3) + k, 64);
+        double best = (r >= k) ? fabs(colv) : -1.0;
+        int brow = r;
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            double ob = __shfl_xor(best, off, 64);
+            int orow = __shfl_xor(brow, off, 64);
+            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+        }
+        const int p = brow;  // uniform
+        const int src_row = (r == k) ? p : ((r == p) ? k : r);
+        a = __shfl(a, (src_row << 3) + c, 64);
+        inv = __shfl(inv, (src_row << 3) + c, 64);
+        if (p != k) neg ^= 1;
+        const double piv = __shfl(a, (k << 3) + k, 64);
+        logabs += log(fabs(piv));
+        if (piv < 0.0) neg ^= 1;
+        const double rk_a = __shfl(a, (k << 3) + c, 64) / piv;
+        const double rk_i = __shfl(inv, (k << 3) + c, 64) / piv;
+        const double f = __shfl(a, (r << 3) + k, 64);
+        if (r == k) { a = rk_a; inv = rk_i; }
+        else        { a -= f * rk_a; inv -= f * rk_i; }
+    }
+    if (r < n && c < n) w_inv[r * n + c] = (float)inv;
+    if (lane == 0) logdet_w[0] = neg ? __builtin_nanf("") : (float)logabs;
+}
+
+// channel of row k (k = h*(N/2)+s) in group g:  h*(C/2) + g*(N/2) + s      (layers.py:247-252)
+template <int N>
+__device__ __forceinline__ int invconv_channel(int k, int g, int C) {
+    return (k / (N / 2)) * (C / 2) + g * (N / 2) + (k % (N / 2));
+}
+
+template <int N, int V>
+__global__ __launch_bounds__(256) void invconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                          const float *__restrict__ w, const float *__restrict__ logdet_w,
+                                                          const float *__restrict__ x_len, float *__restrict__ z,
+                                                          float *__restrict__ logdet, int B, int C, int T) {
+    const int TV = T / V;
+    const int G = C / N;
+    const long n = (long)B * G * TV;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int tv = (int)(i % TV);
+        const long bg = i / TV;
+        const int g = (int)(bg % G);
+        const int b = (int)(bg / G);
+        float wr[N * N];
+#pragma unroll
+        for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+        Vec<V> xin[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            xin[k] = Vec<V>::load(x + ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            Vec<V> acc;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s += wr[o * N + k] * xin[k][j];
+                acc[j] = s * mv[j];
+            }
+            acc.store(z + ((long)b * C + invconv_channel<N>(o, g, C)) * T + (long)tv * V);
+        }
+    }
+    if (logdet != nullptr && blockIdx.x == 0) {
+        const float ld = logdet_w[0] * (float)(C / N);
+        for (int b = threadIdx.x; b < B; b += 256) logdet[b] = ld * x_len[b];
+    }
+}
+
+template <int N, int V>
+__global__ __launch_bounds__(256) void invconv_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                          const float *__restrict__ w, const float *__restrict__ w_inv,
+                                                          const float *__restrict__ dz, const float *__restrict__ dlogdet,
+                                                          const float *__restrict__ x_len, float *__restrict__ dx,
+                                                          float *__restrict__ dw, int B, int C, int T) {
+    __shared__ float red[4][N * N];
+    const int TV = T / V;
+    const int G = C / N;
+    const long n = (long)B * G * TV;
+    float wr[N * N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+    float acc[N * N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) acc[q] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int tv = (int)(i % TV);
+        const long bg = i / TV;
+        const int g = (int)(bg % G);
+        const int b = (int)(bg / G);
+        Vec<V> xin[N], gz[N];
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const long off = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
+            xin[k] = Vec<V>::load(x + off);
+            gz[k] = Vec<V>::load(dz + off);
+#pragma unroll
+            for (int j = 0; j < V; ++j) gz[k][j] *= mv[j];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            Vec<V> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < N; ++oo) s += wr[oo * N + k] * gz[oo][j];
+                o[j] = s;
+            }
+            o.store(dx + ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V);
+        }
+#pragma unroll
+        for (int oo = 0; oo < N; ++oo)
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[oo * N + k] += gz[oo][j] * xin[k][j];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) {
+        const float s = wave_sum(acc[q]);
+        if (lane == 0) red[wave][q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < N * N) {
+        const int q = threadIdx.x;
+        float s = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        if (blockIdx.x == 0 && dlogdet != nullptr) {
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += dlogdet[b] * x_len[b];
+            const int o = q / N, k = q % N;
+            s += w_inv[k * N + o] * (float)(C / N) * t;  // d logdet(W) / dW = W^-T
+        }
+        atomicAdd(dw + q, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// affine coupling apply
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float coupling_logs(float raw, bool sig) {
+    return sig ? logf(1e-6f + sigmoidf_(raw + 2.0f)) : raw;
+}
+
+// grid (chunks, B): each workgroup stays inside one utterance so logdet[b] takes one atomic per workgroup.
+template <int V, bool REV>
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(const float *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ mask, float *__restrict__ z,
+                                                           float *__restrict__ logdet, int C, int T, int sig) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int TV = T / V;
+    const int half = C / 2;
+    const int items = half * TV;
+    float ld = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < items; i += gridDim.x * 256) {
+        const int c = i / TV, tv = i % TV;
+        const long o0 = ((long)b * C + c) * T + (long)tv * V;
+        const long o1 = o0 + (long)half * T;
+        Vec<V> x0 = Vec<V>::load(x + o0);
+        Vec<V> x1 = Vec<V>::load(x + o1);
+        Vec<V> m = Vec<V>::load(out + o0);
+        Vec<V> lr = Vec<V>::load(out + o1);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> z1;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float l = coupling_logs(lr[j], sig != 0);
+            if (REV) {
+                z1[j] = (x1[j] - m[j]) * expf(-l) * mv[j];
+            } else {
+                z1[j] = (m[j] + expf(l) * x1[j]) * mv[j];
+                ld += l * mv[j];
+            }
+        }
+        x0.store(z + o0);
+        z1.store(z + o1);
+    }
+    if (!REV) {
+        ld = block_sum_256(ld, red);
+        if (threadIdx.x == 0) atomicAdd(logdet + b, ld);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void coupling_bwd_kernel(const float *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ mask, const float *__restrict__ dz,
+                                                           const float *__restrict__ dlogdet, float *__restrict__ dx,
+                                                           float *__restrict__ dout, int C, int T, int sig) {
+    const int b = blockIdx.y;
+    const int TV = T / V;
+    const int half = C / 2;
+    const int items = half * TV;
+    const float dld = dlogdet ? dlogdet[b] : 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < items; i += gridDim.x * 256) {
+        const int c = i / TV, tv = i % TV;
+        const long o0 = ((long)b * C + c) * T + (long)tv * V;
+        const long o1 = o0 + (long)half * T;
+        Vec<V> x1 = Vec<V>::load(x + o1);
+        Vec<V> lr = Vec<V>::load(out + o1);
+        Vec<V> g0 = Vec<V>::load(dz + o0);
+        Vec<V> g1 = Vec<V>::load(dz + o1);
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> dx1, dm, dl;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float l = coupling_logs(lr[j], sig != 0);
+            const float e = expf(l);
+            const float gm = g1[j] * mv[j];
+            dx1[j] = gm * e;
+            dm[j] = gm;
+            float dlp = (gm * e * x1[j]) + dld * mv[j];      // d / d logs'
+            if (sig) {
+                // logs' = log(1e-6 + s), s = sigmoid(raw + 2):  dlogs'/draw = s (1 - s) / (1e-6 + s)
+                const float s = sigmoidf_(lr[j] + 2.0f);
+                dlp *= s * (1.0f - s) / (1e-6f + s);
+            }
+            dl[j] = dlp;
+        }
+        g0.store(dx + o0);
+        dx1.store(dx + o1);
+        dm.store(dout + o0);
+        dl.store(dout + o1);
+    }
+}
+
+}  // namespace glowtts
+
+// ================================================================================================================
+// C ABI
+// ================================================================================================================
+using namespace glowtts;
+
+extern "C" int glowtts_mask_len(const float *mask, float *x_len, int B, int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(mask && x_len && B >= 0 && T >= 0, "glowtts_mask_len: bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(mask_len_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mask, x_len, T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mask_len");
+}
+
+extern "C" int glowtts_actnorm_fwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                   const float *x_len, float *z, float *logdet, int B, int C, int T, int reverse,
+                                   glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && logs && bias && z, "glowtts_actnorm_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_actnorm_fwd: bad shape (%d,%d,%d)", B, C, T);
+    GLOWTTS_CHECK_ARG(reverse || !logdet || x_len, "glowtts_actnorm_fwd: logdet requested without x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, mask, z});
+    const long n = (long)B * C * (v4 ? T / 4 : T);
+    const int grid = cdiv(n, 256);
+    if (reverse) {
+        if (v4) hipLaunchKernelGGL((actnorm_fwd_kernel<4, true>), dim3(grid), dim3(256), 0, s, x, mask, logs, bias, x_len, z, logdet, B, C, T);
+        else    hipLaunchKernelGGL((actnorm_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, s, x, mask, logs, bias, x_len, z, logdet, B, C, T);
+    } else {
+        if (v4) hipLaunchKernelGGL((actnorm_fwd_kernel<4, false>), dim3(grid), dim3(256), 0, s, x, mask, logs, bias, x_len, z, logdet, B, C, T);
+        else    hipLaunchKernelGGL((actnorm_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, s, x, mask, logs, bias, x_len, z, logdet, B, C, T);
+    }
+    GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_fwd");
+}
+
+static inline int slab_size(int B, int C) {
+    // enough workgroups to fill 256 CUs several times over, at least one utterance per workgroup
+    int nbk = (2048 + C - 1) / C;
+    if (nbk > B) nbk = B;
+    if (nbk < 1) nbk = 1;
+    return (B + nbk - 1) / nbk;
+}
+
+extern "C" int glowtts_actnorm_bwd(const float *x, const float *mask, const float *logs, const float *dz,
+                                   const float *dlogdet, const float *x_len, float *dx, float *dlogs, float *dbias,
+                                   int B, int C, int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && logs && dz && dx && dlogs && dbias, "glowtts_actnorm_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_actnorm_bwd: bad shape");
+    GLOWTTS_CHECK_ARG(!dlogdet || x_len, "glowtts_actnorm_bwd: dlogdet given without x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = slab_size(B, C);
+    dim3 grid(C, (B + nb - 1) / nb);
+    if (can_vec4(T, {x, mask, dz, dx}))
+        hipLaunchKernelGGL((actnorm_bwd_kernel<4>), grid, dim3(256), 0, s, x, mask, logs, dz, dlogdet, x_len, dx, dlogs, dbias, B, C, T, nb);
+    else
+        hipLaunchKernelGGL((actnorm_bwd_kernel<1>), grid, dim3(256), 0, s, x, mask, logs, dz, dlogdet, x_len, dx, dlogs, dbias, B, C, T, nb);
+    GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_bwd");
+}
+
+extern "C" int glowtts_actnorm_stats(const float *x, const float *mask, float *sum_x, float *sum_x2, int B, int C,
+                                     int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && sum_x && sum_x2, "glowtts_actnorm_stats: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_actnorm_stats: bad shape");
+    if ((long)B * C * T == 0) return 0;
+    const int nb = slab_size(B, C);
+    dim3 grid(C, (B + nb - 1) / nb);
+    if (can_vec4(T, {x, mask}))
+        hipLaunchKernelGGL((actnorm_stats_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, x, mask, sum_x, sum_x2, B, C, T, nb);
+    else
+        hipLaunchKernelGGL((actnorm_stats_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, mask, sum_x, sum_x2, B, C, T, nb);
+    GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_stats");
+}
+
+extern "C" int glowtts_invconv_prepare(const float *w, float *w_inv, float *logdet_w, int n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(w && w_inv && logdet_w, "glowtts_invconv_prepare: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 1 && n <= 8, "glowtts_invconv_prepare: n_split=%d not in [1,8]", n);
+    hipLaunchKernelGGL(invconv_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
+    GLOWTTS_LAUNCH_CHECK("glowtts_invconv_prepare");
+}
+
+#define INVCONV_DISPATCH(KERNEL, GRID, ...)                                                              \
+    do {                                                                                                 \
+        if (n_split == 4) {                                                                              \
+            if (v4) hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+            else    hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        } else if (n_split == 2) {                                                                       \
+            if (v4) hipLaunchKernelGGL((KERNEL<2, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+            else    hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        } else {                                                                                         \
+            if (v4) hipLaunchKernelGGL((KERNEL<8, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+            else    hipLaunchKernelGGL((KERNEL<8, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        }                                                                                                \
+    } while (0)
+
+extern "C" int glowtts_invconv_fwd(const float *x, const float *mask, const float *w, const float *logdet_w,
+                                   const float *x_len, float *z, float *logdet, int B, int C, int T, int n_split,
+                                   glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && w && z, "glowtts_invconv_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4 || n_split == 8, "glowtts_invconv_fwd: n_split=%d (supported: 2, 4, 8)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_invconv_fwd: C=%d not divisible by n_split=%d", C, n_split);
+    GLOWTTS_CHECK_ARG(!logdet || (logdet_w && x_len), "glowtts_invconv_fwd: logdet requested without logdet_w/x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, mask, z});
+    const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
+    dim3 grid(cdiv(n, 256));
+    INVCONV_DISPATCH(invconv_fwd_kernel, grid, x, mask, w, logdet_w, x_len, z, logdet, B, C, T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_invconv_fwd");
+}
+
+extern "C" int glowtts_invconv_bwd(const float *x, const float *mask, const float *w, const float *w_inv,
+                                   const float *dz, const float *dlogdet, const float *x_len, float *dx, float *dw,
+                                   int B, int C, int T, int n_split, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && w && dz && dx && dw, "glowtts_invconv_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4 || n_split == 8, "glowtts_invconv_bwd: n_split=%d (supported: 2, 4, 8)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_invconv_bwd: bad shape");
+    GLOWTTS_CHECK_ARG(!dlogdet || (w_inv && x_len), "glowtts_invconv_bwd: dlogdet given without w_inv/x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, mask, dz, dx});
+    const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
+    int g = cdiv(n, 256);
+    if (g > 1024) g = 1024;
+    dim3 grid(g);
+    INVCONV_DISPATCH(invconv_bwd_kernel, grid, x, mask, w, w_inv, dz, dlogdet, x_len, dx, dw, B, C, T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_invconv_bwd");
+}
+
+extern "C" int glowtts_coupling_fwd(const float *x, const float *out, const float *mask, float *z, float *logdet,
+                                    int B, int C, int T, int sigmoid_scale, int reverse, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && out && mask && z, "glowtts_coupling_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(reverse || logdet, "glowtts_coupling_fwd: forward needs logdet");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && (C % 2) == 0 && T >= 0, "glowtts_coupling_fwd: bad shape");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, out, mask, z});
+    const long items = (long)(C / 2) * (v4 ? T / 4 : T);
+    int gx = cdiv(items, 256);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, B);
+    if (reverse) {
+        if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, true>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
+        else    hipLaunchKernelGGL((coupling_fwd_kernel<1, true>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
+    } else {
+        if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, false>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
+        else    hipLaunchKernelGGL((coupling_fwd_kernel<1, false>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
+    }
+    GLOWTTS_LAUNCH_CHECK("glowtts_coupling_fwd");
+}
+
+extern "C" int glowtts_coupling_bwd(const float *x, const float *out, const float *mask, const float *dz,
+                                    const float *dlogdet, float *dx, float *dout, int B, int C, int T,
+                                    int sigmoid_scale, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && out && mask && dz && dx && dout, "glowtts_coupling_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && (C % 2) == 0 && T >= 0, "glowtts_coupling_bwd: bad shape");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, out, mask, dz, dx, dout});
+    const long items = (long)(C / 2) * (v4 ? T / 4 : T);
+    int gx = cdiv(items, 256);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, B);
+    if (v4) hipLaunchKernelGGL((coupling_bwd_kernel<4>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
+    else    hipLaunchKernelGGL((coupling_bwd_kernel<1>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
+    GLOWTTS_LAUNCH_CHECK("glowtts_coupling_bwd");
+}

@@ -1,0 +1,256 @@
+// train_ops.hip — the remaining HBM-bound pieces of the training step for gfx950:
+//   squeeze / unsqueeze                    (utils.py:135-160)
+//   mle_loss forward reduction + backward  (utils.py:14-23)
+//   clip_grad_value_ over a flat buffer    (utils.py:118-132)   — replaces one .item() host sync PER PARAMETER TENSOR
+//   Adam + Noam schedule over flat buffers (optimize.py:8-64)   — learning rate derived on device from a step
+//                                                                  counter, so the whole step is hipGraph-capturable
+#include "common.hpp"
+
+namespace glowtts {
+
+// ------------------------------------------------------------------------------------------------------------
+// squeeze: thread -> (b, c, t'), reads n consecutive frames (8 B for n = 2), writes n rows (each coalesced in t').
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void squeeze_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                      float *__restrict__ xs, float *__restrict__ ms, int B, int C, int T,
+                                                      int n) {
+    const int Ts = T / n;
+    const long total = (long)B * C * Ts;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ts = (int)(i % Ts);
+    const long row = i / Ts;
+    const int c = (int)(row % C);
+    const int b = (int)(row / C);
+    const float m = mask ? mask[(long)b * T + (long)ts * n + (n - 1)] : 1.0f;
+    const float *src = x + row * T + (long)ts * n;
+    for (int s = 0; s < n; ++s) xs[((long)b * n * C + (long)s * C + c) * Ts + ts] = src[s] * m;
+    if (c == 0 && ms) ms[(long)b * Ts + ts] = m;
+}
+
+__global__ __launch_bounds__(256) void unsqueeze_kernel(const float *__restrict__ xs, const float *__restrict__ ms,
+                                                        float *__restrict__ x, float *__restrict__ mask_out, int B, int C,
+                                                        int Ts, int n) {
+    const long total = (long)B * C * Ts;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ts = (int)(i % Ts);
+    const long row = i / Ts;
+    const int c = (int)(row % C);
+    const int b = (int)(row / C);
+    const float m = ms ? ms[(long)b * Ts + ts] : 1.0f;
+    float *dst = x + row * (long)Ts * n + (long)ts * n;
+    for (int s = 0; s < n; ++s) dst[s] = xs[((long)b * n * C + (long)s * C + c) * Ts + ts] * m;
+    if (c == 0 && mask_out)
+        for (int s = 0; s < n; ++s) mask_out[(long)b * Ts * n + (long)ts * n + s] = m;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// mle_loss
+// ------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void mle_fwd_kernel(const float *__restrict__ z, const float *__restrict__ m,
+                                                      const float *__restrict__ logs, const float *__restrict__ mask,
+                                                      float *__restrict__ acc, long nv, long nmask) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        Vec<V> zv = Vec<V>::load(z + i * V);
+        Vec<V> mv = Vec<V>::load(m + i * V);
+        Vec<V> lv = Vec<V>::load(logs + i * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float d = zv[j] - mv[j];
+            s += lv[j] + 0.5f * expf(-2.0f * lv[j]) * d * d;
+        }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+    if (blockIdx.x == 0) {
+        float t = 0.f;
+        for (long i = threadIdx.x; i < nmask; i += 256) t += mask[i];
+        t = block_sum_256(t, red);
+        if (threadIdx.x == 0) atomicAdd(acc + 1, t);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void mle_bwd_kernel(const float *__restrict__ z, const float *__restrict__ m,
+                                                      const float *__restrict__ logs, const float *__restrict__ scale,
+                                                      float *__restrict__ dz, float *__restrict__ dm,
+                                                      float *__restrict__ dlogs, long nv) {
+    const float sc = scale[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        Vec<V> zv = Vec<V>::load(z + i * V);
+        Vec<V> mv = Vec<V>::load(m + i * V);
+        Vec<V> lv = Vec<V>::load(logs + i * V);
+        Vec<V> gz, gm, gl;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float d = zv[j] - mv[j];
+            const float e = expf(-2.0f * lv[j]);
+            gz[j] = sc * e * d;
+            gm[j] = -gz[j];
+            gl[j] = sc * (1.0f - e * d * d);
+        }
+        gz.store(dz + i * V);
+        gm.store(dm + i * V);
+        gl.store(dlogs + i * V);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// clip + Adam/Noam on flat buffers
+// ------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void clip_kernel(float *__restrict__ g, long nv, float clip, float *__restrict__ sumsq) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        Vec<V> gv = Vec<V>::load(g + i * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            s += gv[j] * gv[j];
+            gv[j] = fminf(fmaxf(gv[j], -clip), clip);
+        }
+        gv.store(g + i * V);
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0 && sumsq) atomicAdd(sumsq, s);
+}
+
+__device__ __forceinline__ float noam_rate(float step, float lr, float dim_model, float warmup) {
+    if (warmup <= 0.f) return lr;
+    // optimize.py:32-41 — lr * d^-0.5 * min(s^-0.5, s * w^-1.5); fp64 like the reference's numpy arithmetic
+    const double s = (double)step;
+    const double a = 1.0 / sqrt(s);
+    const double b = s * pow((double)warmup, -1.5);
+    return (float)((double)lr * (1.0 / sqrt((double)dim_model)) * (a < b ? a : b));
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, long nv, const float *__restrict__ state, float lr,
+                                                   float b1, float b2, float eps, float dim_model, float warmup) {
+    // torch.optim.Adam (no amsgrad, no weight decay): step_size = lr_t / (1 - b1^t); denom = sqrt(v)/sqrt(1 - b2^t) + eps
+    const float t = state[0];
+    const float lr_t = noam_rate(state[1], lr, dim_model, warmup);
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr_t / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        Vec<V> pv = Vec<V>::load(p + i * V);
+        Vec<V> gv = Vec<V>::load(g + i * V);
+        Vec<V> mv = Vec<V>::load(m + i * V);
+        Vec<V> vv = Vec<V>::load(v + i * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            mv[j] = b1 * mv[j] + (1.0f - b1) * gv[j];
+            vv[j] = b2 * vv[j] + (1.0f - b2) * gv[j] * gv[j];
+            const float denom = sqrtf(vv[j]) * inv_sqrt_bc2 + eps;
+            pv[j] -= step_size * (mv[j] / denom);
+        }
+        pv.store(p + i * V);
+        mv.store(m + i * V);
+        vv.store(v + i * V);
+    }
+}
+
+__global__ void adam_advance_kernel(float *state, float lr, float dim_model, float warmup) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state[0] += 1.0f;
+        state[1] += 1.0f;
+        state[2] = noam_rate(state[1], lr, dim_model, warmup);
+    }
+}
+
+static inline int stream_grid(long nv) {
+    long g = (nv + 255) / 256;
+    if (g > 2048) g = 2048;   // 256 CUs x 8 workgroups, grid-stride the rest (cdna_hip_programming.md G11)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace glowtts
+
+using namespace glowtts;
+
+extern "C" int glowtts_squeeze(const float *x, const float *mask, float *xs, float *ms, int B, int C, int T, int n,
+                               glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && xs, "glowtts_squeeze: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && n >= 1, "glowtts_squeeze: bad shape");
+    const long total = (long)B * C * (T / n);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(squeeze_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xs, ms, B, C, T, n);
+    GLOWTTS_LAUNCH_CHECK("glowtts_squeeze");
+}
+
+extern "C" int glowtts_unsqueeze(const float *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq,
+                                 int n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(xs && x, "glowtts_unsqueeze: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && Tsq >= 0 && n >= 1, "glowtts_unsqueeze: bad shape");
+    const long total = (long)B * C * Tsq;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(unsqueeze_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xs, ms, x, mask_out, B, C, Tsq, n);
+    GLOWTTS_LAUNCH_CHECK("glowtts_unsqueeze");
+}
+
+extern "C" int glowtts_mle_fwd(const float *z, const float *m, const float *logs, const float *mask, float *acc,
+                               int B, int C, int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(z && m && logs && mask && acc, "glowtts_mle_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_mle_fwd: bad shape");
+    const long n = (long)B * C * T;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0 && aligned16(z) && aligned16(m) && aligned16(logs))
+        hipLaunchKernelGGL((mle_fwd_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, z, m, logs, mask, acc, n / 4, (long)B * T);
+    else
+        hipLaunchKernelGGL((mle_fwd_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, z, m, logs, mask, acc, n, (long)B * T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mle_fwd");
+}
+
+extern "C" int glowtts_mle_bwd(const float *z, const float *m, const float *logs, const float *scale, float *dz,
+                               float *dm, float *dlogs, int64_t n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(z && m && logs && scale && dz && dm && dlogs, "glowtts_mle_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 0, "glowtts_mle_bwd: negative size");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0 && aligned16(z) && aligned16(m) && aligned16(logs) && aligned16(dz) && aligned16(dm) && aligned16(dlogs))
+        hipLaunchKernelGGL((mle_bwd_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, z, m, logs, scale, dz, dm, dlogs, (long)(n / 4));
+    else
+        hipLaunchKernelGGL((mle_bwd_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, z, m, logs, scale, dz, dm, dlogs, (long)n);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mle_bwd");
+}
+
+extern "C" int glowtts_clip_grad_value(float *g, int64_t n, float clip, float *sumsq, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(g, "glowtts_clip_grad_value: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 0 && clip >= 0.f, "glowtts_clip_grad_value: bad argument");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0 && aligned16(g))
+        hipLaunchKernelGGL((clip_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, g, (long)(n / 4), clip, sumsq);
+    else
+        hipLaunchKernelGGL((clip_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, g, (long)n, clip, sumsq);
+    GLOWTTS_LAUNCH_CHECK("glowtts_clip_grad_value");
+}
+
+extern "C" int glowtts_adam_noam(float *p, const float *g, float *m, float *v, int64_t n, const float *state,
+                                 float lr, float beta1, float beta2, float eps, float dim_model, float warmup,
+                                 glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(p && g && m && v && state, "glowtts_adam_noam: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 0, "glowtts_adam_noam: negative size");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v))
+        hipLaunchKernelGGL((adam_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, p, g, m, v, (long)(n / 4), state, lr, beta1, beta2, eps, dim_model, warmup);
+    else
+        hipLaunchKernelGGL((adam_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, p, g, m, v, (long)n, state, lr, beta1, beta2, eps, dim_model, warmup);
+    GLOWTTS_LAUNCH_CHECK("glowtts_adam_noam");
+}
+
+extern "C" int glowtts_adam_advance(float *state, float lr, float dim_model, float warmup, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(state, "glowtts_adam_advance: null pointer");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, dim_model, warmup);
+    GLOWTTS_LAUNCH_CHECK("glowtts_adam_advance");
+}

@@ -1,0 +1,137 @@
+"""ctypes binding of libglowtts_hip.so (include/glowtts_hip.h) — the only way the Python host reaches the GPU kernels.
+
+PyTorch is used for device memory (``tensor.data_ptr()``) and streams (``torch.cuda.current_stream()``); the
+kernels themselves are the hand-written HIP in ``glow-tts-train_amd/csrc``.  There is NO fallback: if the library
+is missing, or a tensor handed to an operator is not a contiguous fp32 CUDA/HIP tensor, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get(
+    "GLOWTTS_HIP_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libglowtts_hip.so")
+)
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argument ctypes (every function returns int; the trailing stream argument is appended automatically)
+_SIGNATURES = {
+    "glowtts_mas_path": [_P, _P, _P, _P, _I, _I, _I],
+    "glowtts_mask_len": [_P, _P, _I, _I],
+    "glowtts_actnorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_actnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_actnorm_stats": [_P, _P, _P, _P, _I, _I, _I],
+    "glowtts_invconv_prepare": [_P, _P, _P, _I],
+    "glowtts_invconv_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_invconv_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_coupling_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "glowtts_coupling_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_gate_fwd": [_P, _P, _P, _I, _I, _I],
+    "glowtts_gate_bwd": [_P, _P, _P, _P, _I, _I, _I],
+    "glowtts_res_skip_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_res_skip_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_squeeze": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_unsqueeze": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_mle_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_mle_bwd": [_P, _P, _P, _P, _P, _P, _P, _L],
+    "glowtts_clip_grad_value": [_P, _L, _F, _P],
+    "glowtts_adam_noam": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F],
+    "glowtts_adam_advance": [_P, _F, _F, _F],
+}
+
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version"])
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the C-ABI library.  Raises HipLibraryMissing — never falls back to another path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryMissing(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU or eager fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.glowtts_last_error.restype = ctypes.c_char_p
+    lib.glowtts_last_error.argtypes = []
+    lib.glowtts_abi_version.restype = _I
+    lib.glowtts_abi_version.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = list(args) + [_P]
+    _lib = lib
+    return lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(
+            "glow_tts_train (MI355X build): operator received a CPU tensor; this package runs only on HIP devices"
+        )
+    if not t.is_contiguous():
+        raise RuntimeError("glow_tts_train: non-contiguous tensor passed to a HIP kernel")
+    return t.data_ptr()
+
+
+def f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"glow_tts_train: HIP kernels are fp32, got {t.dtype}")
+    return t
+
+
+# Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).  Off by
+# default: the product path records nothing.
+_timing: Optional[dict] = None
+
+
+def enable_timing() -> None:
+    global _timing
+    _timing = {}
+
+
+def disable_timing() -> dict:
+    """Stop timing and return {name: [milliseconds per launch, ...]} (synchronises once to read the events)."""
+    global _timing
+    t, _timing = _timing or {}, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in t.items()}
+
+
+def call(name: str, *args) -> None:
+    """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure."""
+    lib = load()
+    cur = torch.cuda.current_stream()
+    if _timing is not None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(cur)
+        rc = getattr(lib, name)(*args, cur.cuda_stream)
+        b.record(cur)
+        _timing.setdefault(name, []).append((a, b))
+    else:
+        rc = getattr(lib, name)(*args, cur.cuda_stream)
+    if rc != 0:
+        msg = lib.glowtts_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")

@@ -1,0 +1,171 @@
+"""Text-encoder transformer stack and the affine coupling flow, with the reference's names, constructor arguments
+and state-dict keys (reference: glow_tts_train/attentions.py).
+"""
+from __future__ import annotations
+
+import math
+import typing
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .layers import WN, LayerNorm
+
+
+class Encoder(nn.Module):
+    """Post-LN transformer layers over (B, H, T_text) (reference attentions.py:12-74)."""
+
+    def __init__(self, hidden_channels: int, filter_channels: int, n_heads: int, n_layers: int, kernel_size: int = 1,
+                 p_dropout: float = 0.0, window_size: typing.Optional[int] = None,
+                 block_length: typing.Optional[int] = None):
+        super().__init__()
+        self.hidden_channels, self.filter_channels = hidden_channels, filter_channels
+        self.n_heads, self.n_layers, self.kernel_size = n_heads, n_layers, kernel_size
+        self.p_dropout, self.window_size, self.block_length = p_dropout, window_size, block_length
+        self.drop = nn.Dropout(p_dropout)
+        self.attn_layers = nn.ModuleList(
+            MultiHeadAttention(hidden_channels, hidden_channels, n_heads, window_size=window_size, p_dropout=p_dropout,
+                               block_length=block_length) for _ in range(n_layers))
+        self.norm_layers_1 = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(n_layers))
+        self.ffn_layers = nn.ModuleList(
+            FFN(hidden_channels, hidden_channels, filter_channels, kernel_size, p_dropout=p_dropout)
+            for _ in range(n_layers))
+        self.norm_layers_2 = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(n_layers))
+
+    def forward(self, x, x_mask):
+        pair_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+        for attn, norm1, ffn, norm2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
+            x = x * x_mask
+            x = norm1(x + self.drop(attn(x, x, pair_mask)))
+            x = norm2(x + self.drop(ffn(x, x_mask)))
+        return x * x_mask
+
+
+class CouplingBlock(nn.Module):
+    """Affine coupling flow (reference attentions.py:77-145): (m, logs) = end(WN(start(x_0))); z_1 = (m + e^logs x_1) mask.
+
+    The affine apply + log-det reduction is one HIP kernel writing z directly (no slice / exp / mul / cat chain).
+    """
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0,
+                 sigmoid_scale=False):
+        super().__init__()
+        self.in_channels, self.hidden_channels, self.kernel_size = in_channels, hidden_channels, kernel_size
+        self.dilation_rate, self.n_layers, self.gin_channels = dilation_rate, n_layers, gin_channels
+        self.p_dropout, self.sigmoid_scale = p_dropout, sigmoid_scale
+        self.start = torch.nn.utils.weight_norm(nn.Conv1d(in_channels // 2, hidden_channels, 1))
+        # zero-initialised last layer: the coupling starts as the identity, which stabilises early training
+        self.end = nn.Conv1d(hidden_channels, in_channels, 1)
+        nn.init.zeros_(self.end.weight)
+        nn.init.zeros_(self.end.bias)
+        self.wn = WN(in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, p_dropout)
+
+    def forward(self, x, x_mask=None, reverse: bool = False, g=None, **kwargs):
+        if x_mask is None:
+            x_mask = torch.ones(x.size(0), 1, x.size(2), device=x.device, dtype=x.dtype)
+        m2 = ops.mask2d(x_mask)
+        h = self.start(x[:, : self.in_channels // 2]) * x_mask
+        h = self.wn(h, x_mask, g, m2=m2)
+        out = self.end(h)
+        if reverse:
+            return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
+        return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale)
+
+    def store_inverse(self):
+        self.wn.remove_weight_norm()
+
+
+class MultiHeadAttention(nn.Module):
+    """Self-attention with windowed relative-position keys/values shared across heads (reference attentions.py:148-344).
+
+    The relative terms are stated by index: scores[i,j] += q_i . E_k[j-i+w] and out_i += p_ij E_v[j-i+w] for |j-i| <= w,
+    instead of the reference's pad / reshape skewing of (T, 2T-1) matrices.
+    """
+
+    def __init__(self, channels: int, out_channels: int, n_heads: int, window_size: typing.Optional[int] = None,
+                 heads_share: bool = True, p_dropout: float = 0.0, block_length: typing.Optional[int] = None,
+                 proximal_bias: bool = False, proximal_init: bool = False):
+        super().__init__()
+        assert channels % n_heads == 0
+        self.channels, self.out_channels, self.n_heads = channels, out_channels, n_heads
+        self.window_size, self.heads_share, self.block_length = window_size, heads_share, block_length
+        self.proximal_bias, self.p_dropout = proximal_bias, p_dropout
+        self.attn = None
+        self.k_channels = channels // n_heads
+        self.conv_q = nn.Conv1d(channels, channels, 1)
+        self.conv_k = nn.Conv1d(channels, channels, 1)
+        self.conv_v = nn.Conv1d(channels, channels, 1)
+        if window_size is not None:
+            n_rel = 1 if heads_share else n_heads
+            std = self.k_channels ** -0.5
+            self.emb_rel_k = nn.Parameter(torch.randn(n_rel, 2 * window_size + 1, self.k_channels) * std)
+            self.emb_rel_v = nn.Parameter(torch.randn(n_rel, 2 * window_size + 1, self.k_channels) * std)
+        self.conv_o = nn.Conv1d(channels, out_channels, 1)
+        self.drop = nn.Dropout(p_dropout)
+        for conv in (self.conv_q, self.conv_k, self.conv_v):
+            nn.init.xavier_uniform_(conv.weight)
+        if proximal_init:
+            self.conv_k.weight.data.copy_(self.conv_q.weight.data)
+            self.conv_k.bias.data.copy_(self.conv_q.bias.data)
+
+    def forward(self, x, c, attn_mask=None):
+        q, k, v = self.conv_q(x), self.conv_k(c), self.conv_v(c)
+        y, self.attn = self.attention(q, k, v, mask=attn_mask)
+        return self.conv_o(y)
+
+    def attention(self, query, key, value, mask=None):
+        b, d, t_s = key.size()
+        t_t = query.size(2)
+        nh, dk, w = self.n_heads, self.k_channels, self.window_size
+        q = query.view(b, nh, dk, t_t).transpose(2, 3)
+        k = key.view(b, nh, dk, t_s).transpose(2, 3)
+        v = value.view(b, nh, dk, t_s).transpose(2, 3)
+        scale = 1.0 / math.sqrt(dk)
+        scores = torch.matmul(q, k.transpose(-2, -1)) * scale
+        if w is not None:
+            assert t_s == t_t, "Relative attention is only available for self-attention."
+            pos = torch.arange(t_s, device=q.device)
+            rel = pos[None, :] - pos[:, None]                       # j - i
+            in_win = (rel.abs() <= w)
+            rel_idx = (rel + w).clamp_(0, 2 * w)
+            qe = torch.matmul(q, self.emb_rel_k.unsqueeze(0).transpose(-2, -1))          # (b, h, t, 2w+1)
+            scores = scores + torch.gather(qe, 3, rel_idx.expand(b, nh, t_t, t_s)) * in_win * scale
+        if self.proximal_bias:
+            assert t_s == t_t, "Proximal bias is only available for self-attention."
+            pos = torch.arange(t_s, device=q.device, dtype=scores.dtype)
+            scores = scores - torch.log1p((pos[None, :] - pos[:, None]).abs())
+        if mask is not None:
+            scores = scores.masked_fill(mask == 0, -1e4)
+            if self.block_length is not None:
+                pos = torch.arange(t_s, device=q.device)
+                band = ((pos[None, :] - pos[:, None]).abs() <= self.block_length).to(scores.dtype)
+                scores = scores * band + -1e4 * (1 - band)
+        p_attn = self.drop(F.softmax(scores, dim=-1))
+        out = torch.matmul(p_attn, v)
+        if w is not None:
+            # weights on the 2w+1 diagonals around the main one: pw[..., i, r] = p[i, i + r - w]
+            j = pos_j = torch.arange(t_s, device=q.device)[:, None] + torch.arange(-w, w + 1, device=q.device)[None, :]
+            ok = (j >= 0) & (j < t_s)
+            pw = torch.gather(p_attn, 3, pos_j.clamp(0, t_s - 1).expand(b, nh, t_t, 2 * w + 1)) * ok
+            out = out + torch.matmul(pw, self.emb_rel_v.unsqueeze(0))
+        out = out.transpose(2, 3).contiguous().view(b, d, t_t)
+        return out, p_attn
+
+
+class FFN(nn.Module):
+    """Position-wise conv feed-forward (reference attentions.py:347-381)."""
+
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0.0, activation=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.filter_channels = in_channels, out_channels, filter_channels
+        self.kernel_size, self.p_dropout, self.activation = kernel_size, p_dropout, activation
+        self.conv_1 = nn.Conv1d(in_channels, filter_channels, kernel_size, padding=kernel_size // 2)
+        self.conv_2 = nn.Conv1d(filter_channels, out_channels, kernel_size, padding=kernel_size // 2)
+        self.drop = nn.Dropout(p_dropout)
+
+    def forward(self, x, x_mask):
+        h = self.conv_1(x * x_mask)
+        h = h * torch.sigmoid(1.702 * h) if self.activation == "gelu" else torch.relu(h)
+        return self.conv_2(self.drop(h) * x_mask) * x_mask

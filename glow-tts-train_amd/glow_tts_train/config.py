@@ -1,0 +1,98 @@
+"""Hyper-parameter containers read by `models.setup_model` (field names and defaults of the reference's
+glow_tts_train/config.py:11-81).  Host-side only; JSON overlay / dataclasses_json plumbing is out of this path's scope,
+so these are plain dataclasses with a dict round-trip."""
+from __future__ import annotations
+
+import typing
+from dataclasses import asdict, dataclass, field, fields, is_dataclass
+
+
+class _DictMixin:
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+    @classmethod
+    def from_dict(cls, d: typing.Mapping[str, typing.Any]):
+        kw = {}
+        for f in fields(cls):
+            if f.name not in d:
+                continue
+            v = d[f.name]
+            sub = _NESTED.get((cls.__name__, f.name))
+            kw[f.name] = sub.from_dict(v) if (sub is not None and isinstance(v, typing.Mapping)) else v
+        return cls(**kw)
+
+
+@dataclass
+class AudioConfig(_DictMixin):
+    filter_length: int = 1024
+    hop_length: int = 256
+    win_length: int = 1024
+    mel_channels: int = 80
+    sample_rate: int = 22050
+    sample_bytes: int = 2
+    channels: int = 1
+    mel_fmin: float = 0.0
+    mel_fmax: typing.Optional[float] = 8000.0
+    ref_level_db: float = 20.0
+    spec_gain: float = 1.0
+    signal_norm: bool = True
+    min_level_db: float = -100.0
+    max_norm: float = 1.0
+    clip_norm: bool = True
+    symmetric_norm: bool = True
+    do_dynamic_range_compression: bool = True
+    convert_db_to_amp: bool = True
+
+
+@dataclass
+class ModelConfig(_DictMixin):
+    num_symbols: int = 0
+    hidden_channels: int = 192
+    filter_channels: int = 768
+    filter_channels_dp: int = 256
+    kernel_size: int = 3
+    p_dropout: float = 0.1
+    n_blocks_dec: int = 12
+    n_layers_enc: int = 6
+    n_heads: int = 2
+    p_dropout_dec: float = 0.05
+    dilation_rate: int = 1
+    kernel_size_dec: int = 5
+    n_block_layers: int = 4
+    n_sqz: int = 2
+    prenet: bool = True
+    mean_only: bool = True
+    hidden_channels_enc: int = 192
+    hidden_channels_dec: int = 192
+    window_size: int = 4
+    n_speakers: int = 1
+    n_split: int = 4
+    sigmoid_scale: bool = False
+    block_length: typing.Optional[int] = None
+    gin_channels: int = 0
+    n_frames_per_step: int = 1
+
+
+@dataclass
+class TrainingConfig(_DictMixin):
+    seed: int = 1234
+    epochs: int = 10000
+    learning_rate: float = 1e0
+    betas: typing.Tuple[float, float] = (0.9, 0.98)
+    eps: float = 1e-9
+    grad_clip: float = 5.0
+    warmup_steps: int = 4000
+    scheduler: str = "noam"
+    batch_size: int = 32
+    fp16_run: bool = False
+    min_seq_length: typing.Optional[int] = None
+    max_seq_length: typing.Optional[int] = None
+    audio: AudioConfig = field(default_factory=AudioConfig)
+    model: ModelConfig = field(default_factory=ModelConfig)
+    version: int = 1
+    git_commit: str = ""
+
+
+_NESTED = {("TrainingConfig", "audio"): AudioConfig, ("TrainingConfig", "model"): ModelConfig}
+assert is_dataclass(TrainingConfig)

@@ -1,0 +1,195 @@
+"""Flow and conv-stack operators with the reference's names, constructor arguments and state-dict keys
+(reference: glow_tts_train/layers.py), computing through the HIP kernels in ``csrc/``.
+
+Per-flow operator API: ``f(x, x_mask, g=None, reverse=False) -> (z, logdet | None)`` and
+``f.store_inverse()``; ``x`` is ``(B, C, T)``, ``x_mask`` ``(B, 1, T)`` float 0/1, ``logdet`` ``(B,)``.
+A private keyword ``x_len`` (``sum(x_mask)`` per utterance) may be passed by FlowSpecDecoder to avoid recomputing it.
+"""
+from __future__ import annotations
+
+import typing
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+
+
+def _ones_mask(x: torch.Tensor) -> torch.Tensor:
+    return torch.ones(x.size(0), 1, x.size(2), device=x.device, dtype=x.dtype)
+
+
+class LayerNorm(nn.Module):
+    """Normalisation over the CHANNEL axis of (B, C, T) with eps 1e-4 (reference layers.py:10-28)."""
+
+    def __init__(self, channels, eps=1e-4):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x):
+        # F.layer_norm normalises trailing dims: move channels last, normalise, move back (same biased variance)
+        y = F.layer_norm(x.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps)
+        return y.transpose(1, -1)
+
+
+class ConvReluNorm(nn.Module):
+    """Encoder pre-net (reference layers.py:31-80): n x [conv -> LayerNorm -> ReLU -> dropout], zero-init residual proj."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, kernel_size, n_layers, p_dropout):
+        super().__init__()
+        assert n_layers > 1, "Number of layers should be larger than 0."
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, hidden_channels, out_channels
+        self.kernel_size, self.n_layers, self.p_dropout = kernel_size, n_layers, p_dropout
+        widths = [in_channels] + [hidden_channels] * n_layers
+        self.conv_layers = nn.ModuleList(
+            nn.Conv1d(widths[i], widths[i + 1], kernel_size, padding=kernel_size // 2) for i in range(n_layers)
+        )
+        self.norm_layers = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(n_layers))
+        self.relu_drop = nn.Sequential(nn.ReLU(), nn.Dropout(p_dropout))
+        self.proj = nn.Conv1d(hidden_channels, out_channels, 1)
+        nn.init.zeros_(self.proj.weight)
+        nn.init.zeros_(self.proj.bias)
+
+    def forward(self, x, x_mask):
+        h = x
+        for conv, norm in zip(self.conv_layers, self.norm_layers):
+            h = self.relu_drop(norm(conv(h * x_mask)))
+        return (x + self.proj(h)) * x_mask
+
+
+class WN(nn.Module):
+    """WaveNet-style gated conv stack of the coupling network (reference layers.py:83-170).
+
+    The dilated k-tap and 1x1 convolutions run through PyTorch-ROCm (MIOpen / rocBLAS); the gate and the
+    residual/skip update are the fused HIP kernels ``glowtts_gate_*`` / ``glowtts_res_skip_*`` (one launch each
+    instead of the reference's slice / tanh / sigmoid / mul / add / mul chain and its ``zeros_like`` allocation).
+    """
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        assert hidden_channels % 2 == 0
+        self.in_channels, self.hidden_channels = in_channels, hidden_channels
+        self.kernel_size = (kernel_size,)
+        self.dilation_rate, self.n_layers = dilation_rate, n_layers
+        self.gin_channels, self.p_dropout = gin_channels, p_dropout
+        wn = torch.nn.utils.weight_norm
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        self.drop = nn.Dropout(p_dropout)
+        if gin_channels != 0:
+            self.cond_layer = wn(nn.Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1), name="weight")
+        for i in range(n_layers):
+            d = dilation_rate ** i
+            self.in_layers.append(
+                wn(nn.Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=d,
+                             padding=(kernel_size * d - d) // 2), name="weight"))
+            out_ch = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(wn(nn.Conv1d(hidden_channels, out_ch, 1), name="weight"))
+
+    def forward(self, x, x_mask=None, g=None, **kwargs):
+        H = self.hidden_channels
+        if x_mask is None:
+            x_mask = _ones_mask(x)
+        m2 = kwargs.get("m2")
+        if m2 is None:
+            m2 = ops.mask2d(x_mask)
+        cond = self.cond_layer(g) if g is not None else None          # (B, 2H*n_layers, 1)
+        skip = None
+        last = self.n_layers - 1
+        for i in range(self.n_layers):
+            x_in = self.drop(self.in_layers[i](x))
+            g_l = None if cond is None else cond[:, 2 * H * i: 2 * H * (i + 1), :]
+            acts = ops.GateFn.apply(x_in, g_l)
+            rs = self.res_skip_layers[i](acts)
+            if i < last:
+                x, skip = ops.ResSkipFn.apply(x, rs, m2, skip, False)
+            else:
+                skip = ops.ResSkipFn.apply(None, rs, m2, skip, True)
+        return skip
+
+    def remove_weight_norm(self):
+        if self.gin_channels != 0:
+            torch.nn.utils.remove_weight_norm(self.cond_layer)
+        for layer in list(self.in_layers) + list(self.res_skip_layers):
+            torch.nn.utils.remove_weight_norm(layer)
+
+
+class ActNorm(nn.Module):
+    """Per-channel affine flow with data-dependent initialisation (reference layers.py:173-221)."""
+
+    def __init__(self, channels, ddi=False, **kwargs):
+        super().__init__()
+        self.channels = channels
+        self.initialized = not ddi
+        self.logs = nn.Parameter(torch.zeros(1, channels, 1))
+        self.bias = nn.Parameter(torch.zeros(1, channels, 1))
+
+    def forward(self, x, x_mask=None, reverse=False, **kwargs):
+        if x_mask is None:
+            x_mask = _ones_mask(x)
+        m2 = ops.mask2d(x_mask)
+        if not self.initialized:
+            self.initialize(x, x_mask)
+            self.initialized = True
+        if reverse:
+            return ops.actnorm_reverse(x, m2, self.logs, self.bias), None
+        x_len = kwargs.get("x_len")
+        if x_len is None:
+            x_len = ops.mask_len(m2)
+        return ops.ActNormFn.apply(x, m2, self.logs, self.bias, x_len)
+
+    def store_inverse(self):
+        pass
+
+    def set_ddi(self, ddi):
+        self.initialized = not ddi
+
+    def initialize(self, x, x_mask):
+        """First-batch statistics -> (logs, bias) so the output is zero-mean / unit-variance per channel."""
+        with torch.no_grad():
+            s1, s2, count = ops.actnorm_stats(x, ops.mask2d(x_mask))
+            mean = s1 / count
+            var = s2 / count - mean * mean
+            half_log_var = 0.5 * torch.log(torch.clamp_min(var, 1e-6))
+            self.bias.data.copy_((-mean * torch.exp(-half_log_var)).view_as(self.bias))
+            self.logs.data.copy_((-half_log_var).view_as(self.logs))
+
+
+class InvConvNear(nn.Module):
+    """Invertible 1x1 convolution shared by C / n_split channel groups (reference layers.py:224-275)."""
+
+    def __init__(self, channels, n_split=4, no_jacobian=False, **kwargs):
+        super().__init__()
+        assert n_split % 2 == 0
+        self.channels, self.n_split, self.no_jacobian = channels, n_split, no_jacobian
+        self.weight_inv: typing.Optional[torch.Tensor] = None
+        q, _ = torch.linalg.qr(torch.randn(n_split, n_split))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        self.weight = nn.Parameter(q.contiguous())
+
+    def forward(self, x, x_mask=None, reverse=False, **kwargs):
+        b, c, t = x.size()
+        assert c % self.n_split == 0
+        if x_mask is None:
+            x_mask = _ones_mask(x)
+        m2 = ops.mask2d(x_mask)
+        if reverse:
+            w_inv = self.weight_inv
+            if w_inv is None:  # the reference crashes here; computing the inverse is the evident intent
+                w_inv = ops.invconv_prepare(self.weight)[0]
+            return ops.invconv_apply(x, m2, w_inv.to(x.dtype), self.n_split), None
+        x_len = kwargs.get("x_len")
+        if x_len is None:
+            x_len = ops.mask_len(m2)
+        z, logdet = ops.InvConvFn.apply(x, m2, self.weight, x_len, self.n_split)
+        if self.no_jacobian:
+            logdet = 0
+        return z, logdet
+
+    def store_inverse(self):
+        self.weight_inv = ops.invconv_prepare(self.weight)[0].to(dtype=self.weight.dtype)

@@ -1,0 +1,241 @@
+"""Glow-TTS generator with the reference's public surface (reference: glow_tts_train/models.py):
+`FlowGenerator(...)(x, x_lengths, y, y_lengths, g, gen, noise_scale, length_scale)` returning the same three
+tuples, `FlowSpecDecoder`, `TextEncoder`, `DurationPredictor`, `setup_model`, `ModelType`, and the same
+state-dict keys — computing the flow stack, the alignment search and the losses with the HIP kernels in `csrc/`.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import typing
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import monotonic_align, ops
+from .attentions import CouplingBlock, Encoder
+from .layers import ActNorm, ConvReluNorm, InvConvNear, LayerNorm
+from .optimize import OptimizerType
+from .utils import generate_path, sequence_mask, squeeze, unsqueeze
+
+_LOGGER = logging.getLogger("glow_tts_train.models")
+
+
+class DurationPredictor(nn.Module):
+    """log-duration regressor on the detached encoder output (reference models.py:21-51)."""
+
+    def __init__(self, in_channels, filter_channels, kernel_size, p_dropout):
+        super().__init__()
+        self.in_channels, self.filter_channels = in_channels, filter_channels
+        self.kernel_size, self.p_dropout = kernel_size, p_dropout
+        pad = kernel_size // 2
+        self.drop = nn.Dropout(p_dropout)
+        self.conv_1 = nn.Conv1d(in_channels, filter_channels, kernel_size, padding=pad)
+        self.norm_1 = LayerNorm(filter_channels)
+        self.conv_2 = nn.Conv1d(filter_channels, filter_channels, kernel_size, padding=pad)
+        self.norm_2 = LayerNorm(filter_channels)
+        self.proj = nn.Conv1d(filter_channels, 1, 1)
+
+    def forward(self, x, x_mask):
+        for conv, norm in ((self.conv_1, self.norm_1), (self.conv_2, self.norm_2)):
+            x = self.drop(norm(torch.relu(conv(x * x_mask))))
+        return self.proj(x * x_mask) * x_mask
+
+
+class TextEncoder(nn.Module):
+    """phoneme ids -> (prior mean, prior log-std, log-durations, mask) (reference models.py:54-142)."""
+
+    def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, filter_channels_dp, n_heads, n_layers,
+                 kernel_size, p_dropout, window_size=None, block_length=None, mean_only=False, prenet=False,
+                 gin_channels=0):
+        super().__init__()
+        self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
+        self.filter_channels, self.filter_channels_dp = filter_channels, filter_channels_dp
+        self.n_heads, self.n_layers, self.kernel_size, self.p_dropout = n_heads, n_layers, kernel_size, p_dropout
+        self.window_size, self.block_length = window_size, block_length
+        self.mean_only, self.prenet, self.gin_channels = mean_only, prenet, gin_channels
+
+        self.emb = nn.Embedding(n_vocab, hidden_channels)
+        nn.init.normal_(self.emb.weight, 0.0, hidden_channels ** -0.5)
+        if prenet:
+            self.pre = ConvReluNorm(hidden_channels, hidden_channels, hidden_channels, kernel_size=5, n_layers=3,
+                                    p_dropout=0.5)
+        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                               window_size=window_size, block_length=block_length)
+        self.proj_m = nn.Conv1d(hidden_channels, out_channels, 1)
+        if not mean_only:
+            self.proj_s = nn.Conv1d(hidden_channels, out_channels, 1)
+        self.proj_w = DurationPredictor(hidden_channels + gin_channels, filter_channels_dp, kernel_size, p_dropout)
+
+    def forward(self, x, x_lengths, g=None):
+        h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)          # [b, h, t]
+        x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
+        if self.prenet:
+            h = self.pre(h, x_mask)
+        h = self.encoder(h, x_mask)
+        h_dp = h.detach()
+        if g is not None:
+            h_dp = torch.cat([h_dp, g.expand(-1, -1, h.size(-1))], 1)
+        x_m = self.proj_m(h) * x_mask
+        x_logs = torch.zeros_like(x_m) if self.mean_only else self.proj_s(h) * x_mask
+        return x_m, x_logs, self.proj_w(h_dp, x_mask), x_mask
+
+
+class FlowSpecDecoder(nn.Module):
+    """squeeze -> n_blocks x [ActNorm, InvConvNear, CouplingBlock] -> unsqueeze (reference models.py:145-215).
+
+    `self.flows` keeps the reference's flat ModuleList (state-dict keys `flows.{3i}`, `{3i+1}`, `{3i+2}`); the
+    per-utterance lengths every flow needs for its log-determinant are computed once here and handed down."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_blocks, n_layers, p_dropout=0.0,
+                 n_split=4, n_sqz=2, sigmoid_scale=False, gin_channels=0):
+        super().__init__()
+        self.in_channels, self.hidden_channels, self.kernel_size = in_channels, hidden_channels, kernel_size
+        self.dilation_rate, self.n_blocks, self.n_layers, self.p_dropout = dilation_rate, n_blocks, n_layers, p_dropout
+        self.n_split, self.n_sqz, self.sigmoid_scale, self.gin_channels = n_split, n_sqz, sigmoid_scale, gin_channels
+        c = in_channels * n_sqz
+        self.flows = nn.ModuleList()
+        for _ in range(n_blocks):
+            self.flows.extend([
+                ActNorm(channels=c),
+                InvConvNear(channels=c, n_split=n_split),
+                CouplingBlock(c, hidden_channels, kernel_size=kernel_size, dilation_rate=dilation_rate,
+                              n_layers=n_layers, gin_channels=gin_channels, p_dropout=p_dropout,
+                              sigmoid_scale=sigmoid_scale),
+            ])
+
+    def forward(self, x, x_mask, g=None, reverse=False):
+        if self.n_sqz > 1:
+            x, x_mask = squeeze(x, x_mask, self.n_sqz)
+        if reverse:
+            for f in reversed(self.flows):
+                x, _ = f(x, x_mask, g=g, reverse=True)
+            logdet_tot = None
+        else:
+            x_len = ops.mask_len(ops.mask2d(x_mask))
+            logdet_tot = 0
+            for f in self.flows:
+                x, logdet = f(x, x_mask, g=g, reverse=False, x_len=x_len)
+                logdet_tot = logdet_tot + logdet
+        if self.n_sqz > 1:
+            x, x_mask = unsqueeze(x, x_mask, self.n_sqz)
+        return x, logdet_tot
+
+    def store_inverse(self):
+        for f in self.flows:
+            f.store_inverse()
+
+
+class FlowGenerator(nn.Module):
+    """Top-level model (reference models.py:218-410)."""
+
+    def __init__(self, n_vocab: int, hidden_channels: int, filter_channels: int, filter_channels_dp: int,
+                 out_channels: int, kernel_size: int = 3, n_heads: int = 2, n_layers_enc: int = 6,
+                 p_dropout: float = 0.0, n_blocks_dec: int = 12, kernel_size_dec: int = 5, dilation_rate: int = 5,
+                 n_block_layers: int = 4, p_dropout_dec: float = 0.0, n_speakers: int = 0, gin_channels: int = 0,
+                 n_split: int = 4, n_sqz: int = 1, sigmoid_scale: bool = False,
+                 window_size: typing.Optional[int] = None, block_length: typing.Optional[int] = None,
+                 mean_only: bool = False, hidden_channels_enc: typing.Optional[int] = None,
+                 hidden_channels_dec: typing.Optional[int] = None, prenet: bool = False):
+        super().__init__()
+        for name, value in list(locals().items()):
+            if name not in ("self", "__class__"):
+                setattr(self, name, value)
+        self.encoder = TextEncoder(n_vocab, out_channels, hidden_channels_enc or hidden_channels, filter_channels,
+                                   filter_channels_dp, n_heads, n_layers_enc, kernel_size, p_dropout,
+                                   window_size=window_size, block_length=block_length, mean_only=mean_only,
+                                   prenet=prenet, gin_channels=gin_channels)
+        self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec,
+                                       dilation_rate, n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec,
+                                       n_split=n_split, n_sqz=n_sqz, sigmoid_scale=sigmoid_scale,
+                                       gin_channels=gin_channels)
+        if n_speakers > 1:
+            self.emb_g = nn.Embedding(n_speakers, gin_channels)
+            nn.init.uniform_(self.emb_g.weight, -0.1, 0.1)
+
+    # -- helpers ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _expand_by_alignment(attn, stats):
+        """attn [b,1,t,t'] (0/1), stats [b,d,t] -> [b,d,t']: every frame takes its aligned token's statistics."""
+        return torch.matmul(attn.squeeze(1).transpose(1, 2), stats.transpose(1, 2)).transpose(1, 2)
+
+    @staticmethod
+    def _pairwise_log_likelihood(x_m, x_logs, z):
+        """log N(z_t'; x_m_t, exp(x_logs_t)) for every (token, frame) pair -> [b, t, t'] (reference models.py:362-376)."""
+        inv_var = torch.exp(-2 * x_logs)
+        const = torch.sum(-0.5 * math.log(2 * math.pi) - x_logs, [1]).unsqueeze(-1)
+        quad = torch.matmul(inv_var.transpose(1, 2), -0.5 * (z ** 2))
+        cross = torch.matmul((x_m * inv_var).transpose(1, 2), z)
+        bias = torch.sum(-0.5 * (x_m ** 2) * inv_var, [1]).unsqueeze(-1)
+        return const + quad + cross + bias
+
+    def preprocess(self, y, y_lengths, y_max_length):
+        """Floor frame counts to a multiple of n_sqz (reference models.py:401-406)."""
+        q = self.n_sqz
+        if y_max_length is not None:
+            y_max_length = (y_max_length // q) * q
+            y = y[:, :, :y_max_length]
+        return y, (y_lengths // q) * q, y_max_length
+
+    # -- forward ------------------------------------------------------------------------------------------------
+    def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, gen=False, noise_scale=1.0, length_scale=1.0):
+        if g is not None:
+            g = F.normalize(self.emb_g(g)).unsqueeze(-1)                        # [b, gin, 1]
+        x_m, x_logs, logw, x_mask = self.encoder(x, x_lengths, g=g)
+
+        if gen:
+            w_ceil = torch.ceil(torch.exp(logw) * x_mask * length_scale)
+            y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+            y_max_length = None
+        else:
+            y_max_length = y.size(2)
+        y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y_max_length)
+        z_mask = sequence_mask(y_lengths, y_max_length).unsqueeze(1).to(x_mask.dtype)
+        attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
+
+        if gen:
+            attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+            z_m = self._expand_by_alignment(attn, x_m)
+            z_logs = self._expand_by_alignment(attn, x_logs)
+            logw_ = torch.log(1e-8 + torch.sum(attn, -1)) * x_mask
+            z = (z_m + torch.exp(z_logs) * torch.randn_like(z_m) * noise_scale) * z_mask
+            y, logdet = self.decoder(z, z_mask, g=g, reverse=True)
+            return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
+
+        z, logdet = self.decoder(y, z_mask, g=g, reverse=False)
+        with torch.no_grad():
+            logp = self._pairwise_log_likelihood(x_m, x_logs, z)
+            # device-resident search; lengths are what the reference would read back off attn_mask
+            attn = monotonic_align.maximum_path_lengths(logp, x_lengths, y_lengths).unsqueeze(1).detach()
+        z_m = self._expand_by_alignment(attn, x_m)
+        z_logs = self._expand_by_alignment(attn, x_logs)
+        logw_ = torch.log(1e-8 + torch.sum(attn, -1)) * x_mask
+        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
+
+    def store_inverse(self):
+        self.decoder.store_inverse()
+
+
+ModelType = FlowGenerator
+
+
+def setup_model(config, model: typing.Optional[ModelType] = None, optimizer: typing.Optional[OptimizerType] = None,
+                model_factory=ModelType, optimizer_factory=OptimizerType, create_optimizer: bool = True,
+                use_cuda: bool = True) -> typing.Tuple[ModelType, typing.Optional[OptimizerType]]:
+    """Build (or adopt) the model and its optimizer from a TrainingConfig-shaped object (reference models.py:417-470)."""
+    if model is None:
+        mc = config.model
+        names = ("hidden_channels filter_channels filter_channels_dp kernel_size n_heads n_layers_enc p_dropout "
+                 "n_blocks_dec kernel_size_dec dilation_rate n_block_layers p_dropout_dec n_speakers gin_channels "
+                 "n_split n_sqz sigmoid_scale window_size block_length mean_only hidden_channels_enc "
+                 "hidden_channels_dec prenet").split()
+        model = model_factory(n_vocab=mc.num_symbols, out_channels=config.audio.mel_channels,
+                              **{n: getattr(mc, n) for n in names})
+    if use_cuda:
+        model.cuda()
+    if create_optimizer and optimizer is None:
+        optimizer = optimizer_factory(model.parameters(), scheduler=config.scheduler,
+                                      dim_model=config.model.hidden_channels, warmup_steps=config.warmup_steps,
+                                      lr=config.learning_rate, betas=config.betas, eps=config.eps)
+    return model, optimizer

@@ -1,0 +1,346 @@
+"""Autograd operators over the HIP kernels (hand-written backward for every flow; the reference relies on autograd
+over stock ops).  Every operator takes contiguous fp32 device tensors in the reference layout
+``(B, C, T)`` and launches on PyTorch's current stream through the C ABI in ``_hip.py``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip
+from ._hip import call, f32, ptr
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+def mask2d(x_mask: torch.Tensor) -> torch.Tensor:
+    """(B, 1, T) float mask -> contiguous fp32 (B, T)."""
+    m = x_mask.reshape(x_mask.shape[0], x_mask.shape[-1])
+    if m.dtype != torch.float32:
+        m = m.float()
+    return m.contiguous()
+
+
+def mask_len(m2: torch.Tensor) -> torch.Tensor:
+    """x_len[b] = sum_t mask[b, t]  (layers.py:187,245)."""
+    out = torch.empty(m2.shape[0], device=m2.device, dtype=torch.float32)
+    call("glowtts_mask_len", ptr(m2), ptr(out), m2.shape[0], m2.shape[1])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class ActNormFn(Function):
+    """z = (bias + exp(logs) x) mask, logdet = sum(logs) x_len   (layers.py:196-197)."""
+
+    @staticmethod
+    def forward(ctx, x, m2, logs, bias, x_len):
+        x = f32(_c(x))
+        B, C, T = x.shape
+        z = torch.empty_like(x)
+        logdet = torch.empty(B, device=x.device, dtype=torch.float32)
+        lg, bs = _c(logs.reshape(-1)), _c(bias.reshape(-1))
+        call("glowtts_actnorm_fwd", ptr(x), ptr(m2), ptr(lg), ptr(bs), ptr(x_len), ptr(z), ptr(logdet), B, C, T, 0)
+        ctx.save_for_backward(x, m2, lg, x_len)
+        ctx.pshape = logs.shape
+        return z, logdet
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogdet):
+        x, m2, lg, x_len = ctx.saved_tensors
+        B, C, T = x.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(x)
+        dx = torch.empty_like(x)
+        dpar = torch.zeros(2, C, device=x.device, dtype=torch.float32)
+        call("glowtts_actnorm_bwd", ptr(x), ptr(m2), ptr(lg), ptr(dz), ptr(_c(dlogdet)), ptr(x_len), ptr(dx),
+             ptr(dpar[0]), ptr(dpar[1]), B, C, T)
+        return dx, None, dpar[0].view(ctx.pshape), dpar[1].view(ctx.pshape), None
+
+
+def actnorm_reverse(x, m2, logs, bias):
+    x = f32(_c(x))
+    B, C, T = x.shape
+    z = torch.empty_like(x)
+    call("glowtts_actnorm_fwd", ptr(x), ptr(m2), ptr(_c(logs.reshape(-1))), ptr(_c(bias.reshape(-1))), None, ptr(z),
+         None, B, C, T, 1)
+    return z
+
+
+def actnorm_stats(x, m2):
+    """Masked per-channel sums for the data-dependent init (layers.py:209-211): returns (sum_x, sum_x2, count)."""
+    x = f32(_c(x))
+    B, C, T = x.shape
+    s = torch.zeros(2, C, device=x.device, dtype=torch.float32)
+    call("glowtts_actnorm_stats", ptr(x), ptr(m2), ptr(s[0]), ptr(s[1]), B, C, T)
+    return s[0], s[1], mask_len(m2).sum()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def invconv_prepare(weight: torch.Tensor):
+    """(W^-1, log det W) of the n x n mixing matrix on one wavefront (replaces torch.inverse / torch.logdet)."""
+    w = f32(_c(weight.detach()))
+    n = w.shape[0]
+    w_inv = torch.empty_like(w)
+    logdet_w = torch.empty(1, device=w.device, dtype=torch.float32)
+    call("glowtts_invconv_prepare", ptr(w), ptr(w_inv), ptr(logdet_w), n)
+    return w_inv, logdet_w
+
+
+class InvConvFn(Function):
+    """layers.py:247-272 without the two permute copies: 4x4 (n_split) mix per (b, group, t) in registers."""
+
+    @staticmethod
+    def forward(ctx, x, m2, weight, x_len, n_split):
+        x = f32(_c(x))
+        B, C, T = x.shape
+        w = f32(_c(weight))
+        w_inv, logdet_w = invconv_prepare(w)
+        z = torch.empty_like(x)
+        logdet = torch.empty(B, device=x.device, dtype=torch.float32)
+        call("glowtts_invconv_fwd", ptr(x), ptr(m2), ptr(w), ptr(logdet_w), ptr(x_len), ptr(z), ptr(logdet), B, C, T,
+             n_split)
+        ctx.save_for_backward(x, m2, w, w_inv, x_len)
+        ctx.n_split = n_split
+        return z, logdet
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogdet):
+        x, m2, w, w_inv, x_len = ctx.saved_tensors
+        B, C, T = x.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(x)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        call("glowtts_invconv_bwd", ptr(x), ptr(m2), ptr(w), ptr(w_inv), ptr(dz), ptr(_c(dlogdet)), ptr(x_len), ptr(dx),
+             ptr(dw), B, C, T, ctx.n_split)
+        return dx, None, dw, None, None
+
+
+def invconv_apply(x, m2, w, n_split):
+    """Mix with an explicit matrix and no log-det (the reverse path passes the stored inverse, layers.py:254-258)."""
+    x = f32(_c(x))
+    B, C, T = x.shape
+    z = torch.empty_like(x)
+    call("glowtts_invconv_fwd", ptr(x), ptr(m2), ptr(f32(_c(w))), None, None, ptr(z), None, B, C, T, n_split)
+    return z
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class CouplingFn(Function):
+    """attentions.py:128-142: z = [x_0 ; (m + exp(logs) x_1) mask], logdet = sum logs mask; (m, logs) = `out` halves."""
+
+    @staticmethod
+    def forward(ctx, x, out, m2, sigmoid_scale):
+        x, out = f32(_c(x)), f32(_c(out))
+        B, C, T = x.shape
+        z = torch.empty_like(x)
+        logdet = torch.zeros(B, device=x.device, dtype=torch.float32)
+        call("glowtts_coupling_fwd", ptr(x), ptr(out), ptr(m2), ptr(z), ptr(logdet), B, C, T, int(sigmoid_scale), 0)
+        ctx.save_for_backward(x, out, m2)
+        ctx.sig = int(sigmoid_scale)
+        return z, logdet
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogdet):
+        x, out, m2 = ctx.saved_tensors
+        B, C, T = x.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(x)
+        dx = torch.empty_like(x)
+        dout = torch.empty_like(out)
+        call("glowtts_coupling_bwd", ptr(x), ptr(out), ptr(m2), ptr(dz), ptr(_c(dlogdet)), ptr(dx), ptr(dout), B, C, T,
+             ctx.sig)
+        return dx, dout, None, None
+
+
+def coupling_reverse(x, out, m2, sigmoid_scale):
+    x, out = f32(_c(x)), f32(_c(out))
+    B, C, T = x.shape
+    z = torch.empty_like(x)
+    call("glowtts_coupling_fwd", ptr(x), ptr(out), ptr(m2), ptr(z), None, B, C, T, int(sigmoid_scale), 1)
+    return z
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class GateFn(Function):
+    """utils.py:31-38 with the conditioning row broadcast over time; backward recomputes tanh/sigmoid from `a`."""
+
+    @staticmethod
+    def forward(ctx, a, g):
+        a = f32(_c(a))
+        B, H2, T = a.shape
+        H = H2 // 2
+        g2 = None if g is None else f32(_c(g.reshape(B, H2)))
+        acts = torch.empty(B, H, T, device=a.device, dtype=torch.float32)
+        call("glowtts_gate_fwd", ptr(a), ptr(g2), ptr(acts), B, H, T)
+        ctx.save_for_backward(a, g2)
+        ctx.gshape = None if g is None else g.shape
+        return acts
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dacts):
+        a, g2 = ctx.saved_tensors
+        B, H2, T = a.shape
+        da = torch.empty_like(a)
+        call("glowtts_gate_bwd", ptr(a), ptr(g2), ptr(_c(dacts)), ptr(da), B, H2 // 2, T)
+        dg = None if g2 is None else da.sum(-1).view(ctx.gshape)
+        return da, dg
+
+
+class ResSkipFn(Function):
+    """layers.py:157-162: x <- (x + rs[:, :H]) mask, skip <- skip + rs[:, H:]; the last layer folds `output * mask`."""
+
+    @staticmethod
+    def forward(ctx, x, rs, m2, skip_in, last):
+        rs = f32(_c(rs))
+        B, _, T = rs.shape
+        H = rs.shape[1] if last else rs.shape[1] // 2
+        skip_in = _c(skip_in)
+        skip_out = torch.empty(B, H, T, device=rs.device, dtype=torch.float32)
+        if last:
+            call("glowtts_res_skip_fwd", None, ptr(rs), ptr(m2), ptr(skip_in), None, ptr(skip_out), B, H, T, 1)
+            x_out = None
+        else:
+            x = f32(_c(x))
+            x_out = torch.empty_like(x)
+            call("glowtts_res_skip_fwd", ptr(x), ptr(rs), ptr(m2), ptr(skip_in), ptr(x_out), ptr(skip_out), B, H, T, 0)
+        ctx.save_for_backward(m2)
+        ctx.last, ctx.has_skip, ctx.H = bool(last), skip_in is not None, H
+        if last:
+            return skip_out
+        return x_out, skip_out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        (m2,) = ctx.saved_tensors
+        B, T = m2.shape
+        H = ctx.H
+        if ctx.last:
+            dskip = _c(grads[0])
+            drs = torch.empty_like(dskip)
+            call("glowtts_res_skip_bwd", None, ptr(dskip), ptr(m2), None, ptr(drs), B, H, T, 1)
+            return None, drs, None, (drs if ctx.has_skip else None), None
+        dx_out, dskip = grads
+        dev = m2.device
+        dx_out = _c(dx_out) if dx_out is not None else torch.zeros(B, H, T, device=dev)
+        dskip = _c(dskip) if dskip is not None else torch.zeros(B, H, T, device=dev)
+        drs = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
+        call("glowtts_res_skip_bwd", ptr(dx_out), ptr(dskip), ptr(m2), None, ptr(drs), B, H, T, 0)
+        return drs[:, :H], drs, None, (dskip if ctx.has_skip else None), None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class SqueezeFn(Function):
+    """utils.py:135-147 (time -> channel fold, masked); backward is the unsqueeze kernel with the same mask."""
+
+    @staticmethod
+    def forward(ctx, x, m2, n):
+        x = f32(_c(x))
+        B, C, T = x.shape
+        Ts = T // n
+        xs = torch.empty(B, C * n, Ts, device=x.device, dtype=torch.float32)
+        ms = torch.empty(B, Ts, device=x.device, dtype=torch.float32)
+        call("glowtts_squeeze", ptr(x), ptr(m2), ptr(xs), ptr(ms), B, C, T, n)
+        ctx.save_for_backward(ms)
+        ctx.n, ctx.T = n, T
+        ctx.mark_non_differentiable(ms)
+        return xs, ms
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dxs, _dms):
+        (ms,) = ctx.saved_tensors
+        dxs = _c(dxs)
+        B, Cn, Ts = dxs.shape
+        n = ctx.n
+        if ctx.T == Ts * n:
+            dx = torch.empty(B, Cn // n, ctx.T, device=dxs.device, dtype=torch.float32)
+        else:  # frames cut off by the floor division get zero gradient
+            dx = torch.zeros(B, Cn // n, ctx.T, device=dxs.device, dtype=torch.float32)
+        if ctx.T == Ts * n:
+            call("glowtts_unsqueeze", ptr(dxs), ptr(ms), ptr(dx), None, B, Cn // n, Ts, n)
+        else:
+            tmp = torch.empty(B, Cn // n, Ts * n, device=dxs.device, dtype=torch.float32)
+            call("glowtts_unsqueeze", ptr(dxs), ptr(ms), ptr(tmp), None, B, Cn // n, Ts, n)
+            dx[:, :, : Ts * n] = tmp
+        return dx, None, None
+
+
+class UnsqueezeFn(Function):
+    """utils.py:150-160; backward is the squeeze kernel (mask value per squeezed column)."""
+
+    @staticmethod
+    def forward(ctx, xs, ms, n):
+        xs = f32(_c(xs))
+        B, Cn, Ts = xs.shape
+        x = torch.empty(B, Cn // n, Ts * n, device=xs.device, dtype=torch.float32)
+        mo = torch.empty(B, Ts * n, device=xs.device, dtype=torch.float32)
+        call("glowtts_unsqueeze", ptr(xs), ptr(ms), ptr(x), ptr(mo), B, Cn // n, Ts, n)
+        ctx.save_for_backward(mo)
+        ctx.n = n
+        ctx.mark_non_differentiable(mo)
+        return x, mo
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx, _dmo):
+        (mo,) = ctx.saved_tensors
+        dx = _c(dx)
+        B, C, T = dx.shape
+        n = ctx.n
+        dxs = torch.empty(B, C * n, T // n, device=dx.device, dtype=torch.float32)
+        call("glowtts_squeeze", ptr(dx), ptr(mo), ptr(dxs), None, B, C, T, n)
+        return dxs, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+_HALF_LOG_2PI = 0.5 * math.log(2 * math.pi)
+
+
+class MleLossFn(Function):
+    """utils.py:14-23 as one streaming reduction (+ a handful of scalar ops) instead of ~10 full-tensor passes."""
+
+    @staticmethod
+    def forward(ctx, z, m, logs, logdet, m2):
+        z, m, logs = f32(_c(z)), f32(_c(m)), f32(_c(logs))
+        B, C, T = z.shape
+        acc = torch.zeros(2, device=z.device, dtype=torch.float32)
+        call("glowtts_mle_fwd", ptr(z), ptr(m), ptr(logs), ptr(m2), ptr(acc), B, C, T)
+        denom = acc[1] * C
+        loss = (acc[0] - logdet.sum()) / denom + _HALF_LOG_2PI
+        ctx.save_for_backward(z, m, logs, denom)
+        ctx.B = B
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        z, m, logs, denom = ctx.saved_tensors
+        scale = (dloss / denom).reshape(1).contiguous()
+        dz, dm, dlogs = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        call("glowtts_mle_bwd", ptr(z), ptr(m), ptr(logs), ptr(scale), ptr(dz), ptr(dm), ptr(dlogs), z.numel())
+        return dz, dm, dlogs, (-scale).expand(ctx.B), None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def mas_path(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -> torch.Tensor:
+    """Monotonic alignment search on device; value (B, Tx, Ty) fp32, lengths int32 (B). Returns 0/1 fp32 path."""
+    value = f32(_c(value.detach()))
+    B, Tx, Ty = value.shape
+    path = torch.empty_like(value)
+    t_x = t_x.to(device=value.device, dtype=torch.int32).contiguous()
+    t_y = t_y.to(device=value.device, dtype=torch.int32).contiguous()
+    call("glowtts_mas_path", ptr(value), ptr(path), ptr(t_x), ptr(t_y), B, Tx, Ty)
+    return path
+
+
+def library_loaded() -> bool:
+    return _hip._lib is not None

@@ -1,0 +1,131 @@
+"""Data-parallel gradient averaging for one 8-GPU MI355X node (replaces the DistributedDataParallel wrap of the
+reference, glow_tts_train/__main__.py:83-88,268-271).
+
+One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm).  The reference leaves
+bucketing to DDP's default 25 MB buckets; here the buckets are *slices of the optimizer's flat gradient buffer*
+cut at flow-block boundaries (one [ActNorm, InvConvNear, CouplingBlock] block ~ 1.79 M parameters = 7.1 MB at the
+default width), so
+
+  * nothing is copied into or out of bucket storage — RCCL reduces the gradient memory in place;
+  * a block's all-reduce is issued the moment its last gradient has been accumulated, i.e. while the backward of
+    the blocks below it (and then of the encoder) is still running; RCCL runs on its own stream, so the
+    collective overlaps the remaining flow backward;
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): twelve 7 MB messages + one 29 MB encoder message keep
+    each ring step large enough to be bandwidth- rather than latency-bound without delaying the first launch.
+
+Semantics match DDP: gradients are averaged over ranks (each rank normalises its loss by its own mask sums,
+utils.py:19-21,27) and parameters are broadcast from rank 0 once at start (which is also what makes rank 0's
+data-dependent ActNorm initialisation win).
+"""
+from __future__ import annotations
+
+import re
+import typing
+
+import torch
+import torch.distributed as dist
+
+_FLOW_RE = re.compile(r"^(?:module\.)?decoder\.flows\.(\d+)\.")
+
+
+def default_bucket_key(name: str) -> str:
+    m = _FLOW_RE.match(name)
+    if m:
+        return f"dec{int(m.group(1)) // 3:03d}"
+    if name.startswith("encoder.") or name.startswith("module.encoder."):
+        return "enc"
+    return "misc"
+
+
+class Bucket(typing.NamedTuple):
+    key: str
+    lo: int        # element range [lo, hi) inside the flat gradient buffer
+    hi: int
+    n_params: int
+
+
+class FlowBlockReducer:
+    """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer of `optimize.FlatAdam`."""
+
+    def __init__(self, model: torch.nn.Module, optimizer, process_group=None,
+                 bucket_key: typing.Callable[[str], str] = default_bucket_key):
+        flat = getattr(optimizer, "_optim", optimizer)
+        if not hasattr(flat, "flat_g"):
+            raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self._use_avg = backend == "nccl"
+        named = list(model.named_parameters())
+        by_id = {id(p): (o, p.numel()) for p, o in zip(flat._params, flat.offsets)}
+        self.buckets: typing.List[Bucket] = []
+        self._bucket_of: typing.Dict[int, int] = {}
+        cur_key, lo, hi, cnt = None, 0, 0, 0
+        last_end = None
+        for name, p in named:
+            if id(p) not in by_id:
+                raise RuntimeError(f"parameter {name} is not managed by the optimizer")
+            o, n = by_id[id(p)]
+            if last_end is not None and o < last_end:
+                raise RuntimeError("model.named_parameters() order differs from the optimizer's flat layout")
+            key = bucket_key(name)
+            if key != cur_key:
+                if cur_key is not None:
+                    self.buckets.append(Bucket(cur_key, lo, hi, cnt))
+                cur_key, lo, cnt = key, o, 0
+            hi = o + n
+            last_end = hi
+            cnt += 1
+            self._bucket_of[id(p)] = len(self.buckets)
+        if cur_key is not None:
+            self.buckets.append(Bucket(cur_key, lo, hi, cnt))
+        self._pending = [b.n_params for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works: typing.List[typing.Any] = []
+        self._hooks = []
+        if self.world > 1:
+            for _, p in named:
+                if p.requires_grad:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- collectives ------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0):
+        """One broadcast of the whole flat parameter buffer (DDP's construction-time sync, __main__.py:269-271)."""
+        if self.world > 1:
+            dist.broadcast(self.flat.flat_p, src=src, group=self.group)
+
+    def _launch(self, i: int):
+        b = self.buckets[i]
+        view = self.flat.flat_g[b.lo:b.hi]
+        if self._use_avg:
+            work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:
+            view.div_(self.world)
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(work)
+        self._launched[i] = True
+
+    def _on_grad(self, p: torch.Tensor):
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and not self._launched[i]:
+            self._launch(i)
+
+    def finish(self):
+        """Call after backward(), before clipping: reduces buckets whose parameters got no gradient this step (their
+        slice is the zeros left by zero_grad), then makes the current stream wait for every collective."""
+        if self.world > 1:
+            for i in range(len(self.buckets)):
+                if not self._launched[i]:
+                    self._launch(i)
+            for w in self._works:
+                w.wait()
+        self._works.clear()
+        self._pending = [b.n_params for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()

@@ -1,0 +1,147 @@
+/*
+ * glowtts_hip.h — C ABI of libglowtts_hip.so: the MI355X (gfx950) kernels behind the Glow-TTS training hot path.
+ *
+ * This is the drop-in boundary.  The reference has exactly one native entry point on this path,
+ * the Cython `maximum_path_c` (glow_tts_train/monotonic_align/core.pyx:40); everything else on the path is a
+ * PyTorch op called from its Python operators.  Each function below names the reference site it replaces.
+ *
+ * Conventions (all functions):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
+ *     no allocation, no ownership transfer, no hidden global state (re-entrant from autograd's backward thread);
+ *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)
+ *     holding 0/1 (the reference's (B,1,T) float mask viewed flat); log-determinants are fp32 (B);
+ *   - `stream` is a hipStream_t (pass PyTorch's current stream): launches are asynchronous and ordered on it,
+ *     nothing synchronises, so every call is hipGraph-capturable;
+ *   - outputs documented "accumulated" are atomically ADDED to (caller zeroes them or passes a running sum);
+ *   - return 0 on success, non-zero on argument error or hipError_t; glowtts_last_error() gives the text.
+ *     The Python wrappers raise RuntimeError on non-zero, mirroring the reference's Python asserts
+ *     (layers.py:227,240; attentions.py:162,226-228).
+ */
+#ifndef GLOWTTS_HIP_H
+#define GLOWTTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *glowtts_stream_t; /* hipStream_t */
+
+const char *glowtts_last_error(void);
+int glowtts_abi_version(void);
+
+/* ---- monotonic alignment search ----------------------------------------------------------------------------
+ * replaces maximum_path_c / maximum_path_each (monotonic_align/core.pyx:9-45) and the D2H/H2D round trip of its
+ * wrapper (monotonic_align/__init__.py:11-21).
+ * value : (B, Tx, Ty) fp32 log-likelihoods, READ ONLY (the reference mutates it as scratch; here the running
+ *         column lives in registers).  Only cells inside each utterance's band are read, so `value` need not be
+ *         pre-multiplied by the mask.
+ * path  : (B, Tx, Ty) fp32, fully written with 0/1 (no pre-zeroing needed).
+ * t_x,t_y: (B) int32 valid lengths (the reference derives them from the mask, __init__.py:18-19).
+ * Bit-exact with the reference for identical `value` (one fp32 add per cell, max = (prev > cur) ? prev : cur,
+ * max_neg_val = -1e9).  Limits: Tx <= 512.
+ */
+int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const int32_t *t_y,
+                     int B, int Tx, int Ty, glowtts_stream_t stream);
+
+/* ---- sequence lengths from a mask: x_len[b] = sum_t mask[b, t]  (layers.py:187,245) ------------------------ */
+int glowtts_mask_len(const float *mask, float *x_len, int B, int T, glowtts_stream_t stream);
+
+/* ---- ActNorm (layers.py:182-199; init :207-221) ------------------------------------------------------------
+ * fwd : z = (bias + exp(logs) * x) * mask ; logdet[b] = sum(logs) * x_len[b]   (logdet may be NULL)
+ * rev : z = (x - bias) * exp(-logs) * mask
+ * bwd : dx = dz * exp(logs) * mask ; dlogs[c] += sum_{b,t} dz*x*exp(logs)*mask + sum_b dlogdet[b]*x_len[b] ;
+ *       dbias[c] += sum_{b,t} dz*mask      (dlogs, dbias accumulated; dlogdet may be NULL)
+ * stats: sum_x[c] += sum x*mask ; sum_x2[c] += sum x*x*mask  (accumulated; denominators via glowtts_mask_len) */
+int glowtts_actnorm_fwd(const float *x, const float *mask, const float *logs, const float *bias,
+                        const float *x_len, float *z, float *logdet, int B, int C, int T, int reverse,
+                        glowtts_stream_t stream);
+int glowtts_actnorm_bwd(const float *x, const float *mask, const float *logs, const float *dz,
+                        const float *dlogdet, const float *x_len, float *dx, float *dlogs, float *dbias,
+                        int B, int C, int T, glowtts_stream_t stream);
+int glowtts_actnorm_stats(const float *x, const float *mask, float *sum_x, float *sum_x2, int B, int C, int T,
+                          glowtts_stream_t stream);
+
+/* ---- InvConvNear (layers.py:238-275) ------------------------------------------------------------------------
+ * prepare: one wavefront factorises the n x n weight (n = n_split, even, <= 8) by Gauss-Jordan with partial
+ *          pivoting held across lanes: w_inv (n*n) and logdet_w[0] = log(det W) (NaN if det <= 0, as
+ *          torch.logdet, layers.py:265).  Replaces torch.logdet / torch.inverse (layers.py:258,265,275).
+ * fwd    : per (b, group g, t): z[k_out] = sum_k W[k_out,k] x[k], rows k = h*(n/2)+s <-> channel
+ *          h*(C/2) + g*(n/2) + s  (layers.py:247-252, 267-271), times mask;
+ *          logdet[b] = logdet_w * (C/n) * x_len[b]   (logdet may be NULL; pass w = w_inv for reverse)
+ * bwd    : dx = W^T (dz*mask) ; dw[o,k] += sum dz[o]*mask*x[k] + w_inv[k,o] * (C/n) * sum_b dlogdet[b]*x_len[b]
+ *          (dw accumulated; dlogdet may be NULL) */
+int glowtts_invconv_prepare(const float *w, float *w_inv, float *logdet_w, int n, glowtts_stream_t stream);
+int glowtts_invconv_fwd(const float *x, const float *mask, const float *w, const float *logdet_w,
+                        const float *x_len, float *z, float *logdet, int B, int C, int T, int n_split,
+                        glowtts_stream_t stream);
+int glowtts_invconv_bwd(const float *x, const float *mask, const float *w, const float *w_inv, const float *dz,
+                        const float *dlogdet, const float *x_len, float *dx, float *dw, int B, int C, int T,
+                        int n_split, glowtts_stream_t stream);
+
+/* ---- affine coupling apply (attentions.py:128-142) ----------------------------------------------------------
+ * x   : (B, C, T) flow input; out : (B, C, T) = end-conv output, rows [0,C/2) = m, [C/2,C) = logs
+ * fwd : z[:, :C/2] = x[:, :C/2] ; z[:, C/2:] = (m + exp(logs') * x1) * mask ; logdet[b] += sum logs' * mask
+ *       logs' = log(1e-6 + sigmoid(logs + 2)) if sigmoid_scale else logs      (logdet accumulated)
+ * rev : z[:, C/2:] = (x1 - m) * exp(-logs') * mask
+ * bwd : dx[:, :C/2] = dz0 ; dx1 = dz1 * exp(logs') * mask ; dm = dz1 * mask ;
+ *       dlogs' = (dz1 * exp(logs') * x1 + dlogdet[b]) * mask, chained through sigmoid_scale ; dout = [dm ; dlogs] */
+int glowtts_coupling_fwd(const float *x, const float *out, const float *mask, float *z, float *logdet,
+                         int B, int C, int T, int sigmoid_scale, int reverse, glowtts_stream_t stream);
+int glowtts_coupling_bwd(const float *x, const float *out, const float *mask, const float *dz,
+                         const float *dlogdet, float *dx, float *dout, int B, int C, int T, int sigmoid_scale,
+                         glowtts_stream_t stream);
+
+/* ---- WN gate (utils.py:31-38) and residual/skip update (layers.py:157-161) ----------------------------------
+ * gate fwd: acts[b,c,t] = tanh(a[b,c,t] + g[b,c]) * sigmoid(a[b,H+c,t] + g[b,H+c]) ; a (B,2H,T), g (B,2H) or NULL
+ * gate bwd: da (B,2H,T) from dacts (B,H,T); the activations are recomputed from a, g (nothing else is saved).
+ *           (the conditioning gradient is the row sum of da over t, left to the caller: it exists only with speakers)
+ * res_skip fwd: x_out = (x + rs[:, :H]) * mask ; skip_out = skip_in + rs[:, H:]       (rs is (B,2H,T))
+ *               last layer (`last` = 1): rs is (B,H,T) and skip_out = (skip_in + rs) * mask, x_out untouched (may be NULL)
+ *               skip_in may be NULL (= 0); skip_out may alias skip_in.
+ * res_skip bwd: drs[:, :H] = dx_out * mask ; drs[:, H:] = dskip ; dx = dx_out * mask
+ *               last: drs = dskip * mask (H rows) ; dx / dx_out unused (may be NULL) */
+int glowtts_gate_fwd(const float *a, const float *g, float *acts, int B, int H, int T, glowtts_stream_t stream);
+int glowtts_gate_bwd(const float *a, const float *g, const float *dacts, float *da, int B, int H, int T,
+                     glowtts_stream_t stream);
+int glowtts_res_skip_fwd(const float *x, const float *rs, const float *mask, const float *skip_in, float *x_out,
+                         float *skip_out, int B, int H, int T, int last, glowtts_stream_t stream);
+int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *mask, float *dx, float *drs, int B,
+                         int H, int T, int last, glowtts_stream_t stream);
+
+/* ---- squeeze / unsqueeze (utils.py:135-160) -----------------------------------------------------------------
+ * squeeze  : x (B,C,T) -> xs (B, n*C, T/n): xs[b, s*C+c, t'] = x[b,c,n*t'+s] * mask[b, n*t'+n-1] ; ms[b,t'] = mask[b, n*t'+n-1]
+ * unsqueeze: xs (B, n*C, T') -> x (B,C,n*T'): x[b,c,n*t'+s] = xs[b,s*C+c,t'] * ms[b,t'] ; mask_out[b,n*t'+s] = ms[b,t']
+ * (each is the other's adjoint up to the mask, so they also serve as each other's backward) */
+int glowtts_squeeze(const float *x, const float *mask, float *xs, float *ms, int B, int C, int T, int n,
+                    glowtts_stream_t stream);
+int glowtts_unsqueeze(const float *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq, int n,
+                      glowtts_stream_t stream);
+
+/* ---- mle_loss (utils.py:14-23) ------------------------------------------------------------------------------
+ * fwd : acc[0] += sum(logs) + 0.5*sum(exp(-2 logs) (z-m)^2) ; acc[1] += sum over (b,t) of mask  (accumulated;
+ *       the scalar loss = (acc[0] - sum(logdet)) / (C*acc[1]) + 0.5*log(2*pi) is finished by the caller)
+ * bwd : with s = dloss / (C * sum mask) read from scale[0] on device:
+ *       dz = s*exp(-2logs)(z-m) ; dm = -dz ; dlogs = s*(1 - exp(-2logs)(z-m)^2)   (mask is NOT applied, as in the reference) */
+int glowtts_mle_fwd(const float *z, const float *m, const float *logs, const float *mask, float *acc, int B,
+                    int C, int T, glowtts_stream_t stream);
+int glowtts_mle_bwd(const float *z, const float *m, const float *logs, const float *scale, float *dz, float *dm,
+                    float *dlogs, int64_t n, glowtts_stream_t stream);
+
+/* ---- clip_grad_value_ (utils.py:118-132) and Adam + Noam (optimize.py:8-64) over FLAT buffers ---------------
+ * clip : sumsq[0] += sum g^2 (pre-clamp, as the reference's norm) ; g = clamp(g, -clip, clip)
+ * adam : state[0] = Adam step t (float, >= 1 at the call), state[1] = Noam step_num; the learning rate
+ *        lr * dim_model^-0.5 * min(s^-0.5, s * warmup^-1.5) (or `lr` if warmup <= 0) is computed ON DEVICE from
+ *        state so a captured graph replays with the right rate; torch.optim.Adam arithmetic (no amsgrad/decay).
+ * adam_advance: state[0] += 1; state[1] += 1; state[2] = learning rate of the NEXT update (optimize.py:43-48) */
+int glowtts_clip_grad_value(float *g, int64_t n, float clip, float *sumsq, glowtts_stream_t stream);
+int glowtts_adam_noam(float *p, const float *g, float *m, float *v, int64_t n, const float *state, float lr,
+                      float beta1, float beta2, float eps, float dim_model, float warmup,
+                      glowtts_stream_t stream);
+int glowtts_adam_advance(float *state, float lr, float dim_model, float warmup, glowtts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOWTTS_HIP_H */

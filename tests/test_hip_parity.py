@@ -1,0 +1,496 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libglowtts_hip.so via ctypes), against
+  (1) golden vectors produced by the real reference (tests/golden, oracle/make_golden.py),
+  (2) the CPU oracle (oracle/) on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes (flow invertibility, MAS path structure).
+
+Tolerances: MAS bit-exact; fp32 kernels 1e-3 relative (BASELINE.json north_star) — most checks are far tighter and
+say so.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import T, assert_close, load_golden, rel_err, split_prefix
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-3          # north-star tolerance
+TIGHT = dict(rtol=1e-4, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def G():
+    """The drop-in package (fails loudly if the HIP library is absent)."""
+    from glow_tts_train import _hip, attentions, layers, models, monotonic_align, ops, optimize, utils
+
+    _hip.load()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.hip, ns.attentions, ns.layers, ns.models = _hip, attentions, layers, models
+    ns.mas, ns.ops, ns.optimize, ns.utils = monotonic_align, ops, optimize, utils
+    return ns
+
+
+def dev(a, **kw):
+    return T(a, **kw).cuda()
+
+
+def load_sd(module, golden, prefix="sd."):
+    sd = split_prefix(golden, prefix)
+    module.load_state_dict(sd)
+    return module.cuda()
+
+
+def check_param_grads(module, golden, what, rtol=2e-4, atol=5e-5):
+    gg = split_prefix(golden, "grad.")
+    named = dict(module.named_parameters())
+    assert gg
+    for k, want in gg.items():
+        assert named[k].grad is not None, f"{what}: no grad for {k}"
+        assert_close(named[k].grad, want, what=f"{what} grad {k}", rtol=rtol, atol=atol)
+
+
+# =============================================================================================== library
+def test_library_is_the_hip_one(G):
+    lib = G.hip.load()
+    assert lib.glowtts_abi_version() == 1
+    assert G.hip.library_path().endswith("glow-tts-train_amd/lib/libglowtts_hip.so")
+    with pytest.raises(RuntimeError):
+        G.ops.mask_len(torch.ones(2, 3))          # CPU tensor: no fallback, loud failure
+    with pytest.raises(RuntimeError, match="n_split"):
+        x = torch.zeros(1, 12, 4, device="cuda")
+        G.ops.invconv_apply(x, torch.ones(1, 4, device="cuda"), torch.eye(6, device="cuda"), 6)
+
+
+# =============================================================================================== MAS
+def test_mas_golden_bit_exact(G):
+    g = load_golden("mas_cases")
+    for i in range(int(g["n"])):
+        v, tx, ty, want = g[f"value{i}"], g[f"tx{i}"], g[f"ty{i}"], g[f"path{i}"]
+        got = G.ops.mas_path(dev(v), dev(tx), dev(ty)).cpu().numpy()
+        assert got.dtype == np.float32
+        assert (got == want.astype(np.float32)).all(), f"MAS golden case {i} (shape {v.shape}) differs"
+
+
+def test_mas_reference_wrapper_semantics(G):
+    """maximum_path(value, mask): lengths come from the mask, result has value's dtype/device (__init__.py:6-21)."""
+    g = load_golden("mas_cases")
+    i = 4
+    v, tx, ty, want = g[f"value{i}"], g[f"tx{i}"], g[f"ty{i}"], g[f"path{i}"]
+    b, mx, my = v.shape
+    mask = np.zeros_like(v)
+    for j in range(b):
+        mask[j, : tx[j], : ty[j]] = 1
+    out = G.mas.maximum_path(dev(v), dev(mask))
+    assert out.is_cuda and out.dtype == torch.float32
+    assert (out.cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("b,tx,ty", [(32, 160, 800), (8, 100, 400), (5, 257, 1000), (3, 500, 520), (64, 200, 1000)])
+def test_mas_vs_oracle_full_size(G, b, tx, ty):
+    from oracle import glow_oracle as O
+
+    rng = np.random.RandomState(b * 1000 + tx)
+    v = (rng.randn(b, tx, ty) * 3).astype(np.float32)
+    txs = rng.randint(max(1, tx // 3), tx + 1, size=b).astype(np.int32)
+    tys = np.maximum(txs, rng.randint(ty // 2, ty + 1, size=b)).astype(np.int32)
+    txs[0], tys[0] = tx, ty
+    got = G.ops.mas_path(dev(v), dev(txs), dev(tys)).cpu().numpy()
+    mask = np.zeros_like(v)
+    for j in range(b):
+        mask[j, : txs[j], : tys[j]] = 1
+    want = O.mas_numpy(v * mask, txs, tys)
+    assert (got == want.astype(np.float32)).all()
+    # structure: one token per frame, monotone, surjective
+    for j in range(b):
+        p = got[j, : txs[j], : tys[j]]
+        assert got[j].sum() == tys[j] and (p.sum(0) == 1).all()
+        idx = p.argmax(0)
+        d = np.diff(idx)
+        assert ((d == 0) | (d == 1)).all() and idx[0] == 0 and idx[-1] == txs[j] - 1
+
+
+def test_mas_ties_and_quantised(G):
+    from oracle import glow_oracle as O
+
+    rng = np.random.RandomState(5)
+    v = np.round(rng.randn(6, 70, 300)).astype(np.float32)       # integers: ties everywhere
+    txs = np.array([70, 64, 65, 1, 33, 2], np.int32)
+    tys = np.array([300, 64, 299, 300, 34, 2], np.int32)
+    got = G.ops.mas_path(dev(v), dev(txs), dev(tys)).cpu().numpy()
+    mask = np.zeros_like(v)
+    for j in range(6):
+        mask[j, : txs[j], : tys[j]] = 1
+    assert (got == O.mas_numpy(v * mask, txs, tys)).all()
+
+
+# =============================================================================================== flows vs golden
+@pytest.mark.parametrize("name", ["actnorm_c8", "actnorm_c160"])
+def test_actnorm_golden(G, name):
+    g = load_golden(name)
+    f = load_sd(G.layers.ActNorm(g["x"].shape[1]), g)
+    x = dev(g["x"]).requires_grad_(True)
+    mask = dev(g["mask"])
+    z, logdet = f(x, mask)
+    assert_close(z, g["z"], what="z", **TIGHT)
+    assert_close(logdet, g["logdet"], what="logdet", **TIGHT)
+    ((z * dev(g["r"])).sum() + (logdet * dev(g["s"])).sum()).backward()
+    assert_close(x.grad, g["dx"], what="dx", **TIGHT)
+    check_param_grads(f, g, name)
+    xr, ld = f(z.detach(), mask, reverse=True)
+    assert ld is None
+    assert_close(xr, g["x_rev"], what="x_rev", **TIGHT)
+
+
+def test_actnorm_ddi_golden(G):
+    g = load_golden("actnorm_ddi")
+    f = G.layers.ActNorm(8, ddi=True).cuda()
+    z, logdet = f(dev(g["x"]), dev(g["mask"]))
+    assert f.initialized
+    assert_close(f.logs, g["sd.logs"], what="logs", **TIGHT)
+    assert_close(f.bias, g["sd.bias"], what="bias", **TIGHT)
+    assert_close(z, g["z"], what="z", **TIGHT)
+    assert_close(logdet, g["logdet"], what="logdet", **TIGHT)
+
+
+@pytest.mark.parametrize("name,n_split", [("invconv_c8_s4", 4), ("invconv_c8_s2", 2), ("invconv_c160_s4", 4)])
+def test_invconv_golden(G, name, n_split):
+    g = load_golden(name)
+    f = load_sd(G.layers.InvConvNear(g["x"].shape[1], n_split=n_split), g)
+    x = dev(g["x"]).requires_grad_(True)
+    mask = dev(g["mask"])
+    z, logdet = f(x, mask)
+    assert_close(z, g["z"], what="z", **TIGHT)
+    assert_close(logdet, g["logdet"], what="logdet", **TIGHT)
+    ((z * dev(g["r"])).sum() + (logdet * dev(g["s"])).sum()).backward()
+    assert_close(x.grad, g["dx"], what="dx", **TIGHT)
+    check_param_grads(f, g, name)
+    f.store_inverse()
+    xr, ld = f(z.detach(), mask, reverse=True)
+    assert ld is None
+    assert_close(xr, g["x_rev"], what="x_rev", **TIGHT)
+
+
+def test_invconv_prepare_matches_torch(G):
+    torch.manual_seed(3)
+    for n in (2, 4, 6, 8):
+        w = torch.randn(n, n)
+        if torch.det(w) < 0:
+            w[:, 0] = -w[:, 0]
+        w_inv, ld = G.ops.invconv_prepare(w.cuda())
+        assert_close(w_inv, torch.inverse(w.double()), what=f"inverse n={n}", rtol=1e-4, atol=1e-5)
+        assert_close(ld[0], torch.logdet(w.double()), what=f"logdet n={n}", rtol=1e-5, atol=1e-5)
+    w = torch.eye(4)
+    w[0, 0] = -1.0                                                     # det < 0 -> NaN, as torch.logdet
+    assert torch.isnan(G.ops.invconv_prepare(w.cuda())[1]).all()
+
+
+@pytest.mark.parametrize("name,sig,gin,k,dil,nl", [
+    ("coupling_c8_h16_sig0_gin0", False, 0, 5, 1, 3),
+    ("coupling_c8_h16_sig0_gin8", False, 8, 5, 1, 3),
+    ("coupling_c8_h16_sig1_gin0", True, 0, 5, 1, 3),
+    ("coupling_c8_h16_sig1_gin8", True, 8, 5, 1, 3),
+    ("coupling_c8_h16_k3_d2", False, 0, 3, 2, 3),
+])
+def test_coupling_golden(G, name, sig, gin, k, dil, nl):
+    g = load_golden(name)
+    f = load_sd(G.attentions.CouplingBlock(8, 16, kernel_size=k, dilation_rate=dil, n_layers=nl, gin_channels=gin,
+                                           p_dropout=0.0, sigmoid_scale=sig), g)
+    x = dev(g["x"]).requires_grad_(True)
+    mask = dev(g["mask"])
+    gc = dev(g["g"]).requires_grad_(True) if gin else None
+    z, logdet = f(x, mask, g=gc)
+    assert_close(z, g["z"], what="z", **TIGHT)
+    assert_close(logdet, g["logdet"], what="logdet", **TIGHT)
+    ((z * dev(g["r"])).sum() + (logdet * dev(g["s"])).sum()).backward()
+    assert_close(x.grad, g["dx"], what="dx", rtol=2e-4, atol=5e-5)
+    if gin:
+        assert_close(gc.grad, g["dg"], what="dg", rtol=2e-4, atol=5e-5)
+    check_param_grads(f, g, name)
+    with torch.no_grad():
+        f.store_inverse()
+        xr, ld = f(z.detach(), mask, g=None if gc is None else gc.detach(), reverse=True)
+    assert ld is None
+    assert_close(xr, g["x_rev"], what="x_rev", rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("gin", [0, 8])
+def test_wn_golden(G, gin):
+    g = load_golden(f"wn_h16_gin{gin}")
+    f = load_sd(G.layers.WN(16, 16, 5, 1, 3, gin_channels=gin, p_dropout=0.0), g)
+    x = dev(g["x"]).requires_grad_(True)
+    gc = dev(g["g"]).requires_grad_(True) if gin else None
+    out = f(x, dev(g["mask"]), gc)
+    assert_close(out, g["out"], what="out", **TIGHT)
+    (out * dev(g["r"])).sum().backward()
+    assert_close(x.grad, g["dx"], what="dx", rtol=2e-4, atol=5e-5)
+    if gin:
+        assert_close(gc.grad, g["dg"], what="dg", rtol=2e-4, atol=5e-5)
+    check_param_grads(f, g, "wn")
+
+
+def test_gate_and_squeeze_golden(G):
+    g = load_golden("gate_h16")
+    a, b = dev(g["a"]).requires_grad_(True), dev(g["b"]).requires_grad_(True)
+    acts = G.utils.fused_add_tanh_sigmoid_multiply(a, b, torch.IntTensor([16]))
+    assert_close(acts, g["acts"], what="acts", **TIGHT)
+    (acts * dev(g["r"])).sum().backward()
+    assert_close(a.grad, g["da"], what="da", **TIGHT)
+    assert_close(b.grad, g["db"], what="db", **TIGHT)
+
+    g = load_golden("squeeze_c6_t11")
+    x = dev(g["x"]).requires_grad_(True)
+    xs, ms = G.utils.squeeze(x, dev(g["mask"]), 2)
+    assert_close(xs, g["x_sqz"], what="x_sqz", rtol=0, atol=0)
+    assert_close(ms, g["mask_sqz"], what="mask_sqz", rtol=0, atol=0)
+    xu, mu = G.utils.unsqueeze(xs, ms, 2)
+    assert_close(xu, g["x_unsqz"], what="x_unsqz", rtol=0, atol=0)
+    assert_close(mu, g["mask_unsqz"], what="mask_unsqz", rtol=0, atol=0)
+    # backward of squeeze/unsqueeze against torch autograd of the oracle's layout shuffle
+    from oracle import glow_oracle as O
+
+    r = torch.randn_like(xu)
+    (xu * r).sum().backward()
+    xo = T(g["x"]).requires_grad_(True)
+    xso, mso = O.squeeze(xo, T(g["mask"]), 2)
+    xuo, _ = O.unsqueeze(xso, mso, 2)
+    (xuo * r.cpu()).sum().backward()
+    assert_close(x.grad, xo.grad, what="d squeeze/unsqueeze", rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name", ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4"])
+def test_attention_golden(G, name):
+    g = load_golden(name)
+    win, blk = int(g["window"]), int(g["block"])
+    f = load_sd(G.attentions.MultiHeadAttention(16, 16, 2, window_size=None if win < 0 else win, p_dropout=0.0,
+                                                block_length=None if blk < 0 else blk), g)
+    x = dev(g["x"]).requires_grad_(True)
+    mask = dev(g["mask"])
+    y = f(x, x, mask.unsqueeze(2) * mask.unsqueeze(-1))
+    assert_close(y, g["y"], what="y", **TIGHT)
+    if f.attn is not None:
+        assert_close(f.attn, g["p_attn"], what="p_attn", **TIGHT)
+    (y * dev(g["r"])).sum().backward()
+    assert_close(x.grad, g["dx"], what="dx", rtol=2e-4, atol=5e-5)
+    check_param_grads(f, g, name)
+
+
+def test_losses_golden(G):
+    g = load_golden("losses")
+    z, m, logs = (dev(g[k]).requires_grad_(True) for k in ("z", "m", "logs"))
+    logdet = dev(g["logdet"]).requires_grad_(True)
+    loss = G.utils.mle_loss(z, m, logs, logdet, dev(g["mask"]))
+    assert_close(loss, g["loss"], what="mle", **TIGHT)
+    loss.backward()
+    for t, k in ((z, "dz"), (m, "dm"), (logs, "dlogs"), (logdet, "dlogdet")):
+        assert_close(t.grad, g[k], what=k, **TIGHT)
+    logw = dev(g["logw"]).requires_grad_(True)
+    dl = G.utils.duration_loss(logw, dev(g["logw_"]), dev(g["lengths"]))
+    assert_close(dl, g["dur_loss"], what="dur", **TIGHT)
+
+
+# =============================================================================================== end to end vs golden
+def _small_generator(G, tag):
+    kw = dict(n_vocab=148, hidden_channels=32, filter_channels=64, filter_channels_dp=32, out_channels=80,
+              kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.0, n_blocks_dec=2, kernel_size_dec=5,
+              dilation_rate=1, n_block_layers=2, p_dropout_dec=0.0, n_speakers=0, gin_channels=0, n_split=4, n_sqz=2,
+              sigmoid_scale=False, window_size=4, block_length=None, mean_only=True, hidden_channels_enc=32,
+              hidden_channels_dec=32, prenet=True)
+    if tag == "spk":
+        kw.update(gin_channels=8, n_speakers=3, mean_only=False, sigmoid_scale=True)
+    m = G.models.FlowGenerator(**kw)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+@pytest.mark.parametrize("tag", ["base", "spk"])
+def test_e2e_train_golden(G, tag):
+    g = load_golden(f"e2e_{tag}_train")
+    model = load_sd(_small_generator(G, tag), g).train()
+    spk = dev(g["speaker_ids"]) if "speaker_ids" in g else None
+    x, xl, y, yl = dev(g["x"]), dev(g["x_lengths"]), dev(g["y"]), dev(g["y_lengths"])
+    opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=32, warmup_steps=4000, lr=1.0,
+                          betas=(0.9, 0.98), eps=1e-9)
+    opt.zero_grad()
+    (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = model(x, xl, y, yl, g=spk)
+    outs = dict(z=z, z_m=z_m, z_logs=z_logs, logdet=logdet, z_mask=z_mask, x_m=x_m, x_logs=x_logs, x_mask=x_mask,
+                logw=logw, logw_=logw_)
+    for name, t in outs.items():
+        assert rel_err(t, g[name]) < REL, f"{name}: rel err {rel_err(t, g[name]):.3e}"
+        assert_close(t, g[name], what=name, rtol=5e-4, atol=1e-4)
+    assert (attn.cpu().numpy().astype(np.int8) == g["attn"]).all(), "alignment differs from the reference"
+    l_mle = G.utils.mle_loss(z, z_m, z_logs, logdet, z_mask)
+    l_len = G.utils.duration_loss(logw, logw_, xl)
+    assert_close(l_mle, g["l_mle"], what="l_mle", **TIGHT)
+    assert_close(l_len, g["l_length"], what="l_length", **TIGHT)
+    (l_mle + l_len).backward()
+    gg = split_prefix(g, "grad.")
+    named = dict(model.named_parameters())
+    for k, want in gg.items():
+        assert named[k].grad is not None, k
+        assert_close(named[k].grad, want, what="grad " + k, rtol=2e-3, atol=2e-4)
+    tn = G.utils.clip_grad_value_(model.parameters(), 5.0)
+    assert abs(float(tn) - float(g["total_norm"])) <= 1e-3 * float(g["total_norm"])
+    lrs = [opt.cur_lr]
+    # the golden run applies the SAME (clamped) gradients three times: optimizer.step() does not touch .grad
+    for _ in range(3):
+        opt.step()
+        lrs.append(opt.cur_lr)
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+    after = split_prefix(g, "sd_after3.")
+    sd_now = model.state_dict()
+    for k, want in after.items():
+        assert_close(sd_now[k], want, what="after3 " + k, rtol=2e-3, atol=2e-5)
+    st = opt._optim.dev_state.cpu()
+    assert st[0] == 4.0 and st[1] == 4.0 and abs(float(st[2]) - g["lrs"][3]) <= 1e-6 * g["lrs"][3]
+
+
+@pytest.mark.parametrize("tag", ["base", "spk"])
+def test_e2e_generate_golden(G, tag):
+    gt = load_golden(f"e2e_{tag}_train")
+    g = load_golden(f"e2e_{tag}_gen")
+    model = load_sd(_small_generator(G, tag), gt).eval()
+    model.decoder.store_inverse()
+    spk = dev(g["speaker_ids"]) if "speaker_ids" in g else None
+    noise = dev(g["noise"])
+    orig = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: noise
+    try:
+        with torch.no_grad():
+            (y, z_m, z_logs, ld, z_mask), _, (attn, logw, logw_) = model(
+                dev(g["x"]), dev(g["x_lengths"]), g=spk, gen=True, noise_scale=float(g["noise_scale"]), length_scale=1.0)
+    finally:
+        torch.randn_like = orig
+    assert ld is None
+    assert (attn.cpu().numpy().astype(np.int8) == g["attn"]).all()
+    for name, t in dict(y=y, z_m=z_m, z_logs=z_logs, z_mask=z_mask, logw=logw, logw_=logw_).items():
+        assert rel_err(t, g[name]) < REL, f"{name}: rel err {rel_err(t, g[name]):.3e}"
+
+
+# =============================================================================================== HIP vs oracle, mid size
+def _oracle_pair(G, hp, seed=11):
+    from oracle import glow_oracle as O
+
+    sd = O.init_state_dict(hp, seed=seed)
+    for k in list(sd):
+        if k.endswith(".end.weight"):
+            sd[k] = 0.05 * torch.randn_like(sd[k])
+    m = G.models.FlowGenerator(
+        n_vocab=hp.n_vocab, hidden_channels=hp.hidden_channels, filter_channels=hp.filter_channels,
+        filter_channels_dp=hp.filter_channels_dp, out_channels=hp.out_channels, kernel_size=hp.kernel_size,
+        n_heads=hp.n_heads, n_layers_enc=hp.n_layers_enc, p_dropout=0.0, n_blocks_dec=hp.n_blocks_dec,
+        kernel_size_dec=hp.kernel_size_dec, dilation_rate=hp.dilation_rate, n_block_layers=hp.n_block_layers,
+        p_dropout_dec=0.0, n_speakers=hp.n_speakers, gin_channels=hp.gin_channels, n_split=hp.n_split, n_sqz=hp.n_sqz,
+        sigmoid_scale=hp.sigmoid_scale, window_size=hp.window_size, mean_only=hp.mean_only, prenet=hp.prenet)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return sd, m.cuda().train()
+
+
+def test_decoder_vs_oracle_config1_shapes(G):
+    """FlowSpecDecoder forward + backward at BASELINE config 1 decoder shapes (B=8, 80 x 400, 6 blocks, H=192)."""
+    from oracle import glow_oracle as O
+
+    hp = O.HParams(n_blocks_dec=6, n_layers_enc=1)
+    sd, model = _oracle_pair(G, hp)
+    torch.manual_seed(0)
+    b, t = 8, 400
+    yl = torch.linspace(t, t // 2, b).long()
+    y = torch.randn(b, 80, t) * (torch.arange(t)[None, None] < yl[:, None, None])
+    mask = (torch.arange(t)[None, None] < ((yl // 2) * 2)[:, None, None]).float()
+    r = torch.randn(b, 80, t)
+    s = torch.randn(b)
+
+    yd = y.cuda().requires_grad_(True)
+    z, logdet = model.decoder(yd, mask.cuda())
+    ((z * r.cuda()).sum() + (logdet * s.cuda()).sum()).backward()
+
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    yo = y.clone().requires_grad_(True)
+    zo, ldo = O.flow_decoder(sdo, yo, mask, None, hp)
+    ((zo * r).sum() + (ldo * s).sum()).backward()
+
+    assert rel_err(z, zo) < REL and rel_err(logdet, ldo) < REL, (rel_err(z, zo), rel_err(logdet, ldo))
+    assert rel_err(yd.grad, yo.grad) < REL, rel_err(yd.grad, yo.grad)
+    named = dict(model.named_parameters())
+    worst = max((rel_err(named[k].grad, v.grad), k) for k, v in sdo.items())
+    assert worst[0] < 5e-3, worst            # parameter gradients: long fp32 reductions in different orders
+    # reverse path: mel back from z (the "mel output within 1e-3" target)
+    with torch.no_grad():
+        model.decoder.store_inverse()
+        yr, _ = model.decoder(z.detach(), mask.cuda(), reverse=True)
+    assert rel_err(yr, y * mask) < REL
+
+
+def test_full_step_vs_oracle_small_config(G):
+    """Whole training step (forward, both losses, backward, clamp, Adam/Noam) vs the oracle, multi-speaker variant."""
+    from oracle import glow_oracle as O
+
+    hp = O.HParams(n_vocab=60, hidden_channels=64, filter_channels=128, filter_channels_dp=64, n_layers_enc=2,
+                   n_blocks_dec=3, n_block_layers=2, n_speakers=4, gin_channels=16, mean_only=False)
+    sd, model = _oracle_pair(G, hp, seed=5)
+    torch.manual_seed(1)
+    b, tx, ty = 4, 30, 160
+    xl = torch.tensor([30, 25, 17, 9])
+    yl = torch.tensor([160, 140, 101, 48])
+    x = torch.randint(1, 60, (b, tx)) * (torch.arange(tx)[None] < xl[:, None])
+    y = torch.randn(b, 80, ty) * (torch.arange(ty)[None, None] < yl[:, None, None])
+    spk = torch.tensor([0, 3, 1, 2])
+
+    opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=64, warmup_steps=4000, lr=1.0)
+    from glow_tts_train.train import train_batch
+
+    loss = train_batch(model, opt, (x.cuda(), xl.cuda(), y.cuda(), yl.cuda(), spk.cuda()), 5.0)
+
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oopt = O.AdamNoam({k: v for k, v in sdo.items()}, dim_model=64)
+    oloss, frames = O.train_step(sdo, hp, oopt, (x, xl, y, yl, spk), 5.0)
+    assert frames == int(yl.sum())
+    assert abs(float(loss) - oloss) <= 1e-3 * abs(oloss), (float(loss), oloss)
+    now = model.state_dict()
+    # after one Adam step every parameter moved by ~lr; compare the UPDATE, not just the value
+    worst = 0.0
+    for k, v in sdo.items():
+        upd_o = v.detach() - sd[k]
+        upd_h = now[k].cpu() - sd[k]
+        if upd_o.abs().max() == 0:
+            continue
+        worst = max(worst, float((upd_h - upd_o).abs().max() / upd_o.abs().max()))
+    assert worst < 2e-2, worst     # sign-like Adam update amplifies tiny gradient differences near zero gradients
+
+
+# =============================================================================================== full-size properties
+def test_full_size_decoder_roundtrip_and_mas_properties(G):
+    """BASELINE config 2 sizes (B=32, T_mel=800, T_text=160, 12 blocks): size-independent checks only."""
+    from oracle import glow_oracle as O
+
+    hp = O.HParams()
+    sd, model = _oracle_pair(G, hp, seed=2)
+    torch.manual_seed(4)
+    b, t = 32, 800
+    y = torch.randn(b, 80, t, device="cuda")
+    mask = torch.ones(b, 1, t, device="cuda")
+    with torch.no_grad():
+        z, logdet = model.decoder(y, mask)
+        model.decoder.store_inverse()
+        yr, _ = model.decoder(z, mask, reverse=True)
+    assert torch.isfinite(z).all() and torch.isfinite(logdet).all()
+    assert rel_err(yr, y) < REL
+    # linearity of the log-det in the number of frames: an utterance of half the length has half the ActNorm+InvConv part
+    v = torch.randn(b, 160, t, device="cuda")
+    tx = torch.full((b,), 160, dtype=torch.int32, device="cuda")
+    ty = torch.full((b,), t, dtype=torch.int32, device="cuda")
+    p = G.ops.mas_path(v, tx, ty)
+    assert (p.sum(1) == 1).all() and p.sum() == b * t
+    idx = p.argmax(1)
+    d = idx[:, 1:] - idx[:, :-1]
+    assert ((d == 0) | (d == 1)).all() and (idx[:, 0] == 0).all() and (idx[:, -1] == 159).all()
+    # idempotence: the path of a lattice that rewards exactly that path is the same path
+    assert (G.ops.mas_path(p * 10.0, tx, ty) == p).all()

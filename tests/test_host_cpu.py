@@ -1,0 +1,299 @@
+"""CPU tests of the host side: C-ABI surface, state-dict schema, flat-buffer optimizer, data-parallel reducer over
+gloo (world_size 2), config, and loud failure without a GPU.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, T, assert_close, load_golden, split_prefix
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "glowtts_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glowtts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from glow_tts_train import _hip
+
+    so = _hip.library_path()
+    assert os.path.exists(so), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(so)
+    declared = _header_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/glowtts_hip.h but not exported"
+    # the Python binding table and the header agree exactly
+    assert sorted(_hip.EXPORTED_SYMBOLS) == declared
+    lib.glowtts_abi_version.restype = ctypes.c_int
+    assert lib.glowtts_abi_version() == 1
+
+
+def test_cabi_argument_errors_do_not_need_a_gpu():
+    """Argument validation happens on the host before any launch: exercise it without a device."""
+    from glow_tts_train import _hip
+
+    lib = _hip.load()
+    rc = lib.glowtts_invconv_prepare(None, None, None, 4, None)
+    assert rc != 0 and b"null pointer" in lib.glowtts_last_error()
+    rc = lib.glowtts_mas_path(1, 1, 1, 1, 1, 600, 10, None)           # non-null dummies; Tx over the limit
+    assert rc != 0 and b"512" in lib.glowtts_last_error()
+    rc = lib.glowtts_invconv_fwd(1, 1, 1, None, None, 1, None, 1, 12, 4, 6, None)
+    assert rc != 0 and b"n_split" in lib.glowtts_last_error()
+    assert lib.glowtts_actnorm_fwd(1, 1, 1, 1, None, 1, None, 0, 4, 0, 0, None) == 0   # empty batch: no launch
+
+
+def test_product_fails_loudly_without_gpu():
+    from glow_tts_train import layers, monotonic_align, utils
+
+    f = layers.ActNorm(4)
+    with pytest.raises(RuntimeError, match="CPU tensor|HIP"):
+        f(torch.zeros(1, 4, 8), torch.ones(1, 1, 8))
+    with pytest.raises(RuntimeError):
+        monotonic_align.maximum_path(torch.zeros(1, 2, 3), torch.ones(1, 2, 3))
+    with pytest.raises(RuntimeError):
+        utils.mle_loss(*(torch.zeros(1, 2, 4) for _ in range(3)), torch.zeros(1), torch.ones(1, 1, 4))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "glow-tts-train_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{fn} mentions the oracle"
+                assert "/root/reference" not in src
+
+
+# ------------------------------------------------------------------------------------------------ schema
+def _make(tag="base", **over):
+    from glow_tts_train import models
+
+    kw = dict(n_vocab=148, hidden_channels=32, filter_channels=64, filter_channels_dp=32, out_channels=80,
+              kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.0, n_blocks_dec=2, kernel_size_dec=5,
+              dilation_rate=1, n_block_layers=2, p_dropout_dec=0.0, n_speakers=0, gin_channels=0, n_split=4, n_sqz=2,
+              sigmoid_scale=False, window_size=4, block_length=None, mean_only=True, hidden_channels_enc=32,
+              hidden_channels_dec=32, prenet=True)
+    if tag == "spk":
+        kw.update(gin_channels=8, n_speakers=3, mean_only=False, sigmoid_scale=True)
+    kw.update(over)
+    return models.FlowGenerator(**kw)
+
+
+@pytest.mark.parametrize("tag", ["base", "spk"])
+def test_state_dict_schema_matches_reference(tag):
+    g = load_golden(f"e2e_{tag}_train")
+    want = {k: v.shape for k, v in split_prefix(g, "sd.", as_torch=False).items()}
+    got = {k: tuple(v.shape) for k, v in _make(tag).state_dict().items()}
+    assert list(got) == list(want), "state-dict key ORDER/NAMES differ from the reference"
+    assert got == {k: tuple(s) for k, s in want.items()}
+    m = _make(tag)
+    m.load_state_dict(split_prefix(g, "sd."))                         # strict load works
+
+
+def test_default_config_model_size_and_setup_model():
+    from glow_tts_train import config, models
+
+    cfg = config.TrainingConfig()
+    cfg.model.num_symbols = 148
+    model, opt = models.setup_model(cfg, use_cuda=False, create_optimizer=False)
+    assert opt is None
+    assert sum(p.numel() for p in model.parameters()) == 28_623_889
+    assert len(list(model.parameters())) == 519
+    assert len(model.decoder.flows) == 36 and model.n_sqz == 2
+    flows = list(model.decoder.flows)
+    assert [type(f).__name__ for f in flows[:3]] == ["ActNorm", "InvConvNear", "CouplingBlock"]
+    assert all(hasattr(f, "store_inverse") for f in flows)
+    assert hasattr(flows[0], "set_ddi")
+    w = flows[1].weight.detach()
+    assert_close(w @ w.t(), torch.eye(4), what="orthogonal init", rtol=0, atol=1e-5)
+    assert torch.det(w) > 0
+    assert flows[2].end.weight.abs().max() == 0 and flows[2].end.bias.abs().max() == 0
+    d = cfg.to_dict()
+    cfg2 = config.TrainingConfig.from_dict(d)
+    assert cfg2 == cfg and cfg2.model.n_blocks_dec == 12 and cfg2.betas == (0.9, 0.98)
+
+
+def test_ddi_helper_contract():
+    """ddi.py:10-17 flips every flow that has set_ddi; ActNorm then initialises on its first forward."""
+    m = _make()
+    n = 0
+    for f in m.decoder.flows:
+        if getattr(f, "set_ddi", False):
+            f.set_ddi(True)
+            assert not f.initialized
+            n += 1
+    assert n == 2
+
+
+def test_generate_path_and_sequence_mask():
+    from glow_tts_train import utils
+    from oracle import glow_oracle as O
+
+    dur = torch.tensor([[2.0, 0.0, 3.0, 1.0], [1.0, 1.0, 0.0, 0.0]])
+    mask = torch.zeros(2, 4, 7)
+    mask[0, :4, :6] = 1
+    mask[1, :2, :2] = 1
+    p = utils.generate_path(dur, mask)
+    assert_close(p, O.generate_path(dur, mask), rtol=0, atol=0)
+    assert p[0].sum(0).tolist() == [1, 1, 1, 1, 1, 1, 0]
+    assert p[0, 1].sum() == 0 and p[0, 2, 2:5].sum() == 3
+    assert utils.sequence_mask(torch.tensor([1, 3]), 4).tolist() == [[True, False, False, False], [True, True, True, False]]
+    assert utils.convert_pad_shape([[0, 0], [1, 2], [3, 4]]) == [3, 4, 1, 2, 0, 0]
+    assert utils.intersperse([1, 2], 0) == [0, 1, 0, 2, 0]
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_flat_adam_layout_and_noam_schedule():
+    from glow_tts_train import optimize
+
+    g = load_golden("e2e_base_train")
+    m = _make()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    opt = optimize.Adam(m.parameters(), scheduler="noam", dim_model=32, warmup_steps=4000, lr=1.0)
+    flat = opt._optim
+    # parameters are now views of ONE buffer, values unchanged, 256-byte aligned starts
+    for (k, v) in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    base = flat.flat_p.data_ptr()
+    for p, (o, n) in zip(m.parameters(), flat.slices()):
+        assert p.data_ptr() == base + 4 * o and o % 64 == 0 and n == p.numel()
+        assert p.grad is not None and p.grad.data_ptr() == flat.flat_g.data_ptr() + 4 * o
+    assert flat.numel == sum(p.numel() for p in m.parameters())
+    # autograd accumulates INTO the flat buffer, zero_grad keeps the aliasing
+    loss = sum((p * p).sum() for p in m.parameters())
+    loss.backward()
+    assert flat.flat_g.abs().sum() > 0
+    first = next(iter(m.parameters()))
+    assert_close(first.grad, 2 * first.detach(), rtol=0, atol=0)
+    opt.zero_grad()
+    assert flat.flat_g.abs().sum() == 0 and first.grad.data_ptr() == flat.flat_g.data_ptr()
+    # host mirror of the Noam schedule == the reference's learning rates
+    lrs = [opt.cur_lr]
+    for _ in range(3):
+        opt._update_learning_rate()
+        lrs.append(opt.cur_lr)
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+    assert opt.get_lr() == lrs[-1] and opt._optim.param_groups[0]["lr"] == lrs[-1]
+    # state-dict round trip in torch.optim.Adam's layout
+    flat.flat_m.normal_()
+    flat.flat_v.uniform_()
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(list(m.parameters()))
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    m2 = _make()
+    opt2 = optimize.Adam(m2.parameters(), scheduler="noam", dim_model=32)
+    opt2.load_state_dict(sd)
+    for o, n in flat.slices():          # (padding between parameters is not part of the state)
+        assert torch.equal(opt2._optim.flat_m[o:o + n], flat.flat_m[o:o + n])
+        assert torch.equal(opt2._optim.flat_v[o:o + n], flat.flat_v[o:o + n])
+
+
+# ------------------------------------------------------------------------------------------------ data parallel (gloo)
+class _Toy(torch.nn.Module):
+    """Same parameter naming scheme as FlowGenerator (encoder.*, decoder.flows.N.*, emb_g) on plain CPU layers."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Linear(6, 6))
+        self.decoder = torch.nn.Module()
+        self.decoder.flows = torch.nn.ModuleList(torch.nn.Linear(6, 6) for _ in range(6))
+        self.emb_g = torch.nn.Embedding(3, 6)      # never used in forward: a parameter without gradient
+
+    def forward(self, x):
+        h = self.encoder(x)
+        for f in self.decoder.flows:
+            h = torch.tanh(f(h))
+        return h
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    import sys
+
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    from glow_tts_train import optimize, parallel
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)               # different initial weights per rank: broadcast must fix that
+        model = _Toy()
+        opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+        red = parallel.FlowBlockReducer(model, opt)
+        red.broadcast_parameters(0)
+        keys = [b.key for b in red.buckets]
+        torch.manual_seed(7)
+        data = torch.randn(world * 4, 6)
+        shard = data[rank * 4:(rank + 1) * 4]
+        opt.zero_grad()
+        model(shard).pow(2).mean().backward()
+        launched_during_backward = sum(red._launched)
+        red.finish()
+        q.put((rank, keys, launched_during_backward, opt._optim.flat_p.numpy().copy(), opt._optim.flat_g.numpy().copy()))  # by value
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flow_block_reducer_gloo_world2():
+    from glow_tts_train import optimize
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, keys0, l0, p0, g0), (_, keys1, l1, p1, g1) = res
+    p0, g0, p1, g1 = (torch.from_numpy(a) for a in (p0, g0, p1, g1))
+    assert keys0 == ["enc", "dec000", "dec001", "misc"] == keys1     # 6 flows -> 2 blocks of 3
+    assert l0 >= 2 and l1 >= 2          # decoder buckets were reduced while backward was still running
+    assert torch.equal(p0, p1), "parameters differ after broadcast"
+    assert torch.equal(g0, g1), "averaged gradients differ between ranks"
+    # single-process reference: same weights (rank 0's), mean of the per-rank losses == DDP semantics
+    torch.manual_seed(100)
+    model = _Toy()
+    opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+    torch.manual_seed(7)
+    data = torch.randn(world * 4, 6)
+    opt.zero_grad()
+    (sum(model(data[r * 4:(r + 1) * 4]).pow(2).mean() for r in range(world)) / world).backward()
+    assert_close(g0, opt._optim.flat_g, what="averaged grads", rtol=1e-5, atol=1e-7)
+    assert g0[opt._optim.slices()[-1][0]:].abs().sum() == 0            # unused embedding: zeros, still reduced
+
+
+def test_reducer_single_process_is_a_noop():
+    from glow_tts_train import optimize, parallel
+
+    model = _Toy()
+    opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+    red = parallel.FlowBlockReducer(model, opt)
+    assert red.world == 1 and not red._hooks
+    model(torch.randn(2, 6)).sum().backward()
+    red.finish()
+    red.broadcast_parameters()
+    sizes = [(b.key, b.hi - b.lo) for b in red.buckets]
+    assert sizes[0][0] == "enc" and all(s > 0 for _, s in sizes)
+    # buckets tile the flat buffer in order without overlap
+    for a, b in zip(red.buckets, red.buckets[1:]):
+        assert a.hi <= b.lo
