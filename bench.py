@@ -83,6 +83,33 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
                      "glowtts_coupling_fwd", "glowtts_coupling_bwd")
 
 
+_T0 = time.perf_counter()
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() reports
+    the whole host, which over-subscribes the oracle's thread pool on a shared GPU box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    """Progress line on stderr (the JSON line on stdout stays alone)."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +141,7 @@ def main():
             if hasattr(f, "end"):
                 f.end.weight.normal_(0, 0.01)
     model.train()
+    log(f"model built: {sum(p.numel() for p in model.parameters())} parameters")
 
     gen = torch.Generator().manual_seed(cfg.seed + rank)
     x = torch.randint(1, 148, (B, T_text), generator=gen).to(dev)
@@ -128,12 +156,16 @@ def main():
             f.set_ddi(True)
     with torch.no_grad():
         model(x, x_lengths, y, y_lengths)
+    torch.cuda.synchronize()
+    log("data-dependent init forward done")
     reducer = parallel.FlowBlockReducer(model, opt) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         train_batch(model, opt, batch, cfg.grad_clip, reducer)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done")
 
     def fence():
         torch.cuda.synchronize()
@@ -153,6 +185,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     loss_val = float(loss)
+    log(f"timed region: {args.steps} steps in {dt:.3f} s, loss {loss_val:.4f}")
     frames = world * B * T_mel * args.steps
     ms_per_step = 1e3 * dt / args.steps
 
@@ -177,6 +210,7 @@ def main():
         for _ in range(n_inst):
             train_batch(model, opt, batch, cfg.grad_clip, None)
         times = _hip.disable_timing()
+        log("instrumented pass done")
         table = {}
         for name, ms in times.items():
             if name not in alg:
@@ -204,13 +238,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import glow_oracle as O
 
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         torch.set_num_threads(cores)
         hp = O.HParams(n_vocab=148, n_blocks_dec=args.blocks)
         sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict(hp, seed=cfg.seed).items()}
         oopt = O.AdamNoam(sd, dim_model=hp.hidden_channels)
         cb = (x.cpu(), x_lengths.cpu(), y.cpu(), y_lengths.cpu(), None)
+        log(f"cpu baseline: oracle on {cores} threads")
         O.train_step(sd, hp, oopt, cb, cfg.grad_clip)                    # warm-up (thread pools, allocator)
+        log("cpu baseline warm-up step done")
         t0 = time.perf_counter()
         for _ in range(args.cpu_steps):
             O.train_step(sd, hp, oopt, cb, cfg.grad_clip)

@@ -373,13 +373,13 @@ def test_e2e_generate_golden(G, tag):
 
 
 # =============================================================================================== HIP vs oracle, mid size
-def _oracle_pair(G, hp, seed=11):
+def _oracle_pair(G, hp, seed=11, end_std=0.05):
     from oracle import glow_oracle as O
 
     sd = O.init_state_dict(hp, seed=seed)
     for k in list(sd):
         if k.endswith(".end.weight"):
-            sd[k] = 0.05 * torch.randn_like(sd[k])
+            sd[k] = end_std * torch.randn_like(sd[k])
     m = G.models.FlowGenerator(
         n_vocab=hp.n_vocab, hidden_channels=hp.hidden_channels, filter_channels=hp.filter_channels,
         filter_channels_dp=hp.filter_channels_dp, out_channels=hp.out_channels, kernel_size=hp.kernel_size,
@@ -454,16 +454,29 @@ def test_full_step_vs_oracle_small_config(G):
     oloss, frames = O.train_step(sdo, hp, oopt, (x, xl, y, yl, spk), 5.0)
     assert frames == int(yl.sum())
     assert abs(float(loss) - oloss) <= 1e-3 * abs(oloss), (float(loss), oloss)
-    now = model.state_dict()
-    # after one Adam step every parameter moved by ~lr; compare the UPDATE, not just the value
-    worst = 0.0
+    # gradients (already clamped in place on both sides) agree tensor by tensor
+    named = dict(model.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in sdo.values() if v.grad is not None)
     for k, v in sdo.items():
-        upd_o = v.detach() - sd[k]
-        upd_h = now[k].cpu() - sd[k]
-        if upd_o.abs().max() == 0:
+        if v.grad is None:
             continue
-        worst = max(worst, float((upd_h - upd_o).abs().max() / upd_o.abs().max()))
-    assert worst < 2e-2, worst     # sign-like Adam update amplifies tiny gradient differences near zero gradients
+        # per-tensor relative check with a floor at 1e-5 of the largest gradient in the model: some gradients are
+        # mathematically zero (e.g. the key-projection bias: softmax is invariant to it) and hold only rounding noise
+        assert_close(named[k].grad, v.grad, what="grad " + k, rtol=0,
+                     atol=5e-3 * float(v.grad.abs().max()) + 1e-5 * gmax)
+    # the first Adam update is lr * g / (|g| + eps): sign-like, so it is only comparable where the gradient is
+    # well above rounding noise; there the two updates must agree (the arithmetic itself is pinned bit-tight by
+    # test_e2e_train_golden, which replays the reference's own three updates)
+    now = model.state_dict()
+    lr0 = O.noam_lr(1, 64, 4000)
+    for k, v in sdo.items():
+        if v.grad is None:
+            continue
+        g = v.grad
+        big = g.abs() > 1e-3 * g.abs().max().clamp_min(1e-30)
+        upd_o = (v.detach() - sd[k])[big]
+        upd_h = (now[k].cpu() - sd[k])[big]
+        assert float((upd_h - upd_o).abs().max()) <= 0.05 * lr0, k
 
 
 # =============================================================================================== full-size properties
@@ -472,7 +485,7 @@ def test_full_size_decoder_roundtrip_and_mas_properties(G):
     from oracle import glow_oracle as O
 
     hp = O.HParams()
-    sd, model = _oracle_pair(G, hp, seed=2)
+    sd, model = _oracle_pair(G, hp, seed=2, end_std=0.005)      # well-conditioned couplings: |logs| stays O(0.1)
     torch.manual_seed(4)
     b, t = 32, 800
     y = torch.randn(b, 80, t, device="cuda")
