@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float *__restrict__
     ds.store(da + oa + (long)H * T);
 }
 
+// gate backward from the SAVED tanh / sigmoid values (the fused conv+gate forward stores them): da = d(pre-activation),
+// including the dropout keep-mask / scale of the forward when one was applied (layers.py:147).
+template <int V>
+__global__ __launch_bounds__(256) void gate_bwd_ts_kernel(const float *__restrict__ ts, const float *__restrict__ dacts,
+                                                          const unsigned char *__restrict__ drop, float drop_scale,
+                                                          float *__restrict__ da, int B, int H, int T) {
+    const int TV = T / V;
+    const long n = (long)B * H * TV;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int tv = (int)(i % TV);
+    const long row = i / TV;
+    const int c = (int)(row % H);
+    const int b = (int)(row / H);
+    const long ot = ((long)b * 2 * H + c) * T + (long)tv * V;
+    const long os = ot + (long)H * T;
+    Vec<V> th = Vec<V>::load(ts + ot);
+    Vec<V> sg = Vec<V>::load(ts + os);
+    Vec<V> go = Vec<V>::load(dacts + row * T + (long)tv * V);
+    Vec<V> dt, ds;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        dt[j] = go[j] * sg[j] * (1.0f - th[j] * th[j]);
+        ds[j] = go[j] * th[j] * sg[j] * (1.0f - sg[j]);
+        if (drop) {
+            dt[j] = drop[ot + j] ? dt[j] * drop_scale : 0.f;
+            ds[j] = drop[os + j] ? ds[j] * drop_scale : 0.f;
+        }
+    }
+    dt.store(da + ot);
+    ds.store(da + os);
+}
+
 template <int V, bool LAST>
 __global__ __launch_bounds__(256) void res_skip_fwd_kernel(const float *__restrict__ x, const float *__restrict__ rs,
                                                            const float *__restrict__ mask, const float *__restrict__ skip_in,
@@ -152,6 +185,18 @@ extern "C" int glowtts_gate_bwd(const float *a, const float *g, const float *dac
     if (v4) hipLaunchKernelGGL((gate_bwd_kernel<4>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, g, dacts, da, B, H, T);
     else    hipLaunchKernelGGL((gate_bwd_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, g, dacts, da, B, H, T);
     GLOWTTS_LAUNCH_CHECK("glowtts_gate_bwd");
+}
+
+extern "C" int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale,
+                                   float *da, int B, int H, int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(ts && dacts && da, "glowtts_gate_bwd_ts: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0, "glowtts_gate_bwd_ts: bad shape");
+    if ((long)B * H * T == 0) return 0;
+    const bool v4 = can_vec4(T, {ts, dacts, da});
+    const long n = (long)B * H * (v4 ? T / 4 : T);
+    if (v4) hipLaunchKernelGGL((gate_bwd_ts_kernel<4>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ts, dacts, drop, drop_scale, da, B, H, T);
+    else    hipLaunchKernelGGL((gate_bwd_ts_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ts, dacts, drop, drop_scale, da, B, H, T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_gate_bwd_ts");
 }
 
 extern "C" int glowtts_res_skip_fwd(const float *x, const float *rs, const float *mask, const float *skip_in,

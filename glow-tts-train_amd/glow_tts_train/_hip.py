@@ -38,6 +38,14 @@ _SIGNATURES = {
     "glowtts_gate_bwd": [_P, _P, _P, _P, _I, _I, _I],
     "glowtts_res_skip_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_res_skip_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_conv_fwd": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_conv_gate_fwd": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I],
+    "glowtts_conv_res_skip_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_conv_wrw": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
+    "glowtts_gate_bwd_ts": [_P, _P, _P, _F, _P, _I, _I, _I],
     "glowtts_squeeze": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_unsqueeze": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_mle_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import ops
+from . import convops, ops
 from .layers import WN, LayerNorm
 
 
@@ -66,9 +66,11 @@ class CouplingBlock(nn.Module):
         if x_mask is None:
             x_mask = torch.ones(x.size(0), 1, x.size(2), device=x.device, dtype=x.dtype)
         m2 = ops.mask2d(x_mask)
-        h = self.start(x[:, : self.in_channels // 2]) * x_mask
+        sv, sg, sb = WN._conv_params(self.start)
+        # the 1x1 convs consume the channel slice in place (batch stride C*T) and fold bias and mask into the epilogue
+        h = convops.Conv1dFn.apply(x[:, : self.in_channels // 2], sv, sg, sb, m2, True, 1)
         h = self.wn(h, x_mask, g, m2=m2)
-        out = self.end(h)
+        out = convops.Conv1dFn.apply(h, self.end.weight, None, self.end.bias, m2, False, 1)
         if reverse:
             return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
         return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale)

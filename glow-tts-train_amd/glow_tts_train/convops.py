@@ -1,0 +1,249 @@
+"""Autograd operators over the fp32-MFMA convolution kernels (csrc/convgemm.hip): a weight-normed 1-D convolution and
+the whole WaveNet-style WN stack with a hand-composed backward.
+
+The reference leaves these contractions to cuDNN/MIOpen through `F.conv1d` and autograd (layers.py:138-162,
+attentions.py:124-126).  Here every contraction is one launch of the implicit-GEMM kernel family with bias / mask /
+gate / residual-skip fused into the epilogue; parameter gradients are accumulated straight into `param.grad` when it
+already exists (the flat-buffer optimizer keeps it allocated), which removes one `add` launch per parameter per step.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._hip import call, f32, ptr
+
+# parameters whose .grad was written directly by a backward (no AccumulateGrad node runs for them); a data-parallel
+# reducer subscribes here to learn that a gradient is complete (parallel.FlowBlockReducer)
+_grad_ready_listeners: List = []
+
+
+def add_grad_ready_listener(fn) -> None:
+    _grad_ready_listeners.append(fn)
+
+
+def remove_grad_ready_listener(fn) -> None:
+    if fn in _grad_ready_listeners:
+        _grad_ready_listeners.remove(fn)
+
+
+def _notify(params) -> None:
+    for fn in _grad_ready_listeners:
+        for p in params:
+            fn(p)
+
+
+def _rows_ok(x: torch.Tensor) -> bool:
+    """(B, C, T) tensor whose rows are dense and T-contiguous inside each utterance (a channel slice qualifies)."""
+    return x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2]
+
+
+def _dense(x: torch.Tensor) -> torch.Tensor:
+    return x if _rows_ok(x) else x.contiguous()
+
+
+def pack_weight(v: torch.Tensor, g: Optional[torch.Tensor], want_bwd: bool = True):
+    """weight (Cout, Cin, taps) [+ weight-norm gain (Cout,1,1)] -> packed forward / backward-data layouts, 1/||v||."""
+    v = f32(v.detach().contiguous())
+    cout, cin, taps = v.shape
+    dev = v.device
+    wp_f = torch.empty(taps, cin, cout, device=dev, dtype=torch.float32)
+    wp_b = torch.empty(taps, cout, cin, device=dev, dtype=torch.float32) if want_bwd else None
+    inv = torch.empty(cout, device=dev, dtype=torch.float32) if g is not None else None
+    gg = None if g is None else f32(g.detach().reshape(-1).contiguous())
+    call("glowtts_pack_weight", ptr(v), ptr(gg), ptr(wp_f), ptr(wp_b), ptr(inv), cout, cin, taps)
+    return wp_f, wp_b, inv
+
+
+def conv_fwd(x, wp, bias, m2, y, cin, cout, taps, dil, pad, mask_in=False, mask_out=False, addend=None, mask_add=False):
+    B, _, T = x.shape
+    call("glowtts_conv_fwd", ptr_rows(x), x.stride(0), ptr(wp), ptr(bias), ptr(m2),
+         None if addend is None else ptr_rows(addend), 0 if addend is None else addend.stride(0),
+         ptr(y), y.stride(0), B, cin, cout, T, taps, dil, pad, int(mask_in), int(mask_out), int(mask_add))
+    return y
+
+
+def ptr_rows(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("glow_tts_train (MI355X build): operator received a CPU tensor")
+    if not _rows_ok(t):
+        raise RuntimeError("glow_tts_train: tensor rows are not dense")
+    return t.data_ptr()
+
+
+class _GradSink:
+    """Where a parameter gradient goes: in place into param.grad (no autograd add) or into a fresh zero tensor."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.direct = all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32)
+                          for p in self.params)
+        self.bufs = [None if p is None else (p.grad if self.direct else torch.zeros_like(p)) for p in self.params]
+
+    def buf(self, i):
+        return self.bufs[i]
+
+    def results(self):
+        if self.direct:
+            _notify([p for p in self.params if p is not None])
+            return [None] * len(self.params)
+        return self.bufs
+
+
+def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad):
+    """dW (through the weight norm) and dbias of y = conv(x): one wrw launch, one unpack launch, one row-sum launch."""
+    B, cin, T = x.shape
+    cout = d.shape[1]
+    dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
+    call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(dwp), B, cin, cout, T,
+         taps, dil, pad)
+    gg = None if g is None else g.detach().reshape(-1).contiguous()
+    call("glowtts_unpack_weight_grad", ptr(dwp), ptr(v.detach().contiguous()), ptr(gg), ptr(inv), ptr(dv_buf),
+         None if dg_buf is None else ptr(dg_buf), cout, cin, taps)
+    if db_buf is not None:
+        call("glowtts_rowsum", ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(db_buf), B, cout, T)
+
+
+class Conv1dFn(Function):
+    """y = conv1d(x; weight_norm(v, g) or v, bias, dilation, 'same' padding) [* mask] on the MFMA kernels."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, m2, mask_out, dil):
+        x = _dense(f32(x))
+        B, cin, T = x.shape
+        cout, _, taps = v.shape
+        pad = (taps * dil - dil) // 2
+        wp_f, wp_b, inv = pack_weight(v, g)
+        y = torch.empty(B, cout, T, device=x.device, dtype=torch.float32)
+        b1 = None if bias is None else f32(bias.detach().contiguous())
+        conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_out=bool(mask_out))
+        ctx.save_for_backward(x, wp_b, inv, m2 if mask_out else None)
+        ctx.params = (v, g, bias)
+        ctx.cfg = (taps, dil, pad, bool(mask_out))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, wp_b, inv, m2 = ctx.saved_tensors
+        v, g, bias = ctx.params
+        taps, dil, pad, mask_out = ctx.cfg
+        dy = _dense(dy)
+        B, cin, T = x.shape
+        cout = dy.shape[1]
+        sink = _GradSink([v, g, bias])
+        _weight_grads(x, dy, m2, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2), taps, dil, pad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
+            conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out)
+        dv, dg, db = sink.results()
+        return dx, dv, dg, db, None, None, None
+
+
+class WNFn(Function):
+    """The whole WN stack (reference layers.py:138-162) as one autograd node.
+
+    forward, per layer i:  acts, ts = conv_gate(x_i)                 [k-tap dilated conv + bias + dropout + cond + gate]
+                           x_{i+1}, skip = conv_res_skip(acts, x_i)  [1x1 conv + bias + residual*mask + skip accumulate]
+    backward, per layer (reverse): d_rs = [dx_{i+1} mask ; dskip] -> weight grads (wrw) -> d_acts = W_rs^T d_rs
+                           -> gate backward from the saved tanh/sigmoid -> weight grads -> dx_i = d_rs[:H] + W_in^T (*) d_xin
+    Saved per layer: x_i (H), acts (H), ts (2H) [+ dropout bytes].
+    """
+
+    @staticmethod
+    def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, *params):
+        # params: per layer (in_v, in_g, in_b, rs_v, rs_g, rs_b)
+        x = f32(x.contiguous())
+        B, H, T = x.shape
+        dev = x.device
+        saved, packs, drops = [], [], []
+        skip = None
+        cur = x
+        for i in range(n_layers):
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
+            taps = in_v.shape[2]
+            dil = dil_rate ** i
+            pad = (taps * dil - dil) // 2
+            wf_in, wb_in, inv_in = pack_weight(in_v, in_g)
+            wf_rs, wb_rs, inv_rs = pack_weight(rs_v, rs_g)
+            drop = None
+            if p_drop > 0.0:
+                drop = (torch.rand(B, 2 * H, T, device=dev) >= p_drop).to(torch.uint8)
+            acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            ts = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
+            c_i = None if cond is None else f32(cond[:, 2 * H * i: 2 * H * (i + 1)].reshape(B, 2 * H).contiguous())
+            call("glowtts_conv_gate_fwd", ptr(cur), ptr(wf_in), ptr(f32(in_b.detach().contiguous())), ptr(c_i), ptr(drop),
+                 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, ptr(acts), ptr(ts), B, H, T, taps, dil, pad)
+            last = i == n_layers - 1
+            skip_out = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            nxt = None if last else torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(f32(rs_b.detach().contiguous())), ptr(m2),
+                 None if last else ptr(cur), ptr(skip), None if last else ptr(nxt), ptr(skip_out), B, H, T, int(last))
+            saved += [cur, acts, ts]
+            packs += [wb_in, inv_in, wb_rs, inv_rs]
+            drops.append(drop)
+            skip = skip_out
+            if not last:
+                cur = nxt
+        ctx.save_for_backward(m2, *saved, *packs, *[d for d in drops if d is not None])
+        ctx.params = params
+        ctx.cfg = (n_layers, dil_rate, float(p_drop), cond is not None, B, H, T)
+        return skip
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        n_layers, dil_rate, p_drop, has_cond, B, H, T = ctx.cfg
+        sv = ctx.saved_tensors
+        m2 = sv[0]
+        saved = sv[1: 1 + 3 * n_layers]
+        packs = sv[1 + 3 * n_layers: 1 + 7 * n_layers]
+        drops = list(sv[1 + 7 * n_layers:]) if p_drop > 0 else [None] * n_layers
+        params = ctx.params
+        dev = dout.device
+        sink = _GradSink(params)
+        dskip = dout.contiguous()
+        dx_next = None
+        dconds = [None] * n_layers
+        scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        for i in reversed(range(n_layers)):
+            in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
+            x_i, acts, ts = saved[3 * i: 3 * i + 3]
+            wb_in, inv_in, wb_rs, inv_rs = packs[4 * i: 4 * i + 4]
+            taps = in_v.shape[2]
+            dil = dil_rate ** i
+            pad = (taps * dil - dil) // 2
+            last = i == n_layers - 1
+            m_rs = H if last else 2 * H
+            d_rs = torch.empty(B, m_rs, T, device=dev, dtype=torch.float32)
+            call("glowtts_res_skip_bwd", None if last else ptr(dx_next), ptr(dskip), ptr(m2), None, ptr(d_rs), B, H, T, int(last))
+            if last:
+                dskip = d_rs                          # d(skip_in) of the last layer carries the folded mask
+            _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3), sink.buf(6 * i + 4),
+                          sink.buf(6 * i + 5), 1, 1, 0)
+            d_acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            conv_fwd(d_rs, wb_rs, None, None, d_acts, m_rs, H, 1, 1, 0)
+            d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
+            call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), ptr(drops[i]), scale, ptr(d_xin), B, H, T)
+            if has_cond:
+                if drops[i] is None:
+                    dconds[i] = d_xin.sum(-1)
+                else:  # conditioning is added after the dropout: its gradient is the un-dropped pre-activation gradient
+                    tmp = torch.empty_like(d_xin)
+                    call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), None, 1.0, ptr(tmp), B, H, T)
+                    dconds[i] = tmp.sum(-1)
+            _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i), sink.buf(6 * i + 1),
+                          sink.buf(6 * i + 2), taps, dil, pad)
+            dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
+            conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
+                     addend=None if last else d_rs[:, :H])
+            dx_next = dx
+        dcond = None
+        if has_cond:
+            dcond = torch.cat(dconds, 1).unsqueeze(-1)
+        return (dx_next, None, dcond, None, None, None, *sink.results())

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import ops
+from . import convops, ops
 
 
 def _ones_mask(x: torch.Tensor) -> torch.Tensor:
@@ -90,26 +90,26 @@ class WN(nn.Module):
             out_ch = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
             self.res_skip_layers.append(wn(nn.Conv1d(hidden_channels, out_ch, 1), name="weight"))
 
+    @staticmethod
+    def _conv_params(conv):
+        """(v, g, bias) of a conv with or without weight norm (store_inverse() strips it, reference layers.py:164-170)."""
+        if hasattr(conv, "weight_v"):
+            return conv.weight_v, conv.weight_g, conv.bias
+        return conv.weight, None, conv.bias
+
     def forward(self, x, x_mask=None, g=None, **kwargs):
-        H = self.hidden_channels
         if x_mask is None:
             x_mask = _ones_mask(x)
         m2 = kwargs.get("m2")
         if m2 is None:
             m2 = ops.mask2d(x_mask)
-        cond = self.cond_layer(g) if g is not None else None          # (B, 2H*n_layers, 1)
-        skip = None
-        last = self.n_layers - 1
-        for i in range(self.n_layers):
-            x_in = self.drop(self.in_layers[i](x))
-            g_l = None if cond is None else cond[:, 2 * H * i: 2 * H * (i + 1), :]
-            acts = ops.GateFn.apply(x_in, g_l)
-            rs = self.res_skip_layers[i](acts)
-            if i < last:
-                x, skip = ops.ResSkipFn.apply(x, rs, m2, skip, False)
-            else:
-                skip = ops.ResSkipFn.apply(None, rs, m2, skip, True)
-        return skip
+        cond = self.cond_layer(g) if g is not None else None          # (B, 2H*n_layers, 1): tiny, left to torch
+        flat = []
+        for in_layer, rs_layer in zip(self.in_layers, self.res_skip_layers):
+            flat.extend(self._conv_params(in_layer))
+            flat.extend(self._conv_params(rs_layer))
+        p_drop = float(self.p_dropout) if self.training else 0.0
+        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, *flat)
 
     def remove_weight_norm(self):
         if self.gin_channels != 0:

@@ -25,6 +25,8 @@ import typing
 import torch
 import torch.distributed as dist
 
+from . import convops
+
 _FLOW_RE = re.compile(r"^(?:module\.)?decoder\.flows\.(\d+)\.")
 
 
@@ -88,6 +90,8 @@ class FlowBlockReducer:
             for _, p in named:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            # gradients the conv operators write straight into .grad never pass an AccumulateGrad node
+            convops.add_grad_ready_listener(self._on_grad)
 
     # -- collectives ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -107,6 +111,8 @@ class FlowBlockReducer:
         self._launched[i] = True
 
     def _on_grad(self, p: torch.Tensor):
+        if id(p) not in self._bucket_of:
+            return
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
         if self._pending[i] == 0 and not self._launched[i]:
@@ -129,3 +135,4 @@ class FlowBlockReducer:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        convops.remove_grad_ready_listener(self._on_grad)

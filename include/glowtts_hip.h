@@ -110,6 +110,44 @@ int glowtts_res_skip_fwd(const float *x, const float *rs, const float *mask, con
 int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *mask, float *dx, float *drs, int B,
                          int H, int T, int last, glowtts_stream_t stream);
 
+/* ---- fp32-MFMA implicit-GEMM 1-D convolutions (csrc/convgemm.hip) --------------------------------------------
+ * replace F.conv1d / conv-transpose / weight-gradient calls of WN and the coupling 1x1 convs (layers.py:146,156;
+ * attentions.py:124-126) — MIOpen / rocBLAS through PyTorch in the reference.  All tensors (B, C, T), T contiguous;
+ * `*_bs` = batch stride in elements (lets a channel slice such as x[:, :C/2] be consumed in place).
+ * Packed weights: wp_f[tap][Cin][Cout] (forward) and wp_b[taps-1-tap][Cout][Cin] (backward-data), produced by
+ * glowtts_pack_weight, which also applies torch's weight_norm (w = g v / ||v||, dim 0) when g != NULL.
+ *
+ * conv_fwd      : y[b,m,t] = sum_tap sum_k wp[tap][k][m] * (x[b,k,t + tap*dil - pad] * (mask_in ? mask : 1)) + bias[m]
+ *                 then (* mask if mask_out) ; if addend != NULL: y += addend (* mask if mask_add)
+ *                 (backward-data = the same call with wp_b, Cin/M swapped, pad' = (taps-1)*dil - pad)
+ * conv_gate_fwd : WN in-layer + gate: pre = conv(x) + bias, dropout keep-mask bytes `drop` (scale 1/(1-p)) applied to
+ *                 pre, + cond[b, :] ; acts = tanh(pre[:H]) * sigmoid(pre[H:]) ; ts (B,2H,T) = the tanh / sigmoid values
+ * conv_res_skip_fwd : WN res/skip 1x1 + update: rs = W acts + b ; x_out = (x_in + rs[:H]) * mask ; skip_out = skip_in + rs[H:]
+ *                 last = 1: W is (H x H), skip_out = (skip_in + rs) * mask   (folds layers.py:162)
+ * conv_wrw      : dwp[tap][k][m] += sum_{b,t} x[b,k,t + tap*dil - pad] * d[b,m,t] (* mask[b,t] if mask)   (accumulated)
+ * unpack_weight_grad : packed gradient -> dv (+= , weight layout [Cout][Cin][taps]) and dg (+=) through the weight norm
+ * rowsum        : out[m] += sum_{b,t} d[b,m,t] (* mask)                                  (bias gradients, accumulated)
+ * gate_bwd_ts   : da (B,2H,T) from dacts (B,H,T) and the saved ts; the forward's dropout mask is re-applied */
+int glowtts_conv_fwd(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
+                     const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T, int taps,
+                     int dil, int pad, int mask_in, int mask_out, int mask_add, glowtts_stream_t stream);
+int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, const float *cond,
+                          const unsigned char *drop, float drop_scale, float *acts, float *ts, int B, int H, int T,
+                          int taps, int dil, int pad, glowtts_stream_t stream);
+int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
+                              const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B, int H, int T,
+                              int last, glowtts_stream_t stream);
+int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp, int B, int Cin,
+                     int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
+int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
+                        int taps, glowtts_stream_t stream);
+int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g, const float *inv_norm, float *dv,
+                               float *dg, int Cout, int Cin, int taps, glowtts_stream_t stream);
+int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,
+                   glowtts_stream_t stream);
+int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale, float *da,
+                        int B, int H, int T, glowtts_stream_t stream);
+
 /* ---- squeeze / unsqueeze (utils.py:135-160) -----------------------------------------------------------------
  * squeeze  : x (B,C,T) -> xs (B, n*C, T/n): xs[b, s*C+c, t'] = x[b,c,n*t'+s] * mask[b, n*t'+n-1] ; ms[b,t'] = mask[b, n*t'+n-1]
  * unsqueeze: xs (B, n*C, T') -> x (B,C,n*T'): x[b,c,n*t'+s] = xs[b,s*C+c,t'] * ms[b,t'] ; mask_out[b,n*t'+s] = ms[b,t']

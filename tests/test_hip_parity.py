@@ -507,3 +507,105 @@ def test_full_size_decoder_roundtrip_and_mas_properties(G):
     assert ((d == 0) | (d == 1)).all() and (idx[:, 0] == 0).all() and (idx[:, -1] == 159).all()
     # idempotence: the path of a lattice that rewards exactly that path is the same path
     assert (G.ops.mas_path(p * 10.0, tx, ty) == p).all()
+
+
+# =============================================================================================== MFMA conv kernels
+@pytest.mark.parametrize("b,cin,cout,t,k,dil,mask_out,slice_in", [
+    (3, 80, 192, 50, 1, 1, True, True),       # coupling start conv: channel slice consumed in place, masked output
+    (2, 192, 384, 400, 5, 1, False, False),   # WN in-layer shape, 80-frame tiles
+    (2, 192, 160, 77, 1, 1, False, False),    # end conv, ragged T (64-frame tiles, partial rows)
+    (2, 24, 36, 130, 3, 2, True, False),      # dilation 2, small odd channel counts
+    (1, 5, 4, 16, 5, 3, False, False),        # halo wider than the tile interior
+    (4, 192, 192, 160, 3, 1, False, False),
+])
+def test_conv1d_fn_vs_torch(G, b, cin, cout, t, k, dil, mask_out, slice_in):
+    from glow_tts_train import convops
+
+    torch.manual_seed(b * 100 + cin)
+    full = torch.randn(b, cin * (2 if slice_in else 1), t)
+    v = torch.randn(cout, cin, k) * (cin * k) ** -0.5
+    g = torch.rand(cout, 1, 1) + 0.5
+    bias = torch.randn(cout) * 0.1
+    lengths = torch.linspace(t, max(1, t // 2), b).long()
+    mask = (torch.arange(t)[None, :] < lengths[:, None]).float()
+    r = torch.randn(b, cout, t)
+
+    def ref(use_g):
+        xf = full.clone().requires_grad_(True)
+        vv, gg, bb = v.clone().requires_grad_(True), g.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        w = vv * (gg / vv.flatten(1).norm(dim=1).view(-1, 1, 1)) if use_g else vv
+        y = torch.nn.functional.conv1d(xf[:, :cin], w, bb, dilation=dil, padding=(k * dil - dil) // 2)
+        if mask_out:
+            y = y * mask.unsqueeze(1)
+        (y * r).sum().backward()
+        return y, xf.grad, vv.grad, gg.grad if use_g else None, bb.grad
+
+    for use_g in (True, False):
+        y0, dx0, dv0, dg0, db0 = ref(use_g)
+        xf = full.cuda().requires_grad_(True)
+        vv, bb = v.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
+        gg = g.cuda().requires_grad_(True) if use_g else None
+        y = convops.Conv1dFn.apply(xf[:, :cin], vv, gg, bb, mask.cuda(), mask_out, dil)
+        (y * r.cuda()).sum().backward()
+        assert_close(y, y0, what="y", rtol=1e-4, atol=1e-4)
+        assert_close(xf.grad, dx0, what="dx", rtol=1e-4, atol=1e-4)
+        assert_close(vv.grad, dv0, what="dv", rtol=2e-4, atol=2e-4)
+        assert_close(bb.grad, db0, what="db", rtol=2e-4, atol=2e-4)
+        if use_g:
+            assert_close(gg.grad, dg0, what="dg", rtol=2e-4, atol=2e-4)
+
+
+def test_conv_grads_accumulate_in_place_when_grad_exists(G):
+    """With .grad pre-allocated (flat-buffer optimizer) the operators add into it and hand autograd None."""
+    from glow_tts_train import convops
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 40, device="cuda")
+    v = torch.randn(12, 8, 3, device="cuda", requires_grad=True)
+    bias = torch.zeros(12, device="cuda", requires_grad=True)
+    m = torch.ones(2, 40, device="cuda")
+    convops.Conv1dFn.apply(x, v, None, bias, m, False, 1).sum().backward()
+    gv, gb = v.grad.clone(), bias.grad.clone()
+    before = v.grad.data_ptr()
+    convops.Conv1dFn.apply(x, v, None, bias, m, False, 1).sum().backward()       # second backward: in place, 2x
+    assert v.grad.data_ptr() == before
+    assert_close(v.grad, 2 * gv, rtol=1e-5, atol=1e-5)
+    assert_close(bias.grad, 2 * gb, rtol=1e-5, atol=1e-5)
+
+
+def test_wn_dropout_path_matches_manual_mask(G):
+    """Training-mode dropout inside WN (layers.py:147): reproduce the keep-masks from the seed and check fwd + bwd."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(3)
+    H, L, b, t, p = 16, 3, 2, 48, 0.3
+    wn = G.layers.WN(16, H, 5, 1, L, gin_channels=0, p_dropout=p).cuda().train()
+    x = torch.randn(b, H, t, device="cuda", requires_grad=True)
+    mask = torch.ones(b, 1, t, device="cuda")
+    mask[1, :, 30:] = 0
+    r = torch.randn(b, H, t, device="cuda")
+    torch.manual_seed(99)
+    out = wn(x, mask)
+    (out * r).sum().backward()
+    # manual: same RNG stream, same order
+    torch.manual_seed(99)
+    keeps = [(torch.rand(b, 2 * H, t, device="cuda") >= p).float() for _ in range(L)]
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in wn.state_dict().items()}
+    xo = x.detach().cpu().clone().requires_grad_(True)
+    cur, skip = xo, 0
+    for i in range(L):
+        pre = O.conv1d(sd, f"in_layers.{i}", cur) * keeps[i].cpu() / (1 - p)
+        acts = O.gate(pre, torch.zeros_like(pre), H)
+        rs = O.conv1d(sd, f"res_skip_layers.{i}", acts)
+        if i < L - 1:
+            cur = (cur + rs[:, :H]) * mask.cpu()
+            skip = skip + rs[:, H:]
+        else:
+            skip = skip + rs
+    want = skip * mask.cpu()
+    (want * r.cpu()).sum().backward()
+    assert_close(out, want, what="out", rtol=1e-4, atol=1e-4)
+    assert_close(x.grad, xo.grad, what="dx", rtol=2e-4, atol=2e-4)
+    named = dict(wn.named_parameters())
+    for k, vref in sd.items():
+        assert_close(named[k].grad, vref.grad, what="grad " + k, rtol=5e-4, atol=5e-4)
