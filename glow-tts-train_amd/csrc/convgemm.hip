@@ -47,8 +47,79 @@ struct ConvGemmParams {
     int xp_pitch;            // LDS pitch of the activation slab (floats)
     int mask_out;            // PLAIN: multiply the result by mask
     int mask_add;            // ADD: multiply the addend by mask
+    int vec_epilogue;        // pipelined kernel: 16-byte epilogue through LDS (all epilogue tensors 16-byte aligned)
     float drop_scale;        // 1 / (1 - p)
 };
+
+// ---- shared epilogue: lane holds rows lk*4 + reg, column lrow of every 16x16 accumulator tile -------------------
+template <int RTW, int NCT, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&acc)[RTW][NCT], int b, int t0, int tile_m,
+                                              int wave, int lane) {
+    constexpr int WGR = 64 * RTW;
+    const int lrow = lane & 15, lk = lane >> 4;
+    auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
+    const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    if (EPI == EPI_GATE) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int t = t0 + c * 16 + lrow;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ch = tile_m * 64 + wave * 16 + lk * 4 + reg;       // channel in [0, H)
+                if (ch < p.H && t < p.T) {
+                    float vt = acc[0][c][reg], vs = acc[RTW - 1][c][reg];
+                    if (p.bias) { vt += p.bias[ch]; vs += p.bias[p.H + ch]; }
+                    const long ot = ((long)b * 2 * p.H + ch) * p.T + t;
+                    const long os = ot + (long)p.H * p.T;
+                    if (p.drop) {   // dropout on the pre-activation (layers.py:147), keep-mask generated by the host RNG
+                        vt = p.drop[ot] ? vt * p.drop_scale : 0.f;
+                        vs = p.drop[os] ? vs * p.drop_scale : 0.f;
+                    }
+                    if (p.cond) { vt += p.cond[(long)b * 2 * p.H + ch]; vs += p.cond[(long)b * 2 * p.H + p.H + ch]; }
+                    const float th = tanhf(vt), sg = sigmoidf_(vs);
+                    p.y0[((long)b * p.H + ch) * p.T + t] = th * sg;
+                    if (p.y1) { p.y1[ot] = th; p.y1[os] = sg; }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int t = t0 + c * 16 + lrow;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = tile_m * WGR + ltile(r) * 16 + lk * 4 + reg;
+                if (row >= p.M || t >= p.T) continue;
+                float v = acc[r][c][reg];
+                if (p.bias) v += p.bias[row];
+                const float m = mk ? mk[t] : 1.f;
+                if (EPI == EPI_PLAIN) {
+                    if (p.mask_out) v *= m;
+                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v;
+                } else if (EPI == EPI_ADD) {
+                    const float add = p.r0[(long)b * p.r_bs + (long)row * p.T + t];
+                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v + (p.mask_add ? add * m : add);
+                } else if (EPI == EPI_RESSKIP) {
+                    // rows [0,H): residual -> next layer input ; rows [H,2H): skip accumulation  (layers.py:157-159)
+                    if (row < p.H) {
+                        const long o = ((long)b * p.H + row) * p.T + t;
+                        p.y0[o] = (p.r0[o] + v) * m;
+                    } else {
+                        const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
+                        p.y1[o] = (p.r1 ? p.r1[o] : 0.f) + v;
+                    }
+                } else if (EPI == EPI_RESSKIP_LAST) {
+                    // last layer: all H rows go to the skip sum, and WN's final `output * x_mask` is folded in (:161-162)
+                    const long o = ((long)b * p.H + row) * p.T + t;
+                    p.y1[o] = ((p.r1 ? p.r1[o] : 0.f) + v) * m;
+                }
+            }
+        }
+    }
+}
 
 template <int RTW, int NCT, int EPI>
 __global__ __launch_bounds__(256) void convgemm_kernel(ConvGemmParams p) {
@@ -146,67 +217,239 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvGemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds rows lk*4 + reg, column lrow of every 16x16 tile ----------------------------------------
+    conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
+}
+
+// ---- vectorised epilogue for the pipelined kernel: accumulator tiles -> LDS [row][frame] -> every lane handles 4
+// consecutive frames of one row with 16-byte global loads / stores (the direct epilogue writes 64-byte row segments).
+// Needs T % 4 == 0 (a float4 is then entirely inside or outside the utterance).
+template <int RTW, int NCT, int EPI>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4 (&acc)[RTW][NCT], float *Ls, int b, int t0,
+                                                  int tile_m, int wave, int lane) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT, LP = NT + 4, Q = NT / 4;
+    const int lrow = lane & 15, lk = lane >> 4;
+    auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
+#pragma unroll
+    for (int r = 0; r < RTW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Ls[(ltile(r) * 16 + lk * 4 + reg) * LP + c * 16 + lrow] = acc[r][c][reg];
+    __syncthreads();
+    const int tid = threadIdx.x;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    auto ld4 = [](const float *q) { return *reinterpret_cast<const float4 *>(q); };
+    auto st4 = [](float *q, float4 v) { *reinterpret_cast<float4 *>(q) = v; };
     if (EPI == EPI_GATE) {
+        for (int idx = tid; idx < 64 * Q; idx += 256) {
+            const int lr = idx / Q, q = idx - lr * Q;
+            const int ch = tile_m * 64 + lr;
+            const int t = t0 + q * 4;
+            if (ch >= p.H || t >= p.T) continue;
+            float4 vt = ld4(Ls + lr * LP + q * 4), vs = ld4(Ls + (64 + lr) * LP + q * 4);
+            const float bt = p.bias ? p.bias[ch] : 0.f, bs = p.bias ? p.bias[p.H + ch] : 0.f;
+            const long ot = ((long)b * 2 * p.H + ch) * p.T + t;
+            const long os = ot + (long)p.H * p.T;
+            float pt[4] = {vt.x + bt, vt.y + bt, vt.z + bt, vt.w + bt};
+            float ps[4] = {vs.x + bs, vs.y + bs, vs.z + bs, vs.w + bs};
+            if (p.drop) {
+                const uchar4 kt = *reinterpret_cast<const uchar4 *>(p.drop + ot);
+                const uchar4 ks = *reinterpret_cast<const uchar4 *>(p.drop + os);
+                const unsigned char kta[4] = {kt.x, kt.y, kt.z, kt.w}, ksa[4] = {ks.x, ks.y, ks.z, ks.w};
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const int t = t0 + c * 16 + lrow;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int ch = tile_m * 64 + wave * 16 + lk * 4 + reg;       // channel in [0, H)
-                if (ch < p.H && t < p.T) {
-                    float vt = acc[0][c][reg], vs = acc[RTW - 1][c][reg];
-                    if (p.bias) { vt += p.bias[ch]; vs += p.bias[p.H + ch]; }
-                    const long ot = ((long)b * 2 * p.H + ch) * p.T + t;
-                    const long os = ot + (long)p.H * p.T;
-                    if (p.drop) {   // dropout on the pre-activation (layers.py:147), keep-mask generated by the host RNG
-                        vt = p.drop[ot] ? vt * p.drop_scale : 0.f;
-                        vs = p.drop[os] ? vs * p.drop_scale : 0.f;
-                    }
-                    if (p.cond) { vt += p.cond[(long)b * 2 * p.H + ch]; vs += p.cond[(long)b * 2 * p.H + p.H + ch]; }
-                    const float th = tanhf(vt), sg = sigmoidf_(vs);
-                    p.y0[((long)b * p.H + ch) * p.T + t] = th * sg;
-                    if (p.y1) { p.y1[ot] = th; p.y1[os] = sg; }
+                for (int j = 0; j < 4; ++j) {
+                    pt[j] = kta[j] ? pt[j] * p.drop_scale : 0.f;
+                    ps[j] = ksa[j] ? ps[j] * p.drop_scale : 0.f;
                 }
+            }
+            if (p.cond) {
+                const float ct = p.cond[(long)b * 2 * p.H + ch], cs = p.cond[(long)b * 2 * p.H + p.H + ch];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pt[j] += ct; ps[j] += cs; }
+            }
+            float th[4], sg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { th[j] = tanhf(pt[j]); sg[j] = sigmoidf_(ps[j]); }
+            st4(p.y0 + ((long)b * p.H + ch) * p.T + t, make_float4(th[0] * sg[0], th[1] * sg[1], th[2] * sg[2], th[3] * sg[3]));
+            if (p.y1) {
+                st4(p.y1 + ot, make_float4(th[0], th[1], th[2], th[3]));
+                st4(p.y1 + os, make_float4(sg[0], sg[1], sg[2], sg[3]));
             }
         }
         return;
     }
+    for (int idx = tid; idx < WGR * Q; idx += 256) {
+        const int lr = idx / Q, q = idx - lr * Q;
+        const int row = tile_m * WGR + lr;
+        const int t = t0 + q * 4;
+        if (row >= p.M || t >= p.T) continue;
+        float4 v = ld4(Ls + lr * LP + q * 4);
+        if (p.bias) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
+        float4 m = mk ? ld4(mk + t) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (EPI == EPI_PLAIN) {
+            if (p.mask_out) { v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
+            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, v);
+        } else if (EPI == EPI_ADD) {
+            float4 a = ld4(p.r0 + (long)b * p.r_bs + (long)row * p.T + t);
+            if (p.mask_add) { a.x *= m.x; a.y *= m.y; a.z *= m.z; a.w *= m.w; }
+            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w));
+        } else if (EPI == EPI_RESSKIP) {
+            if (row < p.H) {
+                const long o = ((long)b * p.H + row) * p.T + t;
+                const float4 xi = ld4(p.r0 + o);
+                st4(p.y0 + o, make_float4((xi.x + v.x) * m.x, (xi.y + v.y) * m.y, (xi.z + v.z) * m.z, (xi.w + v.w) * m.w));
+            } else {
+                const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
+                const float4 si = p.r1 ? ld4(p.r1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st4(p.y1 + o, make_float4(si.x + v.x, si.y + v.y, si.z + v.z, si.w + v.w));
+            }
+        } else if (EPI == EPI_RESSKIP_LAST) {
+            const long o = ((long)b * p.H + row) * p.T + t;
+            const float4 si = p.r1 ? ld4(p.r1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(p.y1 + o, make_float4((si.x + v.x) * m.x, (si.y + v.y) * m.y, (si.z + v.z) * m.z, (si.w + v.w) * m.w));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// software-pipelined forward-type kernel: compile-time TAPS / KT, 16-byte global loads of chunk c+1 are in flight in
+// registers while the MFMAs of chunk c run from LDS; two LDS buffers, ONE barrier per chunk.
+// (The first version staged through run-time loops: every load waited for the previous one — 40 % of peak on the
+//  5-tap convs and 15 % on the 1x1s, profiles/r01_*_mfma_v1.csv.)
+// Preconditions (checked by the launcher, else the generic kernel runs): T % 4 == 0, 16-byte aligned x / mask rows,
+// halo (TAPS-1)*dil <= 12, M % 4 == 0.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int cpitch16(int n) { return ((n + 15) / 32 * 32 + 16 - 32 >= n) ? (n + 15) / 32 * 32 + 16 - 32 : (n + 15) / 32 * 32 + 16; }
+
+template <int RTW, int NCT, int EPI, int TAPS, int KT>
+__global__ __launch_bounds__(256) void convgemm_pipe_kernel(ConvGemmParams p) {
+    constexpr int WGR = 64 * RTW, WP = WGR + 16, NT = 16 * NCT;
+    constexpr int XC = NT + 16;                 // staged frames per row: 16-byte aligned window covering the halo
+    constexpr int XP = cpitch16(XC);
+    constexpr int W4 = TAPS * KT * (WGR / 4);   // 16-byte pieces per weight chunk
+    constexpr int NW = (W4 + 255) / 256;
+    constexpr int X4 = KT * (XC / 4);
+    constexpr int NX = (X4 + 255) / 256;
+    constexpr int WSZ = TAPS * KT * WP, XSZ = KT * XP;
+    extern __shared__ __align__(16) float smem[];
+    float *Ws = smem;                    // [2][WSZ]
+    float *Xs = smem + 2 * WSZ;          // [2][XSZ]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int ntile_t = (p.T + NT - 1) / NT;
+    const int b = blockIdx.x / ntile_t;
+    const int t0 = (blockIdx.x - b * ntile_t) * NT;
+    const int tile_m = blockIdx.y;
+    const int off = (4 - (p.pad & 3)) & 3;      // window start ts = t0 - pad - off is a multiple of 4
+    const int ts = t0 - p.pad - off;
+
+    auto grow = [&](int lr) -> int {
+        if (EPI == EPI_GATE) return lr < 64 ? tile_m * 64 + lr : p.H + tile_m * 64 + (lr - 64);
+        return tile_m * WGR + lr;
+    };
+    auto row_ok = [&](int lr) -> bool {
+        if (EPI == EPI_GATE) return tile_m * 64 + (lr & 63) < p.H;
+        return tile_m * WGR + lr < p.M;
+    };
+    auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
+
+    f32x4 acc[RTW][NCT];
 #pragma unroll
-    for (int r = 0; r < RTW; ++r) {
+    for (int r = 0; r < RTW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            const int t = t0 + c * 16 + lrow;
+        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float *xb = p.x + (long)b * p.x_bs;
+    const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    float4 wreg[NW], xreg[NX];
+
+    auto load_chunk = [&](int kc0) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = tile_m * WGR + ltile(r) * 16 + lk * 4 + reg;
-                if (row >= p.M || t >= p.T) continue;
-                float v = acc[r][c][reg];
-                if (p.bias) v += p.bias[row];
-                const float m = mk ? mk[t] : 1.f;
-                if (EPI == EPI_PLAIN) {
-                    if (p.mask_out) v *= m;
-                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v;
-                } else if (EPI == EPI_ADD) {
-                    const float add = p.r0[(long)b * p.r_bs + (long)row * p.T + t];
-                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v + (p.mask_add ? add * m : add);
-                } else if (EPI == EPI_RESSKIP) {
-                    // rows [0,H): residual -> next layer input ; rows [H,2H): skip accumulation  (layers.py:157-159)
-                    if (row < p.H) {
-                        const long o = ((long)b * p.H + row) * p.T + t;
-                        p.y0[o] = (p.r0[o] + v) * m;
-                    } else {
-                        const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
-                        p.y1[o] = (p.r1 ? p.r1[o] : 0.f) + v;
-                    }
-                } else if (EPI == EPI_RESSKIP_LAST) {
-                    // last layer: all H rows go to the skip sum, and WN's final `output * x_mask` is folded in (:161-162)
-                    const long o = ((long)b * p.H + row) * p.T + t;
-                    p.y1[o] = ((p.r1 ? p.r1[o] : 0.f) + v) * m;
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + i * 256;
+            const int m4 = idx % (WGR / 4);
+            const int rest = idx / (WGR / 4);
+            const int k = rest % KT, tap = rest / KT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < W4 && kc0 + k < p.Cin && row_ok(m4 * 4))
+                v = *reinterpret_cast<const float4 *>(p.wp + ((long)tap * p.Cin + kc0 + k) * p.M + grow(m4 * 4));
+            wreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XC / 4), k = idx / (XC / 4);
+            const int t = ts + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < X4 && kc0 + k < p.Cin && t >= 0 && t < p.T) {
+                v = *reinterpret_cast<const float4 *>(xb + (long)(kc0 + k) * p.T + t);
+                if (p.mask_in) {
+                    const float4 m = *reinterpret_cast<const float4 *>(mk + t);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
                 }
             }
+            xreg[i] = v;
         }
+    };
+    auto store_chunk = [&](int buf) {
+        float *wd = Ws + buf * WSZ;
+        float *xd = Xs + buf * XSZ;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int idx = tid + i * 256;
+            const int m4 = idx % (WGR / 4);
+            const int rest = idx / (WGR / 4);          // = tap * KT + k
+            if (idx < W4) *reinterpret_cast<float4 *>(wd + rest * WP + m4 * 4) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XC / 4), k = idx / (XC / 4);
+            if (idx < X4) *reinterpret_cast<float4 *>(xd + k * XP + q * 4) = xreg[i];
+        }
+    };
+    auto compute = [&](int buf) {
+        // operand registers are double-buffered by hand: the LDS reads of step s+1 are issued before the MFMAs of step s,
+        // so a wave that is alone on its SIMD does not stall on LDS latency between k-steps
+        const float *wd = Ws + buf * WSZ + lk * WP + lrow;
+        const float *xd = Xs + buf * XSZ + off + lrow + lk * XP;
+        constexpr int S = TAPS * (KT / 4);
+        float a[2][RTW], bv[2][NCT];
+        auto fetch = [&](int s, int slot) {
+            const int tap = s / (KT / 4), k4 = s % (KT / 4);
+#pragma unroll
+            for (int r = 0; r < RTW; ++r) a[slot][r] = wd[(tap * KT + k4 * 4) * WP + ltile(r) * 16];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bv[slot][c] = xd[(k4 * 4) * XP + c * 16 + tap * p.dil];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 < S) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+            for (int r = 0; r < RTW; ++r)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][r], bv[s & 1][c], acc[r][c], 0, 0, 0);
+        }
+    };
+
+    const int nchunks = (p.Cin + KT - 1) / KT;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk((c + 1) * KT);
+        compute(c & 1);
+        if (more) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+    if (p.vec_epilogue) {
+        conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);   // LDS is free after the last barrier
+    } else {
+        conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
     }
 }
 
@@ -217,6 +460,7 @@ struct ConvWrwParams {
     const float *x;      // (B, Cin, T) forward input, batch stride x_bs
     const float *d;      // (B, M, T) output gradient, batch stride d_bs
     float *dwp;          // [taps][Cin][M] accumulated (atomics)
+    float *dbias;        // [M] accumulated row sums of (masked) d, or null
     const float *mask;   // (B, T): multiply d by it while staging, or null
     long x_bs, d_bs;
     int B, Cin, M, T, taps, dil, pad;
@@ -287,6 +531,160 @@ __global__ __launch_bounds__(256) void convwrw_kernel(ConvWrwParams p) {
             const int m = m0 + i * 16 + lrow;
             if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tap * p.Cin + k) * p.M + m, acc[i][reg]);
         }
+    }
+}
+
+// software-pipelined weight gradient: workgroup = 64 input channels (one 16-row k-tile per wave) x 64 output channels
+// (4 m-tiles per wave) x ALL taps (each tap is the same staged X slab read at a shifted column), contraction over the
+// frames of `nb` utterances in chunks of CT frames; chunk c+1 travels HBM/L2 -> registers while chunk c feeds the MFMAs.
+constexpr int cpitch2(int n) { return ((n - 2 + 31) / 32 * 32 + 2) < n ? ((n - 2 + 31) / 32 * 32 + 2) + 32 : ((n - 2 + 31) / 32 * 32 + 2); }
+
+template <int TAPS, int CT>
+__global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
+    constexpr int XC = CT + 16;
+    constexpr int XP = cpitch2(XC), DP = cpitch2(CT);          // pitches == 2 (mod 32): conflict-free operand reads
+    constexpr int X4 = 64 * (XC / 4), D4 = 64 * (CT / 4);
+    constexpr int NX = (X4 + 255) / 256, ND = (D4 + 255) / 256;
+    constexpr int XSZ = 64 * XP, DSZ = 64 * DP;
+    extern __shared__ __align__(16) float smem[];
+    float *Xs = smem;                // [2][XSZ]
+    float *Ds = smem + 2 * XSZ;      // [2][DSZ]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int nkt = (p.Cin + 63) / 64;
+    const int kt = blockIdx.x % nkt, mt = blockIdx.x / nkt;
+    const int b0 = blockIdx.z * p.nb;
+    const int b1 = min(p.B, b0 + p.nb);
+    const int k0 = kt * 64, m0 = mt * 64;
+    const int off = (4 - (p.pad & 3)) & 3;
+    const int nct = (p.T + CT - 1) / CT;             // chunks per utterance
+    const int nchunks = (b1 - b0) * nct;
+
+    f32x4 acc[TAPS][4];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 xreg[NX], dreg[ND];
+    float bsum[ND];                                   // bias gradient: running sums of this thread's D pieces
+#pragma unroll
+    for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
+    const bool do_bias = (p.dbias != nullptr) && (kt == 0);
+
+    auto load_chunk = [&](int c) {
+        const int b = b0 + c / nct;
+        const int tc = (c % nct) * CT;
+        const int ts = tc - p.pad - off;
+        const float *xb = p.x + (long)b * p.x_bs;
+        const float *db = p.d + (long)b * p.d_bs;
+        const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XC / 4), r = idx / (XC / 4);
+            const int t = ts + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < X4 && k0 + r < p.Cin && t >= 0 && t < p.T)
+                v = *reinterpret_cast<const float4 *>(xb + (long)(k0 + r) * p.T + t);
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (CT / 4), r = idx / (CT / 4);
+            const int t = tc + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < D4 && m0 + r < p.M && t < p.T) {
+                v = *reinterpret_cast<const float4 *>(db + (long)(m0 + r) * p.T + t);
+                if (mk) {
+                    const float4 m = *reinterpret_cast<const float4 *>(mk + t);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            dreg[i] = v;
+            if (do_bias) bsum[i] += (v.x + v.y) + (v.z + v.w);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *xd = Xs + buf * XSZ;
+        float *dd = Ds + buf * DSZ;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XC / 4), r = idx / (XC / 4);
+            if (idx < X4) {           // pitch is even, not a multiple of 4: two 8-byte stores
+                float2 *d2 = reinterpret_cast<float2 *>(xd + r * XP + q * 4);
+                d2[0] = make_float2(xreg[i].x, xreg[i].y);
+                d2[1] = make_float2(xreg[i].z, xreg[i].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (CT / 4), r = idx / (CT / 4);
+            if (idx < D4) {
+                float2 *d2 = reinterpret_cast<float2 *>(dd + r * DP + q * 4);
+                d2[0] = make_float2(dreg[i].x, dreg[i].y);
+                d2[1] = make_float2(dreg[i].z, dreg[i].w);
+            }
+        }
+    };
+    auto compute = [&](int buf) {
+        const float *xd = Xs + buf * XSZ + (wave * 16 + lrow) * XP + off + lk;
+        const float *dd = Ds + buf * DSZ + lrow * DP + lk;
+        constexpr int S = CT / 4;
+        float a[2][TAPS], bv[2][4];
+        auto fetch = [&](int c4, int slot) {
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) a[slot][tp] = xd[c4 * 4 + tp * p.dil];   // A[row = channel][k = frame + tap shift]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[slot][i] = dd[i * 16 * DP + c4 * 4];        // B[k = frame][col = out channel]
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int c4 = 0; c4 < S; ++c4) {
+            if (c4 + 1 < S) fetch(c4 + 1, (c4 + 1) & 1);
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[tp][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c4 & 1][tp], bv[c4 & 1][i], acc[tp][i], 0, 0, 0);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk(c + 1);
+        compute(c & 1);
+        if (more) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int k = k0 + wave * 16 + lk * 4 + reg;
+                const int m = m0 + i * 16 + lrow;
+                if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+            }
+    if (do_bias) {      // a thread's piece i always belongs to row (tid + 256 i) / (CT/4): reduce rows in LDS, then one atomic each
+        float *rowacc = smem;
+        if (tid < 64) rowacc[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < D4) atomicAdd(rowacc + idx / (CT / 4), bsum[i]);
+        }
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
     }
 }
 
@@ -395,18 +793,71 @@ static int launch_convgemm(ConvGemmParams &p, hipStream_t s) {
     GLOWTTS_LAUNCH_CHECK("glowtts_conv");
 }
 
+template <int RTW, int NCT, int EPI, int TAPS, int KT>
+static int launch_convgemm_pipe(ConvGemmParams &p, hipStream_t s) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT;
+    constexpr size_t lds_pipe = 2 * ((size_t)TAPS * KT * (WGR + 16) + (size_t)KT * cpitch16(NT + 16)) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
+    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
+                     aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_pipe_kernel<RTW, NCT, EPI, TAPS, KT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    const int ntile_t = (p.T + NT - 1) / NT;
+    const int rows = (EPI == EPI_GATE) ? p.H : p.M;
+    const int per = (EPI == EPI_GATE) ? 64 : WGR;
+    dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
+    hipLaunchKernelGGL((convgemm_pipe_kernel<RTW, NCT, EPI, TAPS, KT>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv");
+}
+
+template <int RTW, int NCT, int EPI>
+static int dispatch_taps(ConvGemmParams &p, hipStream_t s, bool pipe_ok) {
+    if (pipe_ok) {
+        if (p.taps == 5) return launch_convgemm_pipe<RTW, NCT, EPI, 5, (RTW == 2 ? 8 : 16)>(p, s);
+        if (p.taps == 3) return launch_convgemm_pipe<RTW, NCT, EPI, 3, 16>(p, s);
+        if (p.taps == 1) return launch_convgemm_pipe<RTW, NCT, EPI, 1, 32>(p, s);
+    }
+    return launch_convgemm<RTW, NCT, EPI>(p, s);
+}
+
 template <int EPI>
 static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     // 80-frame tiles when T divides evenly (e.g. T' = 400), else 64; 128-row workgroups unless M is small
     const bool n5 = (p.T % 80 == 0) || (p.T % 64 != 0 && ((p.T + 79) / 80) * 80 < ((p.T + 63) / 64) * 64);
     const bool big = (EPI == EPI_GATE) || (p.M % 128 == 0) || p.M > 192;
-    if (big) return n5 ? launch_convgemm<2, 5, EPI>(p, s) : launch_convgemm<2, 4, EPI>(p, s);
-    return n5 ? launch_convgemm<1, 5, EPI>(p, s) : launch_convgemm<1, 4, EPI>(p, s);
+    const bool pipe_ok = (p.T % 4 == 0) && aligned16(p.x) && (p.x_bs % 4 == 0) && (p.M % 4 == 0) &&
+                         (!p.mask_in || aligned16(p.mask)) && ((p.taps - 1) * p.dil <= 12) &&
+                         (EPI != EPI_GATE || p.H % 4 == 0);
+    if (EPI == EPI_GATE) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);
+    if (big) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);
+    return n5 ? dispatch_taps<1, 5, EPI>(p, s, pipe_ok) : dispatch_taps<1, 4, EPI>(p, s, pipe_ok);
+}
+
+template <int TAPS, int CT>
+static int launch_wrw_pipe(ConvWrwParams &p, hipStream_t s) {
+    constexpr size_t lds = 2 * ((size_t)64 * cpitch2(CT + 16) + (size_t)64 * cpitch2(CT)) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_pipe_kernel<TAPS, CT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);
+    int splits = (640 + tiles - 1) / tiles;
+    if (splits > p.B) splits = p.B;
+    if (splits < 1) splits = 1;
+    p.nb = (p.B + splits - 1) / splits;
+    dim3 grid(tiles, 1, (p.B + p.nb - 1) / p.nb);
+    hipLaunchKernelGGL((convwrw_pipe_kernel<TAPS, CT>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
 }
 
 }  // namespace glowtts
 
 using namespace glowtts;
+
+extern "C" int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,
+                              glowtts_stream_t stream);
 
 static int check_conv_common(const char *name, const void *x, const void *wp, int B, int Cin, int M, int T, int taps,
                              int dil, int pad) {
@@ -459,14 +910,24 @@ extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, con
                 : dispatch_convgemm<EPI_RESSKIP>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp, int B,
-                                int Cin, int M, int T, int taps, int dil, int pad, glowtts_stream_t stream) {
+extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp,
+                                float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
+                                glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && d && dwp, "glowtts_conv_wrw: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && Cin > 0 && M > 0 && T >= 0 && taps >= 1 && dil >= 1 && pad >= 0, "glowtts_conv_wrw: bad shape");
     if ((long)B * T == 0) return 0;
     ConvWrwParams p{};
-    p.x = x; p.d = d; p.dwp = dwp; p.mask = mask; p.x_bs = x_bs; p.d_bs = d_bs;
+    p.x = x; p.d = d; p.dwp = dwp; p.dbias = dbias; p.mask = mask; p.x_bs = x_bs; p.d_bs = d_bs;
     p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
+    const bool pipe_ok = (T % 4 == 0) && aligned16(x) && aligned16(d) && (x_bs % 4 == 0) && (d_bs % 4 == 0) &&
+                         (!mask || aligned16(mask)) && ((taps - 1) * dil <= 12);
+    if (pipe_ok && (taps == 1 || taps == 3 || taps == 5)) {
+        hipStream_t s = (hipStream_t)stream;
+        const bool c40 = (T % 40 == 0);
+        if (taps == 5) return c40 ? launch_wrw_pipe<5, 40>(p, s) : launch_wrw_pipe<5, 32>(p, s);
+        if (taps == 3) return c40 ? launch_wrw_pipe<3, 40>(p, s) : launch_wrw_pipe<3, 32>(p, s);
+        return c40 ? launch_wrw_pipe<1, 40>(p, s) : launch_wrw_pipe<1, 32>(p, s);
+    }
     const int tiles = ((Cin + 63) / 64) * ((M + 127) / 128) * taps;
     int splits = (768 + tiles - 1) / tiles;          // aim at ~3 workgroups per CU
     if (splits > B) splits = B;
@@ -477,6 +938,11 @@ extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long 
     const size_t lds = ((size_t)64 * p.xs_pitch + (size_t)128 * p.ds_pitch) * sizeof(float);
     dim3 grid(((Cin + 63) / 64) * ((M + 127) / 128), taps, (B + p.nb - 1) / p.nb);
     hipLaunchKernelGGL(convwrw_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    if (dbias) {
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) { set_error("glowtts_conv_wrw: launch failed: %s", hipGetErrorString(e0)); return (int)e0; }
+        return glowtts_rowsum(d, d_bs, mask, dbias, B, M, T, stream);
+    }
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
 }
 

@@ -93,18 +93,17 @@ class _GradSink:
         return self.bufs
 
 
-def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad):
-    """dW (through the weight norm) and dbias of y = conv(x): one wrw launch, one unpack launch, one row-sum launch."""
+def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad, dwp=None):
+    """dW (through the weight norm) and dbias of y = conv(x): one wrw launch (bias row sums ride along), one unpack."""
     B, cin, T = x.shape
     cout = d.shape[1]
-    dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
-    call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(dwp), B, cin, cout, T,
-         taps, dil, pad)
+    if dwp is None:
+        dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
+    call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(dwp),
+         None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad)
     gg = None if g is None else g.detach().reshape(-1).contiguous()
     call("glowtts_unpack_weight_grad", ptr(dwp), ptr(v.detach().contiguous()), ptr(gg), ptr(inv), ptr(dv_buf),
          None if dg_buf is None else ptr(dg_buf), cout, cin, taps)
-    if db_buf is not None:
-        call("glowtts_rowsum", ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(db_buf), B, cout, T)
 
 
 class Conv1dFn(Function):
@@ -208,6 +207,14 @@ class WNFn(Function):
         sink = _GradSink(params)
         dskip = dout.contiguous()
         dx_next = None
+        sizes = []
+        for i in range(n_layers):
+            taps_i = params[6 * i].shape[2]
+            sizes += [taps_i * H * 2 * H, H * (H if i == n_layers - 1 else 2 * H)]
+        scratch = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)      # ONE memset for every packed dW
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
         dconds = [None] * n_layers
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         for i in reversed(range(n_layers)):
@@ -224,7 +231,7 @@ class WNFn(Function):
             if last:
                 dskip = d_rs                          # d(skip_in) of the last layer carries the folded mask
             _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3), sink.buf(6 * i + 4),
-                          sink.buf(6 * i + 5), 1, 1, 0)
+                          sink.buf(6 * i + 5), 1, 1, 0, dwp=scratch[offs[2 * i + 1]: offs[2 * i + 2]])
             d_acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             conv_fwd(d_rs, wb_rs, None, None, d_acts, m_rs, H, 1, 1, 0)
             d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
@@ -237,7 +244,7 @@ class WNFn(Function):
                     call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), None, 1.0, ptr(tmp), B, H, T)
                     dconds[i] = tmp.sum(-1)
             _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i), sink.buf(6 * i + 1),
-                          sink.buf(6 * i + 2), taps, dil, pad)
+                          sink.buf(6 * i + 2), taps, dil, pad, dwp=scratch[offs[2 * i]: offs[2 * i + 1]])
             dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
             conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,

@@ -125,6 +125,7 @@ int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *m
  * conv_res_skip_fwd : WN res/skip 1x1 + update: rs = W acts + b ; x_out = (x_in + rs[:H]) * mask ; skip_out = skip_in + rs[H:]
  *                 last = 1: W is (H x H), skip_out = (skip_in + rs) * mask   (folds layers.py:162)
  * conv_wrw      : dwp[tap][k][m] += sum_{b,t} x[b,k,t + tap*dil - pad] * d[b,m,t] (* mask[b,t] if mask)   (accumulated)
+ *                 and, if dbias != NULL, dbias[m] += sum_{b,t} d[b,m,t] (* mask)  (the bias gradient, same pass)
  * unpack_weight_grad : packed gradient -> dv (+= , weight layout [Cout][Cin][taps]) and dg (+=) through the weight norm
  * rowsum        : out[m] += sum_{b,t} d[b,m,t] (* mask)                                  (bias gradients, accumulated)
  * gate_bwd_ts   : da (B,2H,T) from dacts (B,H,T) and the saved ts; the forward's dropout mask is re-applied */
@@ -137,8 +138,8 @@ int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, co
 int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
                               const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B, int H, int T,
                               int last, glowtts_stream_t stream);
-int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp, int B, int Cin,
-                     int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
+int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp, float *dbias,
+                     int B, int Cin, int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
 int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
                         int taps, glowtts_stream_t stream);
 int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g, const float *inv_norm, float *dv,

@@ -517,6 +517,10 @@ def test_full_size_decoder_roundtrip_and_mas_properties(G):
     (2, 24, 36, 130, 3, 2, True, False),      # dilation 2, small odd channel counts
     (1, 5, 4, 16, 5, 3, False, False),        # halo wider than the tile interior
     (4, 192, 192, 160, 3, 1, False, False),
+    (3, 80, 192, 48, 1, 1, True, True),       # pipelined path (T % 4 == 0) with slice input + masked output
+    (2, 40, 72, 120, 3, 2, True, False),      # pipelined, 3 taps dilation 2, T % 40 == 0 weight-grad chunks
+    (2, 192, 384, 96, 5, 2, False, False),    # pipelined 5 taps dilation 2
+    (1, 16, 32, 20, 5, 4, False, False),      # halo 16 > 12: generic fallback
 ])
 def test_conv1d_fn_vs_torch(G, b, cin, cout, t, k, dil, mask_out, slice_in):
     from glow_tts_train import convops
