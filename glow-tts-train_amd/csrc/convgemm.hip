@@ -28,11 +28,14 @@ namespace glowtts {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes of zeros in device memory: the source of every out-of-range staging load (see convgemm_kp_kernel)
+__device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_ADD = 4 };
 
 struct ConvGemmParams {
     const float *x;          // (B, Cin, T) activations, batch stride x_bs elements
-    const float *wp;         // packed weights [taps][Cin][M], M contiguous
+    const float *wp;         // packed weights [taps][G = ceil(Cin/16)][M][16]: 16 consecutive input channels per row
     const float *bias;       // [M] or null
     const float *mask;       // (B, T) or null (applied where the epilogue says so)
     const float *cond;       // EPI_GATE: (B, 2H) conditioning added before the gate, or null
@@ -161,26 +164,16 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvGemmParams p) {
     const float *xb = p.x + (long)b * p.x_bs;
     for (int kc0 = 0; kc0 < p.Cin; kc0 += KT) {
         // ---- stage packed weights: [tap][k][rows] as 16-byte pieces (rows contiguous in global and LDS) ----------
-        if ((p.M & 3) == 0) {
-            const int nw4 = p.taps * KT * (WGR / 4);
-            for (int idx = tid; idx < nw4; idx += 256) {
-                const int m4 = idx % (WGR / 4);
-                const int rest = idx / (WGR / 4);
-                const int k = rest % KT, tap = rest / KT;
-                const int lr = m4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kc0 + k < p.Cin && row_ok(lr))
-                    v = *reinterpret_cast<const float4 *>(p.wp + ((long)tap * p.Cin + kc0 + k) * p.M + grow(lr));
-                *reinterpret_cast<float4 *>(Ws + (tap * KT + k) * WP + lr) = v;
-            }
-        } else {   // row count not a multiple of 4: rows of the packed matrix are not 16-byte aligned
+        {
+            const int G = (p.Cin + 15) / 16;
             const int nw = p.taps * KT * WGR;
             for (int idx = tid; idx < nw; idx += 256) {
                 const int lr = idx % WGR;
                 const int rest = idx / WGR;
                 const int k = rest % KT, tap = rest / KT;
+                const int kk = kc0 + k;
                 float v = 0.f;
-                if (kc0 + k < p.Cin && row_ok(lr)) v = p.wp[((long)tap * p.Cin + kc0 + k) * p.M + grow(lr)];
+                if (kk < p.Cin && row_ok(lr)) v = p.wp[(((long)tap * G + (kk >> 4)) * p.M + grow(lr)) * 16 + (kk & 15)];
                 Ws[(tap * KT + k) * WP + lr] = v;
             }
         }
@@ -312,28 +305,34 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// software-pipelined forward-type kernel: compile-time TAPS / KT, 16-byte global loads of chunk c+1 are in flight in
-// registers while the MFMAs of chunk c run from LDS; two LDS buffers, ONE barrier per chunk.
-// (The first version staged through run-time loops: every load waited for the previous one — 40 % of peak on the
-//  5-tap convs and 15 % on the 1x1s, profiles/r01_*_mfma_v1.csv.)
-// Preconditions (checked by the launcher, else the generic kernel runs): T % 4 == 0, 16-byte aligned x / mask rows,
-// halo (TAPS-1)*dil <= 12, M % 4 == 0.
+// software-pipelined forward-type kernel, "k-packed" LDS image.
+//
+// History (profiles/, tools/mfma_rate.hip): v1 staged through run-time loops (serialised loads, 40 % of the fp32
+// MFMA peak); v2 prefetched chunk c+1 into registers behind the MFMAs of chunk c but fed every MFMA pair from
+// ds_read_b32 — 7 LDS instructions per 10 MFMAs — and the measured ceiling of that instruction mix on one wave per
+// SIMD is 69 % of peak (tools/mfma_rate.hip: 147 TF registers-only, 108 TF with the reads).  v3 (this kernel) lays
+// both operands out with 16 consecutive k per LDS row, so ONE ds_read_b128 per operand tile feeds FOUR k-steps:
+// lane (row = l & 15, slot = l >> 4) consumes k = 4*slot + j in step j for A and B alike — a relabelling of the
+// reduction index the MFMA is free to make — i.e. 7 LDS instructions per 40 MFMAs.
+//   Ws[tap][g][row][20]   : packed weights are stored [tap][g][M][16] in HBM, so staging is a straight 16-byte copy
+//   Xs[g][frame][20]      : activations arrive [k][frame]; each 16-byte load is scattered as 4 ds_write_b32 (lanes
+//                           walk k fastest: 2-way write conflicts at most); taps shift the FRAME index, i.e. the row
+// Preconditions (else the generic kernel runs): T % 4 == 0, 16-byte aligned rows, halo (TAPS-1)*dil <= 12.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int cpitch16(int n) { return ((n + 15) / 32 * 32 + 16 - 32 >= n) ? (n + 15) / 32 * 32 + 16 - 32 : (n + 15) / 32 * 32 + 16; }
-
-template <int RTW, int NCT, int EPI, int TAPS, int KT>
-__global__ __launch_bounds__(256) void convgemm_pipe_kernel(ConvGemmParams p) {
-    constexpr int WGR = 64 * RTW, WP = WGR + 16, NT = 16 * NCT;
-    constexpr int XC = NT + 16;                 // staged frames per row: 16-byte aligned window covering the halo
-    constexpr int XP = cpitch16(XC);
-    constexpr int W4 = TAPS * KT * (WGR / 4);   // 16-byte pieces per weight chunk
+template <int RTW, int NCT, int EPI, int TAPS, int KG>
+__global__ __launch_bounds__(256, 2) void convgemm_kp_kernel(ConvGemmParams p) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT, XC = NT + 16, KP = 20;
+    constexpr int W4 = TAPS * KG * WGR * 4;          // 16-byte pieces per weight chunk
     constexpr int NW = (W4 + 255) / 256;
-    constexpr int X4 = KT * (XC / 4);
+    constexpr int X4 = KG * 16 * (XC / 4);           // 16-byte loads per activation chunk
     constexpr int NX = (X4 + 255) / 256;
-    constexpr int WSZ = TAPS * KT * WP, XSZ = KT * XP;
+    constexpr int WSZ = TAPS * KG * WGR * KP, XSZ = KG * XC * KP;
     extern __shared__ __align__(16) float smem[];
-    float *Ws = smem;                    // [2][WSZ]
-    float *Xs = smem + 2 * WSZ;          // [2][XSZ]
+    // ONE LDS image (chunk c+1 waits in registers while chunk c is consumed): half the LDS of a double buffer, so two
+    // workgroups fit per CU and each SIMD hosts two waves — one wave's staging / barriers / epilogue hide behind the
+    // other's MFMAs (a single wave per SIMD left the MFMA pipe idle 40 % of the time: profiles/r01_pmc_gate_*.txt)
+    float *Ws = smem;                    // [WSZ]
+    float *Xs = smem + WSZ;              // [XSZ]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
@@ -343,6 +342,7 @@ __global__ __launch_bounds__(256) void convgemm_pipe_kernel(ConvGemmParams p) {
     const int tile_m = blockIdx.y;
     const int off = (4 - (p.pad & 3)) & 3;      // window start ts = t0 - pad - off is a multiple of 4
     const int ts = t0 - p.pad - off;
+    const int G = (p.Cin + 15) / 16;
 
     auto grow = [&](int lr) -> int {
         if (EPI == EPI_GATE) return lr < 64 ? tile_m * 64 + lr : p.H + tile_m * 64 + (lr - 64);
@@ -362,89 +362,117 @@ __global__ __launch_bounds__(256) void convgemm_pipe_kernel(ConvGemmParams p) {
 
     const float *xb = p.x + (long)b * p.x_bs;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
-    float4 wreg[NW], xreg[NX];
+    f32x4 wreg[NW], xreg[NX];
 
-    auto load_chunk = [&](int kc0) {
+    // Per-thread source pointers, LDS destinations and validity are fixed for the whole K loop (only the 16-channel
+    // group advances, by a constant stride), so they are computed ONCE; inside the loop a load is an unconditional
+    // 16-byte read from a clamped address plus a select — no address arithmetic and no exec-mask branches that would
+    // keep the wave from issuing MFMAs.
+    int wsrc[NW], wdst[NW], wgrp[NW];          // element offsets from p.wp / LDS offsets / group index (-1 = never valid)
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx & 3;
+        const int lr = (idx >> 2) % WGR;
+        const int rest = (idx >> 2) / WGR;
+        const int g = rest % KG, tap = rest / KG;
+        const bool ok = idx < W4 && row_ok(lr);
+        wgrp[i] = ok ? g : (1 << 30);
+        wdst[i] = (idx >> 2) * KP + q * 4;
+        wsrc[i] = ok ? (int)((((long)tap * G + g) * p.M + grow(lr)) * 16 + q * 4) : 0;
+    }
+    int xsrc[NX], xdst[NX], xk[NX], xt[NX];    // element offsets from xb / LDS offsets / channel-in-chunk / frame
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * 256;
+        const int kk = idx & 15;
+        const int q = (idx >> 4) % (XC / 4);
+        const int g = (idx >> 4) / (XC / 4);
+        const int t = ts + q * 4;
+        const bool ok = idx < X4 && t >= 0 && t < p.T;
+        xk[i] = ok ? g * 16 + kk : (1 << 30);
+        xt[i] = ok ? t : 0;
+        xdst[i] = (g * XC + q * 4) * KP + kk;
+        xsrc[i] = ok ? (g * 16 + kk) * p.T + t : 0;
+    }
+    const int wstride = KG * p.M * 16, xstride = KG * 16 * p.T;
+
+    // Loads are PURE loads: an out-of-range piece reads 16 bytes of zeros from a __device__ constant instead of being
+    // patched with a select afterwards — any use of the loaded value before the MFMAs would put an s_waitcnt vmcnt(0)
+    // in front of them and serialise the prefetch (that is exactly what an earlier revision of this kernel did).
+    f32x4 mreg[NX];
+    auto load_chunk = [&](int g0) {
+        const int c = g0 / KG;
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            const int idx = tid + i * 256;
-            const int m4 = idx % (WGR / 4);
-            const int rest = idx / (WGR / 4);
-            const int k = rest % KT, tap = rest / KT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < W4 && kc0 + k < p.Cin && row_ok(m4 * 4))
-                v = *reinterpret_cast<const float4 *>(p.wp + ((long)tap * p.Cin + kc0 + k) * p.M + grow(m4 * 4));
-            wreg[i] = v;
+            const bool ok = g0 + wgrp[i] < G;
+            wreg[i] = *reinterpret_cast<const f32x4 *>(ok ? p.wp + wsrc[i] + c * wstride : g_zero16);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            const int q = idx % (XC / 4), k = idx / (XC / 4);
-            const int t = ts + q * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < X4 && kc0 + k < p.Cin && t >= 0 && t < p.T) {
-                v = *reinterpret_cast<const float4 *>(xb + (long)(kc0 + k) * p.T + t);
-                if (p.mask_in) {
-                    const float4 m = *reinterpret_cast<const float4 *>(mk + t);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
+            const bool ok = g0 * 16 + xk[i] < p.Cin;
+            xreg[i] = *reinterpret_cast<const f32x4 *>(ok ? xb + xsrc[i] + c * xstride : g_zero16);
+            if (p.mask_in) mreg[i] = *reinterpret_cast<const f32x4 *>(mk + xt[i]);
+        }
+    };
+    auto store_chunk = [&]() {
+        float *wd = Ws;
+        float *xd = Xs;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            if (tid + i * 256 < W4) *reinterpret_cast<f32x4 *>(wd + wdst[i]) = wreg[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (tid + i * 256 < X4) {
+                f32x4 v = xreg[i];
+                if (p.mask_in) v *= mreg[i];
+                float *d = xd + xdst[i];
+                d[0] = v[0]; d[KP] = v[1]; d[2 * KP] = v[2]; d[3 * KP] = v[3];
             }
-            xreg[i] = v;
-        }
     };
-    auto store_chunk = [&](int buf) {
-        float *wd = Ws + buf * WSZ;
-        float *xd = Xs + buf * XSZ;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int idx = tid + i * 256;
-            const int m4 = idx % (WGR / 4);
-            const int rest = idx / (WGR / 4);          // = tap * KT + k
-            if (idx < W4) *reinterpret_cast<float4 *>(wd + rest * WP + m4 * 4) = wreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            const int q = idx % (XC / 4), k = idx / (XC / 4);
-            if (idx < X4) *reinterpret_cast<float4 *>(xd + k * XP + q * 4) = xreg[i];
-        }
-    };
-    auto compute = [&](int buf) {
-        // operand registers are double-buffered by hand: the LDS reads of step s+1 are issued before the MFMAs of step s,
-        // so a wave that is alone on its SIMD does not stall on LDS latency between k-steps
-        const float *wd = Ws + buf * WSZ + lk * WP + lrow;
-        const float *xd = Xs + buf * XSZ + off + lrow + lk * XP;
-        constexpr int S = TAPS * (KT / 4);
-        float a[2][RTW], bv[2][NCT];
+    auto compute = [&]() {
+        const float *wd = Ws + lrow * KP + lk * 4;
+        const float *xd = Xs + (off + lrow) * KP + lk * 4;
+        constexpr int S = KG * TAPS;
+        f32x4 a[2][RTW], bv[2][NCT];
         auto fetch = [&](int s, int slot) {
-            const int tap = s / (KT / 4), k4 = s % (KT / 4);
+            const int g = s / TAPS, tap = s % TAPS;
 #pragma unroll
-            for (int r = 0; r < RTW; ++r) a[slot][r] = wd[(tap * KT + k4 * 4) * WP + ltile(r) * 16];
+            for (int r = 0; r < RTW; ++r)
+                a[slot][r] = *reinterpret_cast<const f32x4 *>(wd + ((tap * KG + g) * WGR + ltile(r) * 16) * KP);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) bv[slot][c] = xd[(k4 * 4) * XP + c * 16 + tap * p.dil];
+            for (int c = 0; c < NCT; ++c)
+                bv[slot][c] = *reinterpret_cast<const f32x4 *>(xd + (g * XC + c * 16 + tap * p.dil) * KP);
         };
         fetch(0, 0);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (s + 1 < S) fetch(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the next step's LDS reads ahead of this step's MFMAs
+            const int sl = s & 1;
 #pragma unroll
-            for (int r = 0; r < RTW; ++r)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][r], bv[s & 1][c], acc[r][c], 0, 0, 0);
+                for (int r = 0; r < RTW; ++r)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][r][j], bv[sl][c][j], acc[r][c], 0, 0, 0);
         }
     };
 
-    const int nchunks = (p.Cin + KT - 1) / KT;
+    const int nchunks = (G + KG - 1) / KG;
     load_chunk(0);
-    store_chunk(0);
+    store_chunk();
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
-        if (more) load_chunk((c + 1) * KT);
-        compute(c & 1);
-        if (more) store_chunk((c + 1) & 1);
-        __syncthreads();
+        if (more) load_chunk((c + 1) * KG);       // HBM/L2 -> registers, in flight behind the MFMAs below
+        compute();
+        __syncthreads();                          // every wave is done reading the LDS image
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
     }
     if (p.vec_epilogue) {
         conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);   // LDS is free after the last barrier
@@ -692,8 +720,9 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
 // weight packing (+ weight norm) and its backward; row sums for bias gradients
 // ------------------------------------------------------------------------------------------------------------
 // one workgroup per output channel o:  w[o] = v[o] * g[o] / ||v[o]||  (torch.nn.utils.weight_norm, dim 0) or w = v
-//   wp_f[tap][c][o]            = w[o][c][tap]          forward packing   (rows = o, K = c)
-//   wp_b[taps-1-tap][o][c]     = w[o][c][tap]          backward-data packing (rows = c, K = o, taps flipped)
+//   wp_f[tap][c/16][o][c%16]        = w[o][c][tap]     forward packing   (rows = o, K = c, 16 k per row)
+//   wp_b[taps-1-tap][o/16][c][o%16] = w[o][c][tap]     backward-data packing (rows = c, K = o, taps flipped)
+// (k positions beyond the channel count must be zero: the caller zero-fills the buffers when a count is not a multiple of 16)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ v, const float *__restrict__ g,
                                                           float *__restrict__ wp_f, float *__restrict__ wp_b,
                                                           float *__restrict__ inv_norm, int Cout, int Cin, int taps) {
@@ -710,11 +739,12 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         scale = g[o] * inv;
         if (threadIdx.x == 0 && inv_norm) inv_norm[o] = inv;
     }
+    const int Gi = (Cin + 15) / 16, Go = (Cout + 15) / 16;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int c = i / taps, tap = i - c * taps;
         const float w = vo[i] * scale;
-        if (wp_f) wp_f[((long)tap * Cin + c) * Cout + o] = w;
-        if (wp_b) wp_b[((long)(taps - 1 - tap) * Cout + o) * Cin + c] = w;
+        if (wp_f) wp_f[(((long)tap * Gi + (c >> 4)) * Cout + o) * 16 + (c & 15)] = w;
+        if (wp_b) wp_b[(((long)(taps - 1 - tap) * Go + (o >> 4)) * Cin + c) * 16 + (o & 15)] = w;
     }
 }
 
@@ -793,32 +823,32 @@ static int launch_convgemm(ConvGemmParams &p, hipStream_t s) {
     GLOWTTS_LAUNCH_CHECK("glowtts_conv");
 }
 
-template <int RTW, int NCT, int EPI, int TAPS, int KT>
-static int launch_convgemm_pipe(ConvGemmParams &p, hipStream_t s) {
+template <int RTW, int NCT, int EPI, int TAPS, int KG>
+static int launch_convgemm_kp(ConvGemmParams &p, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;
-    constexpr size_t lds_pipe = 2 * ((size_t)TAPS * KT * (WGR + 16) + (size_t)KT * cpitch16(NT + 16)) * sizeof(float);
+    constexpr size_t lds_pipe = ((size_t)TAPS * KG * WGR * 20 + (size_t)KG * (NT + 16) * 20) * sizeof(float);
     constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_pipe_kernel<RTW, NCT, EPI, TAPS, KT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
     dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
-    hipLaunchKernelGGL((convgemm_pipe_kernel<RTW, NCT, EPI, TAPS, KT>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv");
 }
 
 template <int RTW, int NCT, int EPI>
 static int dispatch_taps(ConvGemmParams &p, hipStream_t s, bool pipe_ok) {
     if (pipe_ok) {
-        if (p.taps == 5) return launch_convgemm_pipe<RTW, NCT, EPI, 5, (RTW == 2 ? 8 : 16)>(p, s);
-        if (p.taps == 3) return launch_convgemm_pipe<RTW, NCT, EPI, 3, 16>(p, s);
-        if (p.taps == 1) return launch_convgemm_pipe<RTW, NCT, EPI, 1, 32>(p, s);
+        if (p.taps == 5) return launch_convgemm_kp<RTW, NCT, EPI, 5, 1>(p, s);
+        if (p.taps == 3) return launch_convgemm_kp<RTW, NCT, EPI, 3, 1>(p, s);
+        if (p.taps == 1) return launch_convgemm_kp<RTW, NCT, EPI, 1, 2>(p, s);
     }
     return launch_convgemm<RTW, NCT, EPI>(p, s);
 }
@@ -828,7 +858,7 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     // 80-frame tiles when T divides evenly (e.g. T' = 400), else 64; 128-row workgroups unless M is small
     const bool n5 = (p.T % 80 == 0) || (p.T % 64 != 0 && ((p.T + 79) / 80) * 80 < ((p.T + 63) / 64) * 64);
     const bool big = (EPI == EPI_GATE) || (p.M % 128 == 0) || p.M > 192;
-    const bool pipe_ok = (p.T % 4 == 0) && aligned16(p.x) && (p.x_bs % 4 == 0) && (p.M % 4 == 0) &&
+    const bool pipe_ok = (p.T % 4 == 0) && aligned16(p.x) && (p.x_bs % 4 == 0) &&
                          (!p.mask_in || aligned16(p.mask)) && ((p.taps - 1) * p.dil <= 12) &&
                          (EPI != EPI_GATE || p.H % 4 == 0);
     if (EPI == EPI_GATE) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);

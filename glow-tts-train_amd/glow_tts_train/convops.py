@@ -46,12 +46,16 @@ def _dense(x: torch.Tensor) -> torch.Tensor:
 
 
 def pack_weight(v: torch.Tensor, g: Optional[torch.Tensor], want_bwd: bool = True):
-    """weight (Cout, Cin, taps) [+ weight-norm gain (Cout,1,1)] -> packed forward / backward-data layouts, 1/||v||."""
+    """weight (Cout, Cin, taps) [+ weight-norm gain (Cout,1,1)] -> k-packed forward / backward-data layouts
+    wp_f[tap][ceil(Cin/16)][Cout][16], wp_b[tap][ceil(Cout/16)][Cin][16] (taps flipped), and 1/||v|| per output channel."""
     v = f32(v.detach().contiguous())
     cout, cin, taps = v.shape
     dev = v.device
-    wp_f = torch.empty(taps, cin, cout, device=dev, dtype=torch.float32)
-    wp_b = torch.empty(taps, cout, cin, device=dev, dtype=torch.float32) if want_bwd else None
+    gi, go = (cin + 15) // 16, (cout + 15) // 16
+    new_f = torch.empty if cin % 16 == 0 else torch.zeros       # k slots past the channel count must read as zero
+    new_b = torch.empty if cout % 16 == 0 else torch.zeros
+    wp_f = new_f(taps, gi, cout, 16, device=dev, dtype=torch.float32)
+    wp_b = new_b(taps, go, cin, 16, device=dev, dtype=torch.float32) if want_bwd else None
     inv = torch.empty(cout, device=dev, dtype=torch.float32) if g is not None else None
     gg = None if g is None else f32(g.detach().reshape(-1).contiguous())
     call("glowtts_pack_weight", ptr(v), ptr(gg), ptr(wp_f), ptr(wp_b), ptr(inv), cout, cin, taps)

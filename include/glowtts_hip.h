@@ -114,8 +114,10 @@ int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *m
  * replace F.conv1d / conv-transpose / weight-gradient calls of WN and the coupling 1x1 convs (layers.py:146,156;
  * attentions.py:124-126) — MIOpen / rocBLAS through PyTorch in the reference.  All tensors (B, C, T), T contiguous;
  * `*_bs` = batch stride in elements (lets a channel slice such as x[:, :C/2] be consumed in place).
- * Packed weights: wp_f[tap][Cin][Cout] (forward) and wp_b[taps-1-tap][Cout][Cin] (backward-data), produced by
- * glowtts_pack_weight, which also applies torch's weight_norm (w = g v / ||v||, dim 0) when g != NULL.
+ * Packed weights ("k-packed": 16 consecutive reduction channels per 64-byte row, zero beyond the channel count):
+ *   wp_f[tap][ceil(Cin/16)][Cout][16] (forward) and wp_b[taps-1-tap][ceil(Cout/16)][Cin][16] (backward-data), produced by
+ * glowtts_pack_weight, which also applies torch's weight_norm (w = g v / ||v||, dim 0) when g != NULL.  The weight
+ * gradient (conv_wrw) is produced in the plain [tap][Cin][Cout] order that unpack_weight_grad consumes.
  *
  * conv_fwd      : y[b,m,t] = sum_tap sum_k wp[tap][k][m] * (x[b,k,t + tap*dil - pad] * (mask_in ? mask : 1)) + bias[m]
  *                 then (* mask if mask_out) ; if addend != NULL: y += addend (* mask if mask_add)
