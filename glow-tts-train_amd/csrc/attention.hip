@@ -1,0 +1,465 @@
+// attention.hip — windowed relative-position multi-head self-attention of the text encoder on fp32 MFMA
+// (reference attentions.py:214-333: QK^T + relative-key logits -> mask -> softmax -> dropout -> PV + relative values).
+//
+// The reference materialises (B,h,T,2T-1) relative-logit tensors and moves them between "relative" and "absolute"
+// indexing with pad / reshape tricks (attentions.py:284-333), ~15 launches per layer forward.  Here one workgroup owns a
+// 64-query block of one (utterance, head):
+//   phase 1   S = A^T B1 on v_mfma_f32_16x16x4_f32 (A = Q block, B1 = K streamed in 64-key tiles through LDS); each
+//             wave keeps its 16 x T score strip in accumulator registers (T <= 256);
+//   phase 1b  R = A^T E1^T (16 x (2w+1)) once per wave; the band |j-i| <= w of S takes R[i][j-i+w]  (relative keys);
+//   phase 2   scale, mask (-1e4 fill, optional block band), row softmax by 16-lane shuffles; P is written once to HBM
+//             for the backward, and (after dropout) to LDS as the A operand of
+//   phase 4   O = P B2^T (B2 = V streamed in 64-key tiles) + PW E2 with PW[i][r] = P[i][i+r-w]  (relative values);
+//   phase 5   O transposed through LDS and stored in the reference layout (B, C, T).
+// The SAME kernel with MODE = 1 is the first half of the backward: A = dO, B1 = V, E1 = E_v give dP (incl. the
+// relative-value term); phase 2 becomes the softmax backward dS = P (dP - sum_j P dP) * keep/scale; B2 = K, E2 = E_k
+// give dQ; dS is written to HBM for the second half (attn_dkv_kernel: dV = dO Pd, dK = Q dS, contraction over
+// queries) and for the two small embedding-gradient reductions (attn_relgrad_kernel).
+// Limits: T <= 256, d_k % 16 == 0, d_k <= 128, window <= 7.
+#include "common.hpp"
+
+namespace glowtts {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct AttnParams {
+    const float *a;        // MODE 0: q        MODE 1: dO          (B, C, T)
+    const float *b1;       // MODE 0: k        MODE 1: v
+    const float *b2;       // MODE 0: v        MODE 1: k
+    const float *e1;       // MODE 0: emb_rel_k MODE 1: emb_rel_v   (n_rel, 2w+1, dk) or null
+    const float *e2;       // MODE 0: emb_rel_v MODE 1: emb_rel_k
+    const float *mask;     // (B, T)
+    const unsigned char *drop;   // (B, h, T, T) keep bytes or null
+    float *p;              // (B, h, T, T): MODE 0 writes softmax(P) ; MODE 1 reads it
+    float *ds;             // MODE 1: (B, h, T, T) scaled score gradient out
+    float *out;            // MODE 0: O (B, C, T) ; MODE 1: dQ (B, C, T)
+    int B, H, T, dk, w, block_len, e_hs;   // e_hs: head stride of the embeddings (0 when shared across heads)
+    float scale, drop_scale;
+    int TP;                // LDS pitch of the probability strip
+};
+
+constexpr int kAP = 80;    // LDS pitch of the [d][64 queries] A block          (== 16 mod 32)
+constexpr int kBP = 68;    // LDS pitch of the [d][64 keys] B tile              (==  4 mod 32)
+
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int dk = p.dk, T = p.T, w = p.w, TP = p.TP;
+    const int EP = dk + 4, E2P = dk + 16;
+    float *As = smem;                         // [dk][kAP]
+    float *Bs = As + dk * kAP;                // [dk][kBP]
+    float *Ps = Bs + dk * kBP;                // [64][TP]
+    float *E1s = Ps + 64 * TP;                // [16][EP]     E1[r][d]
+    float *E2s = E1s + 16 * EP;               // [16][E2P]    E2[r][d]
+    float *Rs = E2s + 16 * E2P;               // [4 waves][16][17]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lcol = lane & 15, lk = lane >> 4;
+    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int DT = dk >> 4;                               // 16-wide tiles along d
+    const int njt = (T + 63) >> 6;                        // 64-key tiles
+    const long cbase = ((long)b * p.H + h) * dk;          // first channel row of this head in a (B, C, T) tensor
+    const float *Ag = p.a + cbase * T;
+    const float *B1g = p.b1 + cbase * T;
+    const float *B2g = p.b2 + cbase * T;
+    const float *mk = p.mask + (long)b * T;
+    const long pbase = ((long)b * p.H + h) * T * T;
+    const bool rel = (p.e1 != nullptr) && (w >= 0);
+
+    // ---- stage the A block [d][64 queries] and both embedding tables --------------------------------------------------
+    for (int idx = tid; idx < dk * 64; idx += 256) {
+        const int d = idx >> 6, i = idx & 63;
+        As[d * kAP + i] = (q0 + i < T) ? Ag[(long)d * T + q0 + i] : 0.f;
+    }
+    for (int idx = tid; idx < 16 * dk; idx += 256) {
+        const int r = idx / dk, d = idx - r * dk;
+        const bool ok = rel && r <= 2 * w;
+        E1s[r * EP + d] = ok ? p.e1[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
+        E2s[r * E2P + d] = ok ? p.e2[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
+    }
+
+    // ---- phase 1: S strip (16 queries x T keys per wave) ------------------------------------------------------------------
+    f32x4 S[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        if (jt < njt) {
+            __syncthreads();
+            for (int idx = tid; idx < dk * 64; idx += 256) {
+                const int d = idx >> 6, j = idx & 63;
+                Bs[d * kBP + j] = (jt * 64 + j < T) ? B1g[(long)d * T + jt * 64 + j] : 0.f;
+            }
+            __syncthreads();
+            for (int kk = 0; kk < dk; kk += 4) {
+                const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const float bv = Bs[(kk + lk) * kBP + ct * 16 + lcol];
+                    S[jt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, S[jt * 4 + ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- phase 1b: relative term R[i][r] = sum_d A[d][i] E1[r][d], added on the band j - i + w = r ----------------------
+    if (rel) {
+        f32x4 R = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < dk; kk += 4) {
+            const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
+            const float bv = E1s[lcol * EP + kk + lk];
+            R = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, R, 0, 0, 0);
+        }
+        float *rw = Rs + wave * 16 * 17;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) rw[(lk * 4 + reg) * 17 + lcol] = R[reg];
+        // (same wave wrote and reads: LDS is in order within a wave; the barrier below is for the compiler)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int il = lk * 4 + reg;
+                const int r = t * 16 + lcol - (q0 + wave * 16 + il) + w;
+                if (r >= 0 && r <= 2 * w) S[t][reg] += rw[il * 17 + r];
+            }
+        }
+    }
+
+    // ---- phase 2: softmax (MODE 0) / softmax backward (MODE 1) in registers -----------------------------------------------
+    const int ntile = (T + 15) >> 4;
+    float mi[4];
+    int ig[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        ig[reg] = q0 + wave * 16 + lk * 4 + reg;
+        mi[reg] = ig[reg] < T ? mk[ig[reg]] : 0.f;
+    }
+    float *pw = Ps + wave * 16 * TP;
+    if (MODE == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = t * 16 + lcol;
+                float s = S[t][reg] * p.scale;
+                if (t < ntile && j < T) {
+                    const bool keep = (mi[reg] * mk[j] != 0.f) && (p.block_len < 0 || abs(j - ig[reg]) <= p.block_len);
+                    s = keep ? s : -1e4f;
+                    mx = fmaxf(mx, s);
+                } else {
+                    s = -3.0e38f;
+                }
+                S[t][reg] = s;
+            }
+            mx = group16_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float e = (t < ntile) ? expf(S[t][reg] - mx) : 0.f;
+                S[t][reg] = e;
+                sum += e;
+            }
+            sum = group16_sum(sum);
+            const float inv = 1.0f / sum;
+            const int il = lk * 4 + reg;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = t * 16 + lcol;
+                if (t < ntile && j < T) {
+                    float pv = S[t][reg] * inv;
+                    if (ig[reg] < T) p.p[pbase + (long)ig[reg] * T + j] = pv;
+                    if (p.drop && ig[reg] < T) pv = p.drop[pbase + (long)ig[reg] * T + j] ? pv * p.drop_scale : 0.f;
+                    pw[il * TP + j] = (ig[reg] < T) ? pv : 0.f;
+                } else if (t < ntile) {
+                    pw[il * TP + j] = 0.f;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = t * 16 + lcol;
+                float dp = 0.f, pv = 0.f;
+                if (t < ntile && j < T && ig[reg] < T) {
+                    const long o = pbase + (long)ig[reg] * T + j;
+                    pv = p.p[o];
+                    dp = S[t][reg];
+                    if (p.drop) dp = p.drop[o] ? dp * p.drop_scale : 0.f;
+                }
+                S[t][reg] = dp;
+                dot += pv * dp;
+                // keep pv for the second sweep in the low bits of nothing: re-read below (L2-resident, tiny)
+            }
+            dot = group16_sum(dot);
+            const int il = lk * 4 + reg;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = t * 16 + lcol;
+                if (t < ntile && j < T) {
+                    float dsv = 0.f;
+                    if (ig[reg] < T) {
+                        const long o = pbase + (long)ig[reg] * T + j;
+                        const bool keep = (mi[reg] * mk[j] != 0.f) && (p.block_len < 0 || abs(j - ig[reg]) <= p.block_len);
+                        dsv = keep ? p.p[o] * (S[t][reg] - dot) * p.scale : 0.f;
+                        p.ds[o] = dsv;
+                    }
+                    pw[il * TP + j] = dsv;
+                } else if (t < ntile) {
+                    pw[il * TP + j] = 0.f;
+                }
+            }
+        }
+    }
+
+    // ---- phase 4: O (16 queries x dk per wave) = P B2^T + PW E2 -----------------------------------------------------------
+    f32x4 O[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < njt; ++jt) {
+        __syncthreads();
+        for (int idx = tid; idx < dk * 64; idx += 256) {
+            const int d = idx >> 6, j = idx & 63;
+            Bs[d * kBP + j] = (jt * 64 + j < T) ? B2g[(long)d * T + jt * 64 + j] : 0.f;
+        }
+        __syncthreads();
+        const int jmax = min(64, ((T - jt * 64 + 15) >> 4) << 4);     // keys of this tile that exist in the P strip
+        for (int kk = 0; kk < jmax; kk += 4) {
+            const float av = pw[lcol * TP + jt * 64 + kk + lk];
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                if (dt < DT) {
+                    const float bv = Bs[(dt * 16 + lcol) * kBP + kk + lk];
+                    O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (rel) {
+        const int iq = q0 + wave * 16 + lcol;                  // A operand row = query lcol of this wave
+        for (int kk = 0; kk < 2 * w + 1; kk += 4) {
+            const int r = kk + lk;
+            const int j = iq + r - w;
+            const float av = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                if (dt < DT) {
+                    const float bv = E2s[r * E2P + dt * 16 + lcol];
+                    O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- phase 5: transpose O through LDS (reuse the A block) and store rows of 64 queries -----------------------------
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+        if (dt < DT)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) As[(dt * 16 + lcol) * kAP + wave * 16 + lk * 4 + reg] = O[dt][reg];
+    __syncthreads();
+    float *og = p.out + cbase * T;
+    for (int idx = tid; idx < dk * 64; idx += 256) {
+        const int d = idx >> 6, i = idx & 63;
+        if (q0 + i < T) og[(long)d * T + q0 + i] = As[d * kAP + i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// second half of the backward: dV[d][j] = sum_i dO[d][i] Pd[i][j] ;  dK[d][j] = sum_i Q[d][i] dS[i][j]
+// workgroup = one 64-key block of one (utterance, head); wave = 16 keys x all d; contraction over queries in 64-chunks
+// ------------------------------------------------------------------------------------------------------------
+struct AttnDkvParams {
+    const float *dout, *q;             // (B, C, T)
+    const float *p, *ds;               // (B, h, T, T)
+    const unsigned char *drop;
+    float *dv, *dkk;                   // (B, C, T)
+    int B, H, T, dk;
+    float drop_scale;
+};
+
+__global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int dk = p.dk, T = p.T;
+    float *Dos = smem;                  // [dk][kBP]  dO chunk   [d][i]
+    float *Qs = Dos + dk * kBP;         // [dk][kBP]  Q chunk
+    float *Pds = Qs + dk * kBP;         // [64][kAP]  dropped P chunk  [i][j]
+    float *Dss = Pds + 64 * kAP;        // [64][kAP]  dS chunk
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lcol = lane & 15, lk = lane >> 4;
+    const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int DT = dk >> 4;
+    const long cbase = ((long)b * p.H + h) * dk;
+    const long pbase = ((long)b * p.H + h) * T * T;
+    f32x4 aV[8], aK[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) { aV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i0 = 0; i0 < T; i0 += 64) {
+        __syncthreads();
+        for (int idx = tid; idx < dk * 64; idx += 256) {
+            const int d = idx >> 6, i = idx & 63;
+            const bool ok = i0 + i < T;
+            Dos[d * kBP + i] = ok ? p.dout[(cbase + d) * T + i0 + i] : 0.f;
+            Qs[d * kBP + i] = ok ? p.q[(cbase + d) * T + i0 + i] : 0.f;
+        }
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int i = idx >> 6, j = idx & 63;
+            float pv = 0.f, dsv = 0.f;
+            if (i0 + i < T && j0 + j < T) {
+                const long o = pbase + (long)(i0 + i) * T + j0 + j;
+                pv = p.p[o];
+                if (p.drop) pv = p.drop[o] ? pv * p.drop_scale : 0.f;
+                dsv = p.ds[o];
+            }
+            Pds[i * kAP + j] = pv;
+            Dss[i * kAP + j] = dsv;
+        }
+        __syncthreads();
+        const int imax = min(64, ((T - i0 + 3) >> 2) << 2);
+        for (int kk = 0; kk < imax; kk += 4) {
+            const float bp = Pds[(kk + lk) * kAP + wave * 16 + lcol];      // B[k = query][col = key]
+            const float bd = Dss[(kk + lk) * kAP + wave * 16 + lcol];
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                if (dt < DT) {
+                    const float ao = Dos[(dt * 16 + lcol) * kBP + kk + lk];   // A[row = d][k = query]
+                    const float aq = Qs[(dt * 16 + lcol) * kBP + kk + lk];
+                    aV[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bp, aV[dt], 0, 0, 0);
+                    aK[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bd, aK[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int j = j0 + wave * 16 + lcol;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+        if (dt < DT && j < T) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long o = (cbase + dt * 16 + lk * 4 + reg) * T + j;
+                p.dv[o] = aV[dt][reg];
+                p.dkk[o] = aK[dt][reg];
+            }
+        }
+    }
+}
+
+// embedding gradients: dE[r][d] += sum_i M[i][i + r - w] * A[d][i]   (M, A) = (Pd, dO) -> dE_v ; (dS, Q) -> dE_k
+__global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restrict__ p, const float *__restrict__ ds,
+                                                           const unsigned char *__restrict__ drop, float drop_scale,
+                                                           const float *__restrict__ dout, const float *__restrict__ q,
+                                                           float *__restrict__ dek, float *__restrict__ dev, int H, int T,
+                                                           int dk, int w, int e_hs) {
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const long cbase = ((long)b * H + h) * dk;
+    const long pbase = ((long)b * H + h) * T * T;
+    const int n = (2 * w + 1) * dk;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int r = idx / dk, d = idx - r * dk;
+        float sv = 0.f, sk = 0.f;
+        for (int i = 0; i < T; ++i) {
+            const int j = i + r - w;
+            if (j < 0 || j >= T) continue;
+            const long o = pbase + (long)i * T + j;
+            float pv = p[o];
+            if (drop) pv = drop[o] ? pv * drop_scale : 0.f;
+            sv += pv * dout[(cbase + d) * T + i];
+            sk += ds[o] * q[(cbase + d) * T + i];
+        }
+        atomicAdd(dev + (long)h * e_hs + idx, sv);
+        atomicAdd(dek + (long)h * e_hs + idx, sk);
+    }
+}
+
+static int attn_check(const char *name, int B, int H, int T, int dk, int w) {
+    GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && dk > 0, "%s: bad shape", name);
+    GLOWTTS_CHECK_ARG(T <= 256, "%s: T=%d exceeds the 256-token limit of this build", name, T);
+    GLOWTTS_CHECK_ARG(dk % 16 == 0 && dk <= 128, "%s: head width %d must be a multiple of 16 and <= 128", name, dk);
+    GLOWTTS_CHECK_ARG(w <= 7, "%s: window %d > 7", name, w);
+    return 0;
+}
+
+static size_t attn_lds(int dk, int TP) {
+    return ((size_t)dk * kAP + (size_t)dk * kBP + (size_t)64 * TP + (size_t)16 * (dk + 4) + (size_t)16 * (dk + 16) + 4 * 16 * 17) *
+           sizeof(float);
+}
+
+template <int MODE>
+static int attn_launch(AttnParams &p, hipStream_t s) {
+    p.TP = ((p.T + 15) / 16) * 16 + 4;
+    const size_t lds = attn_lds(p.dk, p.TP);
+    GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("glowtts_rel_attn: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    dim3 grid((p.T + 63) / 64, p.H, p.B);
+    hipLaunchKernelGGL((attn_qblock_kernel<MODE>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
+}
+
+}  // namespace glowtts
+
+using namespace glowtts;
+
+extern "C" int glowtts_rel_attn_fwd(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                                    const float *mask, const unsigned char *drop, float drop_scale, float *p_attn,
+                                    float *out, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                                    glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(q && k && v && mask && p_attn && out, "glowtts_rel_attn_fwd: null pointer");
+    if (int rc = attn_check("glowtts_rel_attn_fwd", B, H, T, dk, window)) return rc;
+    if ((long)B * T == 0) return 0;
+    AttnParams p{};
+    p.a = q; p.b1 = k; p.b2 = v; p.e1 = emb_k; p.e2 = emb_v; p.mask = mask; p.drop = drop; p.p = p_attn; p.out = out;
+    p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
+    p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
+    p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
+    return attn_launch<0>(p, (hipStream_t)stream);
+}
+
+extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
+                                    const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
+                                    const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
+                                    float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                                    glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(dout && q && k && v && mask && p_attn && ds && dq && dk_out && dv, "glowtts_rel_attn_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(!emb_k || (emb_v && demb_k && demb_v), "glowtts_rel_attn_bwd: relative embeddings need their gradients");
+    if (int rc = attn_check("glowtts_rel_attn_bwd", B, H, T, dk, window)) return rc;
+    if ((long)B * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    AttnParams p{};
+    p.a = dout; p.b1 = v; p.b2 = k; p.e1 = emb_v; p.e2 = emb_k; p.mask = mask; p.drop = drop;
+    p.p = const_cast<float *>(p_attn); p.ds = ds; p.out = dq;
+    p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
+    p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
+    p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
+    if (int rc = attn_launch<1>(p, s)) return rc;
+    AttnDkvParams d{};
+    d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
+    d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
+    const size_t lds = ((size_t)2 * dk * kBP + (size_t)2 * 64 * kAP) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_dkv_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
+    if (emb_k) {
+        hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H), dim3(256), 0, s, p_attn, ds, drop, drop_scale, dout, q, demb_k,
+                           demb_v, H, T, dk, window, p.e_hs);
+    }
+    GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn_bwd");
+}

@@ -117,7 +117,28 @@ class MultiHeadAttention(nn.Module):
         y, self.attn = self.attention(q, k, v, mask=attn_mask)
         return self.conv_o(y)
 
+    def _kernel_applicable(self, query, key, mask):
+        """The MFMA kernel covers self-attention with a (B,1,T,T) mask that is an outer product of a sequence mask
+        (what Encoder builds, attentions.py:63), T <= 256, d_k a multiple of 16 (<= 128), window <= 7, no proximal bias."""
+        t = key.size(2)
+        return (query.is_cuda and query.size(2) == t and t <= 256 and self.k_channels % 16 == 0 and self.k_channels <= 128
+                and (self.window_size is None or self.window_size <= 7) and not self.proximal_bias and mask is not None
+                and mask.dim() == 4 and mask.size(1) == 1)
+
     def attention(self, query, key, value, mask=None):
+        """[b, d, t] tensors -> ([b, d, t], p_attn [b, n_h, t, t])."""
+        if self._kernel_applicable(query, key, mask):
+            # recover the sequence mask from the pair mask the reference API hands over: m[i] = mask[i, i]
+            m2 = torch.diagonal(mask[:, 0], dim1=1, dim2=2).contiguous().float()
+            p_drop = float(self.p_dropout) if self.training else 0.0
+            ek = self.emb_rel_k if self.window_size is not None else None
+            ev = self.emb_rel_v if self.window_size is not None else None
+            return ops.RelAttnFn.apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
+                                       self.block_length, p_drop)
+        return self._attention_general(query, key, value, mask)
+
+    def _attention_general(self, query, key, value, mask=None):
+        """Shapes outside the kernel's envelope (cross-attention, T > 256, proximal bias): torch ops, index-based."""
         b, d, t_s = key.size()
         t_t = query.size(2)
         nh, dk, w = self.n_heads, self.k_channels, self.window_size
@@ -148,8 +169,8 @@ class MultiHeadAttention(nn.Module):
         out = torch.matmul(p_attn, v)
         if w is not None:
             # weights on the 2w+1 diagonals around the main one: pw[..., i, r] = p[i, i + r - w]
-            j = pos_j = torch.arange(t_s, device=q.device)[:, None] + torch.arange(-w, w + 1, device=q.device)[None, :]
-            ok = (j >= 0) & (j < t_s)
+            pos_j = torch.arange(t_s, device=q.device)[:, None] + torch.arange(-w, w + 1, device=q.device)[None, :]
+            ok = (pos_j >= 0) & (pos_j < t_s)
             pw = torch.gather(p_attn, 3, pos_j.clamp(0, t_s - 1).expand(b, nh, t_t, 2 * w + 1)) * ok
             out = out + torch.matmul(pw, self.emb_rel_v.unsqueeze(0))
         out = out.transpose(2, 3).contiguous().view(b, d, t_t)

@@ -342,5 +342,50 @@ def mas_path(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -> torch
     return path
 
 
+class RelAttnFn(Function):
+    """Windowed relative-position self-attention (attentions.py:214-264) on the MFMA kernels of csrc/attention.hip.
+    q, k, v: (B, H*dk, T); emb_k / emb_v: (1|H, 2w+1, dk) or None; m2: (B, T) sequence mask.  Returns (out, p_attn)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, emb_k, emb_v, m2, n_heads, window, block_length, p_drop):
+        q, k, v = f32(_c(q)), f32(_c(k)), f32(_c(v))
+        B, C, T = q.shape
+        dk = C // n_heads
+        has_rel = emb_k is not None
+        ek = f32(_c(emb_k.detach())) if has_rel else None
+        ev = f32(_c(emb_v.detach())) if has_rel else None
+        share = int((not has_rel) or emb_k.shape[0] == 1)
+        drop = None
+        if p_drop > 0.0:
+            drop = (torch.rand(B, n_heads, T, T, device=q.device) >= p_drop).to(torch.uint8)
+        p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
+        out = torch.empty_like(q)
+        scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        call("glowtts_rel_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale, ptr(p_attn),
+             ptr(out), B, n_heads, T, dk, window if has_rel else 0, share, -1 if block_length is None else block_length)
+        ctx.save_for_backward(q, k, v, ek, ev, m2, drop, p_attn)
+        ctx.cfg = (n_heads, window if has_rel else 0, share, -1 if block_length is None else block_length, scale)
+        ctx.eshape = None if not has_rel else emb_k.shape
+        ctx.mark_non_differentiable(p_attn)
+        return out, p_attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout, _dp):
+        q, k, v, ek, ev, m2, drop, p_attn = ctx.saved_tensors
+        n_heads, window, share, blk, scale = ctx.cfg
+        B, C, T = q.shape
+        dk = C // n_heads
+        dout = _c(dout)
+        ds = torch.empty_like(p_attn)
+        dq, dk_, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        dek = dev = None
+        if ek is not None:
+            dek, dev = torch.zeros_like(ek), torch.zeros_like(ev)
+        call("glowtts_rel_attn_bwd", ptr(dout), ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale,
+             ptr(p_attn), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dek), ptr(dev), B, n_heads, T, dk, window, share, blk)
+        return dq, dk_, dv, dek, dev, None, None, None, None, None
+
+
 def library_loaded() -> bool:
     return _hip._lib is not None

@@ -151,6 +151,25 @@ int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int
 int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale, float *da,
                         int B, int H, int T, glowtts_stream_t stream);
 
+/* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
+ * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)
+ * (head h = channels [h*dk, (h+1)*dk)); emb_k / emb_v: (1 or H, 2*window+1, dk) or NULL (no relative terms);
+ * mask (B, T): pair (i, j) is kept iff mask[i]*mask[j] != 0 (the reference's attn_mask) and, if block_len >= 0,
+ * |i - j| <= block_len; other scores are set to -1e4.  drop: (B, H, T, T) keep bytes applied to softmax(P) with scale
+ * drop_scale, or NULL.  p_attn (B, H, T, T) receives softmax(P) BEFORE dropout (saved for the backward).
+ * fwd : scores = (q_i.k_j + q_i.emb_k[j-i+w]) / sqrt(dk) ; out_i = sum_j Pd_ij v_j + sum_r Pd[i][i+r-w] emb_v[r]
+ * bwd : dq, dk, dv (B, H*dk, T) written; demb_k / demb_v accumulated; ds (B, H, T, T) is scratch (scaled score grads).
+ * Limits: T <= 256, dk % 16 == 0, dk <= 128, window <= 7. */
+int glowtts_rel_attn_fwd(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                         const float *mask, const unsigned char *drop, float drop_scale, float *p_attn, float *out,
+                         int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                         glowtts_stream_t stream);
+int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
+                         const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
+                         const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
+                         float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                         glowtts_stream_t stream);
+
 /* ---- squeeze / unsqueeze (utils.py:135-160) -----------------------------------------------------------------
  * squeeze  : x (B,C,T) -> xs (B, n*C, T/n): xs[b, s*C+c, t'] = x[b,c,n*t'+s] * mask[b, n*t'+n-1] ; ms[b,t'] = mask[b, n*t'+n-1]
  * unsqueeze: xs (B, n*C, T') -> x (B,C,n*T'): x[b,c,n*t'+s] = xs[b,s*C+c,t'] * ms[b,t'] ; mask_out[b,n*t'+s] = ms[b,t']

@@ -228,14 +228,22 @@ def gen_attention(R):
         ("mha_t12_nowin", 12, (12, 7), None, None),
         ("mha_t70_w4", 70, (70, 33), 4, None),     # spans more than one 64-wide tile
     ]
-    for name, t, lengths, win, blk in cases:
+    # (name, t, lengths, window, block, channels): channels 32/192 give d_k = 16/96, the MFMA kernel's envelope
+    cases = [c + (16,) for c in cases] + [
+        ("mha_c32_t70_w4", 70, (70, 33), 4, None, 32),
+        ("mha_c32_t12_w4_blk3", 12, (12, 9), 4, 3, 32),
+        ("mha_c32_t5_w4", 5, (5, 2), 4, None, 32),
+        ("mha_c32_t40_nowin", 40, (40, 17), None, None, 32),
+        ("mha_c192_t160_w4", 160, (160, 101), 4, None, 192),
+    ]
+    for name, t, lengths, win, blk, ch in cases:
         torch.manual_seed(1234)
-        m = A.MultiHeadAttention(16, 16, 2, window_size=win, p_dropout=0.0, block_length=blk)
-        x = torch.randn(2, 16, t)
+        m = A.MultiHeadAttention(ch, ch, 2, window_size=win, p_dropout=0.0, block_length=blk)
+        x = torch.randn(2, ch, t)
         mask = ragged_mask(lengths, t)
         x = (x * mask).requires_grad_(True)
         attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
-        r = torch.randn(2, 16, t)
+        r = torch.randn(2, ch, t)
         y = m(x, x, attn_mask)
         (y * r).sum().backward()
         arrs = dict(x=npy(x), mask=npy(mask), r=npy(r), y=npy(y), p_attn=npy(m.attn), dx=npy(x.grad),

@@ -261,15 +261,22 @@ def test_gate_and_squeeze_golden(G):
     assert_close(x.grad, xo.grad, what="d squeeze/unsqueeze", rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("name", ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4"])
+MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4",     # d_k = 8: torch path
+             "mha_c32_t70_w4", "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4"]     # MFMA kernel
+
+
+@pytest.mark.parametrize("name", MHA_CASES)
 def test_attention_golden(G, name):
     g = load_golden(name)
     win, blk = int(g["window"]), int(g["block"])
-    f = load_sd(G.attentions.MultiHeadAttention(16, 16, 2, window_size=None if win < 0 else win, p_dropout=0.0,
+    ch = g["x"].shape[1]
+    f = load_sd(G.attentions.MultiHeadAttention(ch, ch, 2, window_size=None if win < 0 else win, p_dropout=0.0,
                                                 block_length=None if blk < 0 else blk), g)
     x = dev(g["x"]).requires_grad_(True)
     mask = dev(g["mask"])
-    y = f(x, x, mask.unsqueeze(2) * mask.unsqueeze(-1))
+    pair = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    assert f._kernel_applicable(x, x, pair) == (ch >= 32), "wrong path for this fixture"
+    y = f(x, x, pair)
     assert_close(y, g["y"], what="y", **TIGHT)
     if f.attn is not None:
         assert_close(f.attn, g["p_attn"], what="p_attn", **TIGHT)
@@ -613,3 +620,65 @@ def test_wn_dropout_path_matches_manual_mask(G):
     named = dict(wn.named_parameters())
     for k, vref in sd.items():
         assert_close(named[k].grad, vref.grad, what="grad " + k, rtol=5e-4, atol=5e-4)
+
+
+def test_attention_dropout_matches_manual_mask(G):
+    """Training-mode attention dropout (attentions.py:251): same keep-mask reproduced from the seed, torch reference."""
+    torch.manual_seed(5)
+    ch, t, b, p = 64, 50, 3, 0.25
+    f = G.attentions.MultiHeadAttention(ch, ch, 2, window_size=4, p_dropout=p).cuda().train()
+    x = torch.randn(b, ch, t, device="cuda", requires_grad=True)
+    lens = torch.tensor([50, 31, 7], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).float().unsqueeze(1)
+    pair = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    r = torch.randn(b, ch, t, device="cuda")
+    torch.manual_seed(77)
+    y = f(x, x, pair)
+    (y * r).sum().backward()
+    got = [x.grad.clone()] + [p_.grad.clone() for p_ in f.parameters()]
+    # reference: the general torch path with nn.Dropout replaced by the same keep mask
+    torch.manual_seed(77)
+    keep = (torch.rand(b, 2, t, t, device="cuda") >= p).float() / (1 - p)
+    x.grad = None
+    f.zero_grad()
+
+    class FixedDrop(torch.nn.Module):
+        def forward(self, pa):
+            return pa * keep
+
+    f.drop = FixedDrop()
+    q, k, v = f.conv_q(x), f.conv_k(x), f.conv_v(x)
+    o, _ = f._attention_general(q, k, v, pair)
+    y2 = f.conv_o(o)
+    (y2 * r).sum().backward()
+    want = [x.grad] + [p_.grad for p_ in f.parameters()]
+    assert_close(y, y2, what="y", rtol=1e-4, atol=1e-4)
+    for a, e in zip(got, want):
+        assert_close(a, e, what="grad", rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("t,ch,win,blk", [(160, 192, 4, None), (256, 64, 7, None), (200, 32, 4, 20), (33, 256, 2, None)])
+def test_attention_kernel_vs_general_path(G, t, ch, win, blk):
+    torch.manual_seed(t)
+    b = 2
+    f = G.attentions.MultiHeadAttention(ch, ch, 2, window_size=win, p_dropout=0.0, block_length=blk).cuda().eval()
+    x = torch.randn(b, ch, t, device="cuda", requires_grad=True)
+    lens = torch.tensor([t, max(1, t // 3)], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).float().unsqueeze(1)
+    pair = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    r = torch.randn(b, ch, t, device="cuda")
+    q, k, v = f.conv_q(x), f.conv_k(x), f.conv_v(x)
+    assert f._kernel_applicable(q, k, pair)
+    o1, p1 = f.attention(q, k, v, pair)
+    (o1 * r).sum().backward()
+    g1 = [x.grad.clone(), f.emb_rel_k.grad.clone(), f.emb_rel_v.grad.clone()]
+    x.grad = None
+    f.zero_grad()
+    q, k, v = f.conv_q(x), f.conv_k(x), f.conv_v(x)
+    o2, p2 = f._attention_general(q, k, v, pair)
+    (o2 * r).sum().backward()
+    g2 = [x.grad, f.emb_rel_k.grad, f.emb_rel_v.grad]
+    assert_close(o1, o2, what="out", rtol=1e-4, atol=1e-4)
+    assert_close(p1, p2, what="p_attn", rtol=1e-4, atol=1e-5)
+    for a, e, n in zip(g1, g2, ("dx", "demb_k", "demb_v")):
+        assert_close(a, e, what=n, rtol=5e-4, atol=5e-4)

@@ -196,13 +196,16 @@ def test_gate_and_squeeze():
 
 
 # ------------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("name", ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin",
-                                  "mha_t70_w4"])
+MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4", "mha_c32_t70_w4",
+             "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4"]
+
+
+@pytest.mark.parametrize("name", MHA_CASES)
 def test_attention(name):
     g = load_golden(name)
     win = int(g["window"])
     blk = int(g["block"])
-    hp = O.HParams(hidden_channels=16, n_heads=2, window_size=None if win < 0 else win,
+    hp = O.HParams(hidden_channels=g["x"].shape[1], n_heads=2, window_size=None if win < 0 else win,
                    block_length=None if blk < 0 else blk)
     sd = {"a." + kk: v for kk, v in split_prefix(g, "sd.", requires_grad=True).items()}
     x = T(g["x"]).requires_grad_(True)
