@@ -52,6 +52,27 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// Stage a [rows][64] tile (row r = src + r*T, columns col0 .. col0+63, zero beyond T) into LDS with pitch `pitch`.
+// The loads of one batch are independent (8 in flight per thread) — a plain `for idx` loop serialises load->store and made
+// the seven staging phases of the q-block kernel cost more than all its MFMAs.
+__device__ __forceinline__ void stage_rows64(float *dst, int pitch, const float *src, int rows, int T, int col0, int tid) {
+    const int total = rows * 64;
+    for (int base = 0; base < total; base += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int r = idx >> 6, c = idx & 63;
+            v[u] = (idx < total && col0 + c < T) ? src[(long)r * T + col0 + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < total) dst[(idx >> 6) * pitch + (idx & 63)] = v[u];
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -78,10 +99,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     const bool rel = (p.e1 != nullptr) && (w >= 0);
 
     // ---- stage the A block [d][64 queries] and both embedding tables --------------------------------------------------
-    for (int idx = tid; idx < dk * 64; idx += 256) {
-        const int d = idx >> 6, i = idx & 63;
-        As[d * kAP + i] = (q0 + i < T) ? Ag[(long)d * T + q0 + i] : 0.f;
-    }
+    stage_rows64(As, kAP, Ag, dk, T, q0, tid);
     for (int idx = tid; idx < 16 * dk; idx += 256) {
         const int r = idx / dk, d = idx - r * dk;
         const bool ok = rel && r <= 2 * w;
@@ -97,10 +115,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     for (int jt = 0; jt < 4; ++jt) {
         if (jt < njt) {
             __syncthreads();
-            for (int idx = tid; idx < dk * 64; idx += 256) {
-                const int d = idx >> 6, j = idx & 63;
-                Bs[d * kBP + j] = (jt * 64 + j < T) ? B1g[(long)d * T + jt * 64 + j] : 0.f;
-            }
+            stage_rows64(Bs, kBP, B1g, dk, T, jt * 64, tid);
             __syncthreads();
             for (int kk = 0; kk < dk; kk += 4) {
                 const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
@@ -233,10 +248,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     for (int dt = 0; dt < 8; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int jt = 0; jt < njt; ++jt) {
         __syncthreads();
-        for (int idx = tid; idx < dk * 64; idx += 256) {
-            const int d = idx >> 6, j = idx & 63;
-            Bs[d * kBP + j] = (jt * 64 + j < T) ? B2g[(long)d * T + jt * 64 + j] : 0.f;
-        }
+        stage_rows64(Bs, kBP, B2g, dk, T, jt * 64, tid);
         __syncthreads();
         const int jmax = min(64, ((T - jt * 64 + 15) >> 4) << 4);     // keys of this tile that exist in the P strip
         for (int kk = 0; kk < jmax; kk += 4) {
@@ -312,23 +324,33 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
     for (int dt = 0; dt < 8; ++dt) { aV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int i0 = 0; i0 < T; i0 += 64) {
         __syncthreads();
-        for (int idx = tid; idx < dk * 64; idx += 256) {
-            const int d = idx >> 6, i = idx & 63;
-            const bool ok = i0 + i < T;
-            Dos[d * kBP + i] = ok ? p.dout[(cbase + d) * T + i0 + i] : 0.f;
-            Qs[d * kBP + i] = ok ? p.q[(cbase + d) * T + i0 + i] : 0.f;
-        }
-        for (int idx = tid; idx < 64 * 64; idx += 256) {
-            const int i = idx >> 6, j = idx & 63;
-            float pv = 0.f, dsv = 0.f;
-            if (i0 + i < T && j0 + j < T) {
-                const long o = pbase + (long)(i0 + i) * T + j0 + j;
-                pv = p.p[o];
-                if (p.drop) pv = p.drop[o] ? pv * p.drop_scale : 0.f;
-                dsv = p.ds[o];
+        stage_rows64(Dos, kBP, p.dout + cbase * T, dk, T, i0, tid);
+        stage_rows64(Qs, kBP, p.q + cbase * T, dk, T, i0, tid);
+        {
+            const int rows = min(64, T - i0);
+            stage_rows64(Dss, kAP, p.ds + pbase + (long)i0 * T, rows, T, j0, tid);
+            // dropped probabilities: keep byte applied while staging, 8 independent loads per thread as above
+            for (int base = 0; base < 64 * 64; base += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int i = idx >> 6, j = idx & 63;
+                    float pv = 0.f;
+                    if (i < rows && j0 + j < T) {
+                        const long o = pbase + (long)(i0 + i) * T + j0 + j;
+                        pv = p.p[o];
+                        if (p.drop) pv = p.drop[o] ? pv * p.drop_scale : 0.f;
+                    }
+                    v[u] = pv;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    Pds[(idx >> 6) * kAP + (idx & 63)] = v[u];
+                }
             }
-            Pds[i * kAP + j] = pv;
-            Dss[i * kAP + j] = dsv;
+            for (int idx = rows * 64 + tid; idx < 64 * 64; idx += 256) Dss[(idx >> 6) * kAP + (idx & 63)] = 0.f;
         }
         __syncthreads();
         const int imax = min(64, ((T - i0 + 3) >> 2) << 2);
@@ -361,29 +383,61 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
 }
 
 // embedding gradients: dE[r][d] += sum_i M[i][i + r - w] * A[d][i]   (M, A) = (Pd, dO) -> dE_v ; (dS, Q) -> dE_k
+// workgroup = one (utterance, head): the 2w+1 diagonals of Pd and dS are gathered into LDS once; then each wave takes
+// rows d, lanes walk the queries (coalesced reads of dO[d][:] / Q[d][:]) and a wave reduction finishes each (r, d).
 __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restrict__ p, const float *__restrict__ ds,
                                                            const unsigned char *__restrict__ drop, float drop_scale,
                                                            const float *__restrict__ dout, const float *__restrict__ q,
                                                            float *__restrict__ dek, float *__restrict__ dev, int H, int T,
                                                            int dk, int w, int e_hs) {
+    extern __shared__ __align__(16) float smem[];
+    const int nr = 2 * w + 1;
+    float *dp_ = smem;              // [nr][T]  Pd[i][i+r-w]
+    float *dd_ = smem + nr * T;     // [nr][T]  dS[i][i+r-w]
     const int h = blockIdx.x % H, b = blockIdx.x / H;
     const long cbase = ((long)b * H + h) * dk;
     const long pbase = ((long)b * H + h) * T * T;
-    const int n = (2 * w + 1) * dk;
-    for (int idx = threadIdx.x; idx < n; idx += 256) {
-        const int r = idx / dk, d = idx - r * dk;
-        float sv = 0.f, sk = 0.f;
-        for (int i = 0; i < T; ++i) {
-            const int j = i + r - w;
-            if (j < 0 || j >= T) continue;
+    for (int idx = threadIdx.x; idx < nr * T; idx += 256) {
+        const int r = idx / T, i = idx - r * T;
+        const int j = i + r - w;
+        float pv = 0.f, dv = 0.f;
+        if (j >= 0 && j < T) {
             const long o = pbase + (long)i * T + j;
-            float pv = p[o];
+            pv = p[o];
             if (drop) pv = drop[o] ? pv * drop_scale : 0.f;
-            sv += pv * dout[(cbase + d) * T + i];
-            sk += ds[o] * q[(cbase + d) * T + i];
+            dv = ds[o];
         }
-        atomicAdd(dev + (long)h * e_hs + idx, sv);
-        atomicAdd(dek + (long)h * e_hs + idx, sk);
+        dp_[idx] = pv;
+        dd_[idx] = dv;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int d = wave; d < dk; d += 4) {
+        const float *orow = dout + (cbase + d) * T;
+        const float *qrow = q + (cbase + d) * T;
+        float sv[15], sk[15];
+#pragma unroll
+        for (int r = 0; r < 15; ++r) { sv[r] = 0.f; sk[r] = 0.f; }
+        for (int i = lane; i < T; i += 64) {
+            const float ov = orow[i], qv = qrow[i];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                if (r < nr) {
+                    sv[r] += dp_[r * T + i] * ov;
+                    sk[r] += dd_[r * T + i] * qv;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            if (r < nr) {
+                const float a = wave_sum(sv[r]), c = wave_sum(sk[r]);
+                if (lane == 0) {
+                    atomicAdd(dev + (long)h * e_hs + r * dk + d, a);
+                    atomicAdd(dek + (long)h * e_hs + r * dk + d, c);
+                }
+            }
+        }
     }
 }
 
@@ -458,7 +512,8 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     if (e != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
     if (emb_k) {
-        hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H), dim3(256), 0, s, p_attn, ds, drop, drop_scale, dout, q, demb_k,
+        const size_t lds_r = (size_t)2 * (2 * window + 1) * T * sizeof(float);
+        hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H), dim3(256), lds_r, s, p_attn, ds, drop, drop_scale, dout, q, demb_k,
                            demb_v, H, T, dk, window, p.e_hs);
     }
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn_bwd");

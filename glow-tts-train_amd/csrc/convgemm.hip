@@ -723,11 +723,9 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
 //   wp_f[tap][c/16][o][c%16]        = w[o][c][tap]     forward packing   (rows = o, K = c, 16 k per row)
 //   wp_b[taps-1-tap][o/16][c][o%16] = w[o][c][tap]     backward-data packing (rows = c, K = o, taps flipped)
 // (k positions beyond the channel count must be zero: the caller zero-fills the buffers when a count is not a multiple of 16)
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ v, const float *__restrict__ g,
-                                                          float *__restrict__ wp_f, float *__restrict__ wp_b,
-                                                          float *__restrict__ inv_norm, int Cout, int Cin, int taps) {
-    __shared__ float red[4];
-    const int o = blockIdx.x;
+__device__ __forceinline__ void pack_weight_row(const float *__restrict__ v, const float *__restrict__ g,
+                                                float *__restrict__ wp_f, float *__restrict__ wp_b,
+                                                float *__restrict__ inv_norm, int o, int Cout, int Cin, int taps, float *red) {
     const int n = Cin * taps;
     const float *vo = v + (long)o * n;
     float scale = 1.f;
@@ -748,14 +746,32 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     }
 }
 
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ v, const float *__restrict__ g,
+                                                          float *__restrict__ wp_f, float *__restrict__ wp_b,
+                                                          float *__restrict__ inv_norm, int Cout, int Cin, int taps) {
+    __shared__ float red[4];
+    pack_weight_row(v, g, wp_f, wp_b, inv_norm, blockIdx.x, Cout, Cin, taps, red);
+}
+
+// several convolutions in ONE launch (a WN stack has 2 per layer): desc[c] = {v, g, wp_f, wp_b, inv_norm, Cout, Cin, taps}
+// as 8 x int64, row_prefix[c] = first workgroup of convolution c.  The table is built once per module and reused.
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long long *__restrict__ desc,
+                                                                const int *__restrict__ row_prefix, int n_conv) {
+    __shared__ float red[4];
+    int c = 0;
+    while (c + 1 < n_conv && (int)blockIdx.x >= row_prefix[c + 1]) ++c;
+    const long long *d = desc + (long)c * 8;
+    pack_weight_row(reinterpret_cast<const float *>(d[0]), reinterpret_cast<const float *>(d[1]),
+                    reinterpret_cast<float *>(d[2]), reinterpret_cast<float *>(d[3]), reinterpret_cast<float *>(d[4]),
+                    (int)blockIdx.x - row_prefix[c], (int)d[5], (int)d[6], (int)d[7], red);
+}
+
 // backward of the packing: dw[o][c][tap] = dwp[tap][c][o];  plain conv: dweight += dw
 // weight norm: dg[o] += sum(dw * v) / n ;  dv += (g / n) * (dw - v * sum(dw * v) / n^2)      (n = ||v[o]||)
-__global__ __launch_bounds__(256) void unpack_weight_grad_kernel(const float *__restrict__ dwp, const float *__restrict__ v,
-                                                                 const float *__restrict__ g, const float *__restrict__ inv_norm,
-                                                                 float *__restrict__ dv, float *__restrict__ dg, int Cout,
-                                                                 int Cin, int taps) {
-    __shared__ float red[4];
-    const int o = blockIdx.x;
+__device__ __forceinline__ void unpack_weight_grad_row(const float *__restrict__ dwp, const float *__restrict__ v,
+                                                       const float *__restrict__ g, const float *__restrict__ inv_norm,
+                                                       float *__restrict__ dv, float *__restrict__ dg, int o, int Cout,
+                                                       int Cin, int taps, float *red) {
     const int n = Cin * taps;
     const float *vo = v + (long)o * n;
     if (g == nullptr) {
@@ -779,6 +795,27 @@ __global__ __launch_bounds__(256) void unpack_weight_grad_kernel(const float *__
         const int c = i / taps, tap = i - c * taps;
         dv[(long)o * n + i] += gn * (dwp[((long)tap * Cin + c) * Cout + o] - vo[i] * proj);
     }
+}
+
+__global__ __launch_bounds__(256) void unpack_weight_grad_kernel(const float *__restrict__ dwp, const float *__restrict__ v,
+                                                                 const float *__restrict__ g, const float *__restrict__ inv_norm,
+                                                                 float *__restrict__ dv, float *__restrict__ dg, int Cout,
+                                                                 int Cin, int taps) {
+    __shared__ float red[4];
+    unpack_weight_grad_row(dwp, v, g, inv_norm, dv, dg, blockIdx.x, Cout, Cin, taps, red);
+}
+
+// desc[c] = {dwp, v, g, inv_norm, dv, dg, Cout, Cin, taps} as 9 x int64
+__global__ __launch_bounds__(256) void unpack_weight_grad_multi_kernel(const long long *__restrict__ desc,
+                                                                       const int *__restrict__ row_prefix, int n_conv) {
+    __shared__ float red[4];
+    int c = 0;
+    while (c + 1 < n_conv && (int)blockIdx.x >= row_prefix[c + 1]) ++c;
+    const long long *d = desc + (long)c * 9;
+    unpack_weight_grad_row(reinterpret_cast<const float *>(d[0]), reinterpret_cast<const float *>(d[1]),
+                           reinterpret_cast<const float *>(d[2]), reinterpret_cast<const float *>(d[3]),
+                           reinterpret_cast<float *>(d[4]), reinterpret_cast<float *>(d[5]), (int)blockIdx.x - row_prefix[c],
+                           (int)d[6], (int)d[7], (int)d[8], red);
 }
 
 // out[m] += sum_{b,t} d[b][m][t]   (bias gradients) — grid (M, slabs of utterances)
@@ -992,6 +1029,20 @@ extern "C" int glowtts_unpack_weight_grad(const float *dwp, const float *v, cons
     GLOWTTS_CHECK_ARG(Cout > 0 && Cin > 0 && taps > 0, "glowtts_unpack_weight_grad: bad shape");
     hipLaunchKernelGGL(unpack_weight_grad_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dwp, v, g, inv_norm, dv, dg, Cout, Cin, taps);
     GLOWTTS_LAUNCH_CHECK("glowtts_unpack_weight_grad");
+}
+
+extern "C" int glowtts_pack_weight_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
+                                         glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(desc && row_prefix && n_conv > 0 && total_rows > 0, "glowtts_pack_weight_multi: bad argument");
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, desc, row_prefix, n_conv);
+    GLOWTTS_LAUNCH_CHECK("glowtts_pack_weight_multi");
+}
+
+extern "C" int glowtts_unpack_weight_grad_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
+                                                glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(desc && row_prefix && n_conv > 0 && total_rows > 0, "glowtts_unpack_weight_grad_multi: bad argument");
+    hipLaunchKernelGGL(unpack_weight_grad_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, desc, row_prefix, n_conv);
+    GLOWTTS_LAUNCH_CHECK("glowtts_unpack_weight_grad_multi");
 }
 
 extern "C" int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,

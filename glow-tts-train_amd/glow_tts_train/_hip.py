@@ -45,6 +45,8 @@ _SIGNATURES = {
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
+    "glowtts_pack_weight_multi": [_P, _P, _I, _I],
+    "glowtts_unpack_weight_grad_multi": [_P, _P, _I, _I],
     "glowtts_gate_bwd_ts": [_P, _P, _P, _F, _P, _I, _I, _I],
     "glowtts_rel_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_rel_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],

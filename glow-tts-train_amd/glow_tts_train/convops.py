@@ -97,7 +97,7 @@ class _GradSink:
         return self.bufs
 
 
-def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad, dwp=None):
+def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad, dwp=None, unpack=True):
     """dW (through the weight norm) and dbias of y = conv(x): one wrw launch (bias row sums ride along), one unpack."""
     B, cin, T = x.shape
     cout = d.shape[1]
@@ -105,6 +105,8 @@ def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, 
         dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
     call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(dwp),
          None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad)
+    if not unpack:
+        return
     gg = None if g is None else g.detach().reshape(-1).contiguous()
     call("glowtts_unpack_weight_grad", ptr(dwp), ptr(v.detach().contiguous()), ptr(gg), ptr(inv), ptr(dv_buf),
          None if dg_buf is None else ptr(dg_buf), cout, cin, taps)
@@ -147,35 +149,95 @@ class Conv1dFn(Function):
         return dx, dv, dg, db, None, None, None
 
 
+class WNPackPlan:
+    """Persistent packed-weight / packed-gradient buffers and device descriptor tables of one WN stack, so that weight
+    norm + packing of all 2*n_layers convolutions is ONE launch per forward and their un-packing ONE launch per backward
+    (the tables hold raw device pointers, valid as long as the parameter storage does not move: checked by key)."""
+
+    def __init__(self):
+        self.key = None
+        self.gkey = None
+
+    def ensure(self, params, n_layers):
+        key = tuple(0 if p is None else p.data_ptr() for p in params) + tuple(None if p is None else tuple(p.shape) for p in params)
+        if key == self.key:
+            return
+        dev = params[0].device
+        self.convs = []          # (v, g, wp_f, wp_b, inv, cout, cin, taps, dwp_offset)
+        rows, off = [0], 0
+        for i in range(2 * n_layers):
+            v, g = params[3 * i], params[3 * i + 1]
+            cout, cin, taps = v.shape
+            gi, go = (cin + 15) // 16, (cout + 15) // 16
+            wp_f = (torch.empty if cin % 16 == 0 else torch.zeros)(taps, gi, cout, 16, device=dev)
+            wp_b = (torch.empty if cout % 16 == 0 else torch.zeros)(taps, go, cin, 16, device=dev)
+            inv = torch.empty(cout, device=dev) if g is not None else None
+            self.convs.append((v, g, wp_f, wp_b, inv, cout, cin, taps, off))
+            off += taps * cin * cout
+            rows.append(rows[-1] + cout)
+        self.dwp = torch.empty(off, device=dev, dtype=torch.float32)
+        self.total_rows = rows[-1]
+        self.prefix = torch.tensor(rows, dtype=torch.int32).to(dev)
+        self.desc = torch.tensor(
+            [[v.data_ptr(), 0 if g is None else g.data_ptr(), f.data_ptr(), b.data_ptr(), 0 if inv is None else inv.data_ptr(),
+              cout, cin, taps] for (v, g, f, b, inv, cout, cin, taps, _) in self.convs], dtype=torch.int64).to(dev)
+        self.key, self.gkey = key, None
+
+    def pack(self):
+        call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
+
+    def dwp_view(self, i):
+        cout, cin, taps, off = self.convs[i][5:9]
+        return self.dwp[off: off + taps * cin * cout]
+
+    def unpack_into_grads(self, params):
+        gkey = tuple(0 if p is None else p.grad.data_ptr() for p in params)
+        if gkey != self.gkey:
+            rows = []
+            for i, (v, g, _, _, inv, cout, cin, taps, off) in enumerate(self.convs):
+                pv, pg = params[3 * i], params[3 * i + 1]
+                rows.append([self.dwp.data_ptr() + 4 * off, v.data_ptr(), 0 if g is None else g.data_ptr(),
+                             0 if inv is None else inv.data_ptr(), pv.grad.data_ptr(), 0 if pg is None else pg.grad.data_ptr(),
+                             cout, cin, taps])
+            self.gdesc = torch.tensor(rows, dtype=torch.int64).to(self.dwp.device)
+            self.gkey = gkey
+        call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
+
+
 class WNFn(Function):
     """The whole WN stack (reference layers.py:138-162) as one autograd node.
 
-    forward, per layer i:  acts, ts = conv_gate(x_i)                 [k-tap dilated conv + bias + dropout + cond + gate]
-                           x_{i+1}, skip = conv_res_skip(acts, x_i)  [1x1 conv + bias + residual*mask + skip accumulate]
-    backward, per layer (reverse): d_rs = [dx_{i+1} mask ; dskip] -> weight grads (wrw) -> d_acts = W_rs^T d_rs
-                           -> gate backward from the saved tanh/sigmoid -> weight grads -> dx_i = d_rs[:H] + W_in^T (*) d_xin
+    forward: weight norm + packing of every conv (one launch), dropout keep-masks of every layer (one generator call),
+             then per layer i:  acts, ts = conv_gate(x_i)                 [k-tap dilated conv + bias + dropout + cond + gate]
+                                x_{i+1}, skip = conv_res_skip(acts, x_i)  [1x1 conv + bias + residual*mask + skip accumulate]
+    backward, per layer (reverse): d_rs = [dx_{i+1} mask ; dskip] -> weight grads (wrw, bias sums ride along)
+             -> d_acts = W_rs^T d_rs -> gate backward from the saved tanh/sigmoid -> weight grads
+             -> dx_i = d_rs[:H] + W_in^T (*) d_xin ; finally every packed gradient goes through the weight norm into
+             param.grad in one launch.
     Saved per layer: x_i (H), acts (H), ts (2H) [+ dropout bytes].
     """
 
     @staticmethod
-    def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, *params):
-        # params: per layer (in_v, in_g, in_b, rs_v, rs_g, rs_b)
+    def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, *params):
+        # params: per layer (in_v, in_g, in_b, rs_v, rs_g, rs_b); plan: the module's WNPackPlan
         x = f32(x.contiguous())
         B, H, T = x.shape
         dev = x.device
-        saved, packs, drops = [], [], []
+        saved = []
         skip = None
         cur = x
+        plan.ensure(params, n_layers)
+        plan.pack()
+        drop_all = None
+        if p_drop > 0.0:
+            drop_all = (torch.rand(n_layers, B, 2 * H, T, device=dev) >= p_drop).to(torch.uint8)
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             taps = in_v.shape[2]
             dil = dil_rate ** i
             pad = (taps * dil - dil) // 2
-            wf_in, wb_in, inv_in = pack_weight(in_v, in_g)
-            wf_rs, wb_rs, inv_rs = pack_weight(rs_v, rs_g)
-            drop = None
-            if p_drop > 0.0:
-                drop = (torch.rand(B, 2 * H, T, device=dev) >= p_drop).to(torch.uint8)
+            wf_in, wf_rs = plan.convs[2 * i][2], plan.convs[2 * i + 1][2]
+            drop = None if drop_all is None else drop_all[i]
             acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             ts = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
             c_i = None if cond is None else f32(cond[:, 2 * H * i: 2 * H * (i + 1)].reshape(B, 2 * H).contiguous())
@@ -187,13 +249,12 @@ class WNFn(Function):
             call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(f32(rs_b.detach().contiguous())), ptr(m2),
                  None if last else ptr(cur), ptr(skip), None if last else ptr(nxt), ptr(skip_out), B, H, T, int(last))
             saved += [cur, acts, ts]
-            packs += [wb_in, inv_in, wb_rs, inv_rs]
-            drops.append(drop)
             skip = skip_out
             if not last:
                 cur = nxt
-        ctx.save_for_backward(m2, *saved, *packs, *[d for d in drops if d is not None])
+        ctx.save_for_backward(m2, *saved, *([] if drop_all is None else [drop_all]))
         ctx.params = params
+        ctx.plan = plan
         ctx.cfg = (n_layers, dil_rate, float(p_drop), cond is not None, B, H, T)
         return skip
 
@@ -204,27 +265,20 @@ class WNFn(Function):
         sv = ctx.saved_tensors
         m2 = sv[0]
         saved = sv[1: 1 + 3 * n_layers]
-        packs = sv[1 + 3 * n_layers: 1 + 7 * n_layers]
-        drops = list(sv[1 + 7 * n_layers:]) if p_drop > 0 else [None] * n_layers
-        params = ctx.params
+        drops = list(sv[1 + 3 * n_layers]) if p_drop > 0 else [None] * n_layers
+        params, plan = ctx.params, ctx.plan
         dev = dout.device
         sink = _GradSink(params)
         dskip = dout.contiguous()
         dx_next = None
-        sizes = []
-        for i in range(n_layers):
-            taps_i = params[6 * i].shape[2]
-            sizes += [taps_i * H * 2 * H, H * (H if i == n_layers - 1 else 2 * H)]
-        scratch = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)      # ONE memset for every packed dW
-        offs = [0]
-        for sz in sizes:
-            offs.append(offs[-1] + sz)
         dconds = [None] * n_layers
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        plan.dwp.zero_()                                # ONE memset for every packed weight gradient of the stack
         for i in reversed(range(n_layers)):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             x_i, acts, ts = saved[3 * i: 3 * i + 3]
-            wb_in, inv_in, wb_rs, inv_rs = packs[4 * i: 4 * i + 4]
+            wb_in, inv_in = plan.convs[2 * i][3:5]
+            wb_rs, inv_rs = plan.convs[2 * i + 1][3:5]
             taps = in_v.shape[2]
             dil = dil_rate ** i
             pad = (taps * dil - dil) // 2
@@ -235,7 +289,7 @@ class WNFn(Function):
             if last:
                 dskip = d_rs                          # d(skip_in) of the last layer carries the folded mask
             _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3), sink.buf(6 * i + 4),
-                          sink.buf(6 * i + 5), 1, 1, 0, dwp=scratch[offs[2 * i + 1]: offs[2 * i + 2]])
+                          sink.buf(6 * i + 5), 1, 1, 0, dwp=plan.dwp_view(2 * i + 1), unpack=not sink.direct)
             d_acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             conv_fwd(d_rs, wb_rs, None, None, d_acts, m_rs, H, 1, 1, 0)
             d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
@@ -248,13 +302,15 @@ class WNFn(Function):
                     call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), None, 1.0, ptr(tmp), B, H, T)
                     dconds[i] = tmp.sum(-1)
             _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i), sink.buf(6 * i + 1),
-                          sink.buf(6 * i + 2), taps, dil, pad, dwp=scratch[offs[2 * i]: offs[2 * i + 1]])
+                          sink.buf(6 * i + 2), taps, dil, pad, dwp=plan.dwp_view(2 * i), unpack=not sink.direct)
             dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
             conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
                      addend=None if last else d_rs[:, :H])
             dx_next = dx
+        if sink.direct:                                 # every un-packing (through the weight norm) in one launch
+            plan.unpack_into_grads(params)
         dcond = None
         if has_cond:
             dcond = torch.cat(dconds, 1).unsqueeze(-1)
-        return (dx_next, None, dcond, None, None, None, *sink.results())
+        return (dx_next, None, dcond, None, None, None, None, *sink.results())

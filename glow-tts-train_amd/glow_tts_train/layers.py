@@ -109,7 +109,9 @@ class WN(nn.Module):
             flat.extend(self._conv_params(in_layer))
             flat.extend(self._conv_params(rs_layer))
         p_drop = float(self.p_dropout) if self.training else 0.0
-        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, *flat)
+        if not hasattr(self, "_pack_plan"):
+            self._pack_plan = convops.WNPackPlan()
+        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, *flat)
 
     def remove_weight_norm(self):
         if self.gin_channels != 0:

@@ -148,6 +148,13 @@ int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g,
                                float *dg, int Cout, int Cin, int taps, glowtts_stream_t stream);
 int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,
                    glowtts_stream_t stream);
+/* several convolutions per launch (a WN stack: 2 per layer).  desc = n_conv rows of int64:
+ *   pack  : {v, g, wp_f, wp_b, inv_norm, Cout, Cin, taps}            unpack: {dwp, v, g, inv_norm, dv, dg, Cout, Cin, taps}
+ * row_prefix[c] = sum of Cout of the convolutions before c (int32, n_conv + 1 entries); both tables in DEVICE memory. */
+int glowtts_pack_weight_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
+                              glowtts_stream_t stream);
+int glowtts_unpack_weight_grad_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
+                                     glowtts_stream_t stream);
 int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale, float *da,
                         int B, int H, int T, glowtts_stream_t stream);
 

@@ -602,7 +602,7 @@ def test_wn_dropout_path_matches_manual_mask(G):
     (out * r).sum().backward()
     # manual: same RNG stream, same order
     torch.manual_seed(99)
-    keeps = [(torch.rand(b, 2 * H, t, device="cuda") >= p).float() for _ in range(L)]
+    keeps = list((torch.rand(L, b, 2 * H, t, device="cuda") >= p).float())      # one generator call for all layers
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in wn.state_dict().items()}
     xo = x.detach().cpu().clone().requires_grad_(True)
     cur, skip = xo, 0
