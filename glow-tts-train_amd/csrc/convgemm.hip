@@ -490,6 +490,7 @@ struct ConvWrwParams {
     float *dwp;          // [taps][Cin][M] accumulated (atomics)
     float *dbias;        // [M] accumulated row sums of (masked) d, or null
     const float *mask;   // (B, T): multiply d by it while staging, or null
+    const float *mask_x; // (B, T): multiply x by it while staging (the forward conv consumed x * mask), or null
     long x_bs, d_bs;
     int B, Cin, M, T, taps, dil, pad;
     int nb;              // utterances per workgroup (split of the contraction)
@@ -526,7 +527,10 @@ __global__ __launch_bounds__(256) void convwrw_kernel(ConvWrwParams p) {
                 const int r = idx / CT, j = idx - r * CT;
                 const int t = tc + j + shift;
                 float v = 0.f;
-                if (k0 + r < p.Cin && tc + j < p.T && t >= 0 && t < p.T) v = xb[(long)(k0 + r) * p.T + t];
+                if (k0 + r < p.Cin && tc + j < p.T && t >= 0 && t < p.T) {
+                    v = xb[(long)(k0 + r) * p.T + t];
+                    if (p.mask_x) v *= p.mask_x[(long)b * p.T + t];
+                }
                 Xs[r * XP + j] = v;
             }
             for (int idx = tid; idx < 128 * CT; idx += 256) {
@@ -612,8 +616,13 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
             const int q = idx % (XC / 4), r = idx / (XC / 4);
             const int t = ts + q * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < X4 && k0 + r < p.Cin && t >= 0 && t < p.T)
+            if (idx < X4 && k0 + r < p.Cin && t >= 0 && t < p.T) {
                 v = *reinterpret_cast<const float4 *>(xb + (long)(k0 + r) * p.T + t);
+                if (p.mask_x) {
+                    const float4 m = *reinterpret_cast<const float4 *>(p.mask_x + (long)b * p.T + t);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
             xreg[i] = v;
         }
 #pragma unroll
@@ -977,17 +986,17 @@ extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, con
                 : dispatch_convgemm<EPI_RESSKIP>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp,
-                                float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
-                                glowtts_stream_t stream) {
+extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask,
+                                const float *mask_x, float *dwp, float *dbias, int B, int Cin, int M, int T, int taps,
+                                int dil, int pad, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && d && dwp, "glowtts_conv_wrw: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && Cin > 0 && M > 0 && T >= 0 && taps >= 1 && dil >= 1 && pad >= 0, "glowtts_conv_wrw: bad shape");
     if ((long)B * T == 0) return 0;
     ConvWrwParams p{};
-    p.x = x; p.d = d; p.dwp = dwp; p.dbias = dbias; p.mask = mask; p.x_bs = x_bs; p.d_bs = d_bs;
+    p.x = x; p.d = d; p.dwp = dwp; p.dbias = dbias; p.mask = mask; p.mask_x = mask_x; p.x_bs = x_bs; p.d_bs = d_bs;
     p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
     const bool pipe_ok = (T % 4 == 0) && aligned16(x) && aligned16(d) && (x_bs % 4 == 0) && (d_bs % 4 == 0) &&
-                         (!mask || aligned16(mask)) && ((taps - 1) * dil <= 12);
+                         (!mask || aligned16(mask)) && (!mask_x || aligned16(mask_x)) && ((taps - 1) * dil <= 12);
     if (pipe_ok && (taps == 1 || taps == 3 || taps == 5)) {
         hipStream_t s = (hipStream_t)stream;
         const bool c40 = (T % 40 == 0);

@@ -38,8 +38,8 @@ class Encoder(nn.Module):
         pair_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
         for attn, norm1, ffn, norm2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
             x = x * x_mask
-            x = norm1(x + self.drop(attn(x, x, pair_mask)))
-            x = norm2(x + self.drop(ffn(x, x_mask)))
+            x = norm1(x, res=self.drop(attn(x, x, pair_mask)))       # LN(x + y): residual add fused into the norm kernel
+            x = norm2(x, res=self.drop(ffn(x, x_mask)))
         return x * x_mask
 
 
@@ -68,9 +68,9 @@ class CouplingBlock(nn.Module):
         m2 = ops.mask2d(x_mask)
         sv, sg, sb = WN._conv_params(self.start)
         # the 1x1 convs consume the channel slice in place (batch stride C*T) and fold bias and mask into the epilogue
-        h = convops.Conv1dFn.apply(x[:, : self.in_channels // 2], sv, sg, sb, m2, True, 1)
+        h = convops.Conv1dFn.apply(x[:, : self.in_channels // 2], sv, sg, sb, m2, False, True, 1)
         h = self.wn(h, x_mask, g, m2=m2)
-        out = convops.Conv1dFn.apply(h, self.end.weight, None, self.end.bias, m2, False, 1)
+        out = convops.Conv1dFn.apply(h, self.end.weight, None, self.end.bias, m2, False, False, 1)
         if reverse:
             return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
         return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale)
@@ -113,9 +113,9 @@ class MultiHeadAttention(nn.Module):
             self.conv_k.bias.data.copy_(self.conv_q.bias.data)
 
     def forward(self, x, c, attn_mask=None):
-        q, k, v = self.conv_q(x), self.conv_k(c), self.conv_v(c)
+        q, k, v = convops.conv1d(self.conv_q, x), convops.conv1d(self.conv_k, c), convops.conv1d(self.conv_v, c)
         y, self.attn = self.attention(q, k, v, mask=attn_mask)
-        return self.conv_o(y)
+        return convops.conv1d(self.conv_o, y)
 
     def _kernel_applicable(self, query, key, mask):
         """The MFMA kernel covers self-attention with a (B,1,T,T) mask that is an outer product of a sequence mask
@@ -189,6 +189,7 @@ class FFN(nn.Module):
         self.drop = nn.Dropout(p_dropout)
 
     def forward(self, x, x_mask):
-        h = self.conv_1(x * x_mask)
+        m2 = ops.mask2d(x_mask)
+        h = convops.conv1d(self.conv_1, x, m2, mask_in=True)                       # conv_1(x * mask)
         h = h * torch.sigmoid(1.702 * h) if self.activation == "gelu" else torch.relu(h)
-        return self.conv_2(self.drop(h) * x_mask) * x_mask
+        return convops.conv1d(self.conv_2, self.drop(h), m2, mask_in=True, mask_out=True)   # conv_2(h * mask) * mask

@@ -97,13 +97,14 @@ class _GradSink:
         return self.bufs
 
 
-def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad, dwp=None, unpack=True):
+def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, taps, dil, pad, dwp=None, unpack=True,
+                  m2_for_x=None):
     """dW (through the weight norm) and dbias of y = conv(x): one wrw launch (bias row sums ride along), one unpack."""
     B, cin, T = x.shape
     cout = d.shape[1]
     if dwp is None:
         dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
-    call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(dwp),
+    call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(m2_for_x), ptr(dwp),
          None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad)
     if not unpack:
         return
@@ -113,10 +114,11 @@ def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, 
 
 
 class Conv1dFn(Function):
-    """y = conv1d(x; weight_norm(v, g) or v, bias, dilation, 'same' padding) [* mask] on the MFMA kernels."""
+    """y = conv1d(x [* mask]; weight_norm(v, g) or v, bias, dilation, 'same' padding) [* mask] on the MFMA kernels.
+    `mask_in` / `mask_out` fold the reference's `conv(x * x_mask)` / `conv(...) * x_mask` into the kernel."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, m2, mask_out, dil):
+    def forward(ctx, x, v, g, bias, m2, mask_in, mask_out, dil):
         x = _dense(f32(x))
         B, cin, T = x.shape
         cout, _, taps = v.shape
@@ -124,10 +126,10 @@ class Conv1dFn(Function):
         wp_f, wp_b, inv = pack_weight(v, g)
         y = torch.empty(B, cout, T, device=x.device, dtype=torch.float32)
         b1 = None if bias is None else f32(bias.detach().contiguous())
-        conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_out=bool(mask_out))
-        ctx.save_for_backward(x, wp_b, inv, m2 if mask_out else None)
+        conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_in=bool(mask_in), mask_out=bool(mask_out))
+        ctx.save_for_backward(x, wp_b, inv, m2 if (mask_out or mask_in) else None)
         ctx.params = (v, g, bias)
-        ctx.cfg = (taps, dil, pad, bool(mask_out))
+        ctx.cfg = (taps, dil, pad, bool(mask_in), bool(mask_out))
         return y
 
     @staticmethod
@@ -135,18 +137,60 @@ class Conv1dFn(Function):
     def backward(ctx, dy):
         x, wp_b, inv, m2 = ctx.saved_tensors
         v, g, bias = ctx.params
-        taps, dil, pad, mask_out = ctx.cfg
+        taps, dil, pad, mask_in, mask_out = ctx.cfg
         dy = _dense(dy)
         B, cin, T = x.shape
         cout = dy.shape[1]
         sink = _GradSink([v, g, bias])
-        _weight_grads(x, dy, m2, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2), taps, dil, pad)
+        _weight_grads(x, dy, m2 if mask_out else None, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2),
+                      taps, dil, pad, m2_for_x=m2 if mask_in else None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
-            conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out)
+            conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out, mask_out=mask_in)
         dv, dg, db = sink.results()
-        return dx, dv, dg, db, None, None, None
+        return dx, dv, dg, db, None, None, None, None
+
+
+def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = None, mask_in: bool = False,
+           mask_out: bool = False) -> torch.Tensor:
+    """Run an nn.Conv1d (optionally weight-normed, 'same' padding) through the MFMA kernels."""
+    if hasattr(conv, "weight_v"):
+        v, g = conv.weight_v, conv.weight_g
+    else:
+        v, g = conv.weight, None
+    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0])
+
+
+class ChanLayerNormFn(Function):
+    """y = LayerNorm_over_channels(x + res) on (B, C, T) (reference layers.py:19-28 + the residual add before it)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x = f32(x.contiguous())
+        res = None if res is None else f32(res.contiguous())
+        B, C, T = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty(B, 2, T, device=x.device, dtype=torch.float32)
+        call("glowtts_chan_layernorm_fwd", ptr(x), ptr(res), ptr(gamma.detach().contiguous()), ptr(beta.detach().contiguous()),
+             ptr(y), ptr(stats), B, C, T, float(eps))
+        ctx.save_for_backward(x, res, stats)
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, res, stats = ctx.saved_tensors
+        gamma, beta = ctx.params
+        B, C, T = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        sink = _GradSink([gamma, beta])
+        call("glowtts_chan_layernorm_bwd", ptr(x), ptr(res), ptr(gamma.detach().contiguous()), ptr(stats), ptr(dy), ptr(dx),
+             ptr(sink.buf(0)), ptr(sink.buf(1)), B, C, T)
+        dg, db = sink.results()
+        return dx, (dx if res is not None else None), dg, db, None
 
 
 class WNPackPlan:

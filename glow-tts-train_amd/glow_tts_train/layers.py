@@ -29,10 +29,13 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x):
-        # F.layer_norm normalises trailing dims: move channels last, normalise, move back (same biased variance)
-        y = F.layer_norm(x.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps)
-        return y.transpose(1, -1)
+    def forward(self, x, res=None):
+        """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in)."""
+        if x.dim() == 3:
+            return convops.ChanLayerNormFn.apply(x, res, self.gamma, self.beta, self.eps)
+        # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
+        v = x if res is None else x + res
+        return F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
 
 
 class ConvReluNorm(nn.Module):
@@ -54,10 +57,11 @@ class ConvReluNorm(nn.Module):
         nn.init.zeros_(self.proj.bias)
 
     def forward(self, x, x_mask):
+        m2 = ops.mask2d(x_mask)
         h = x
         for conv, norm in zip(self.conv_layers, self.norm_layers):
-            h = self.relu_drop(norm(conv(h * x_mask)))
-        return (x + self.proj(h)) * x_mask
+            h = self.relu_drop(norm(convops.conv1d(conv, h, m2, mask_in=True)))      # conv(h * mask): mask folded in
+        return (x + convops.conv1d(self.proj, h)) * x_mask
 
 
 class WN(nn.Module):

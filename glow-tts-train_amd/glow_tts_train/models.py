@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import monotonic_align, ops
+from . import convops, monotonic_align, ops
 from .attentions import CouplingBlock, Encoder
 from .layers import ActNorm, ConvReluNorm, InvConvNear, LayerNorm
 from .optimize import OptimizerType
@@ -38,9 +38,10 @@ class DurationPredictor(nn.Module):
         self.proj = nn.Conv1d(filter_channels, 1, 1)
 
     def forward(self, x, x_mask):
+        m2 = ops.mask2d(x_mask)
         for conv, norm in ((self.conv_1, self.norm_1), (self.conv_2, self.norm_2)):
-            x = self.drop(norm(torch.relu(conv(x * x_mask))))
-        return self.proj(x * x_mask) * x_mask
+            x = self.drop(norm(torch.relu(convops.conv1d(conv, x, m2, mask_in=True))))
+        return convops.conv1d(self.proj, x, m2, mask_in=True, mask_out=True)
 
 
 class TextEncoder(nn.Module):
@@ -77,8 +78,9 @@ class TextEncoder(nn.Module):
         h_dp = h.detach()
         if g is not None:
             h_dp = torch.cat([h_dp, g.expand(-1, -1, h.size(-1))], 1)
-        x_m = self.proj_m(h) * x_mask
-        x_logs = torch.zeros_like(x_m) if self.mean_only else self.proj_s(h) * x_mask
+        m2 = ops.mask2d(x_mask)
+        x_m = convops.conv1d(self.proj_m, h, m2, mask_out=True)
+        x_logs = torch.zeros_like(x_m) if self.mean_only else convops.conv1d(self.proj_s, h, m2, mask_out=True)
         return x_m, x_logs, self.proj_w(h_dp, x_mask), x_mask
 
 

@@ -126,7 +126,8 @@ int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *m
  *                 pre, + cond[b, :] ; acts = tanh(pre[:H]) * sigmoid(pre[H:]) ; ts (B,2H,T) = the tanh / sigmoid values
  * conv_res_skip_fwd : WN res/skip 1x1 + update: rs = W acts + b ; x_out = (x_in + rs[:H]) * mask ; skip_out = skip_in + rs[H:]
  *                 last = 1: W is (H x H), skip_out = (skip_in + rs) * mask   (folds layers.py:162)
- * conv_wrw      : dwp[tap][k][m] += sum_{b,t} x[b,k,t + tap*dil - pad] * d[b,m,t] (* mask[b,t] if mask)   (accumulated)
+ * conv_wrw      : dwp[tap][k][m] += sum_{b,t} x[b,k,t'] (* mask_x[b,t'] if mask_x) * d[b,m,t] (* mask[b,t] if mask),
+ *                 t' = t + tap*dil - pad   (accumulated)
  *                 and, if dbias != NULL, dbias[m] += sum_{b,t} d[b,m,t] (* mask)  (the bias gradient, same pass)
  * unpack_weight_grad : packed gradient -> dv (+= , weight layout [Cout][Cin][taps]) and dg (+=) through the weight norm
  * rowsum        : out[m] += sum_{b,t} d[b,m,t] (* mask)                                  (bias gradients, accumulated)
@@ -140,8 +141,9 @@ int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, co
 int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
                               const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B, int H, int T,
                               int last, glowtts_stream_t stream);
-int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, float *dwp, float *dbias,
-                     int B, int Cin, int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
+int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, const float *mask_x,
+                     float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
+                     glowtts_stream_t stream);
 int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
                         int taps, glowtts_stream_t stream);
 int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g, const float *inv_norm, float *dv,
@@ -176,6 +178,15 @@ int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, cons
                          const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
                          float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
                          glowtts_stream_t stream);
+
+/* ---- channel LayerNorm with fused residual (csrc/norm.hip) -----------------------------------------------------
+ * replaces LayerNorm.forward (layers.py:19-28) and the `x + y` before it (attentions.py:68,72):
+ * fwd : v = x (+ res) ; y = gamma * (v - mean_c v) * rsqrt(var_c v + eps) + beta ; stats (B, 2, T) = mean, rstd (may be NULL)
+ * bwd : dx (= d res) written ; dgamma, dbeta accumulated */
+int glowtts_chan_layernorm_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *y,
+                               float *stats, int B, int C, int T, float eps, glowtts_stream_t stream);
+int glowtts_chan_layernorm_bwd(const float *x, const float *res, const float *gamma, const float *stats, const float *dy,
+                               float *dx, float *dgamma, float *dbeta, int B, int C, int T, glowtts_stream_t stream);
 
 /* ---- squeeze / unsqueeze (utils.py:135-160) -----------------------------------------------------------------
  * squeeze  : x (B,C,T) -> xs (B, n*C, T/n): xs[b, s*C+c, t'] = x[b,c,n*t'+s] * mask[b, n*t'+n-1] ; ms[b,t'] = mask[b, n*t'+n-1]

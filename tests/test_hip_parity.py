@@ -558,7 +558,7 @@ def test_conv1d_fn_vs_torch(G, b, cin, cout, t, k, dil, mask_out, slice_in):
         xf = full.cuda().requires_grad_(True)
         vv, bb = v.cuda().requires_grad_(True), bias.cuda().requires_grad_(True)
         gg = g.cuda().requires_grad_(True) if use_g else None
-        y = convops.Conv1dFn.apply(xf[:, :cin], vv, gg, bb, mask.cuda(), mask_out, dil)
+        y = convops.Conv1dFn.apply(xf[:, :cin], vv, gg, bb, mask.cuda(), False, mask_out, dil)
         (y * r.cuda()).sum().backward()
         assert_close(y, y0, what="y", rtol=1e-4, atol=1e-4)
         assert_close(xf.grad, dx0, what="dx", rtol=1e-4, atol=1e-4)
@@ -577,10 +577,10 @@ def test_conv_grads_accumulate_in_place_when_grad_exists(G):
     v = torch.randn(12, 8, 3, device="cuda", requires_grad=True)
     bias = torch.zeros(12, device="cuda", requires_grad=True)
     m = torch.ones(2, 40, device="cuda")
-    convops.Conv1dFn.apply(x, v, None, bias, m, False, 1).sum().backward()
+    convops.Conv1dFn.apply(x, v, None, bias, m, False, False, 1).sum().backward()
     gv, gb = v.grad.clone(), bias.grad.clone()
     before = v.grad.data_ptr()
-    convops.Conv1dFn.apply(x, v, None, bias, m, False, 1).sum().backward()       # second backward: in place, 2x
+    convops.Conv1dFn.apply(x, v, None, bias, m, False, False, 1).sum().backward()       # second backward: in place, 2x
     assert v.grad.data_ptr() == before
     assert_close(v.grad, 2 * gv, rtol=1e-5, atol=1e-5)
     assert_close(bias.grad, 2 * gb, rtol=1e-5, atol=1e-5)
@@ -684,3 +684,30 @@ def test_attention_kernel_vs_general_path(G, t, ch, win, blk):
     assert_close(p1, p2, what="p_attn", rtol=1e-4, atol=1e-5)
     for a, e, n in zip(g1, g2, ("dx", "demb_k", "demb_v")):
         assert_close(a, e, what=n, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("b,c,t,with_res", [(3, 192, 160, True), (2, 32, 37, False), (1, 5, 70, True)])
+def test_chan_layernorm_vs_torch(G, b, c, t, with_res):
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(c)
+    ln = G.layers.LayerNorm(c).cuda()
+    with torch.no_grad():
+        ln.gamma.copy_(torch.rand(c) + 0.5)
+        ln.beta.copy_(torch.randn(c) * 0.1)
+    x = (torch.randn(b, c, t) * 2 + 0.3).cuda().requires_grad_(True)
+    res = torch.randn(b, c, t).cuda().requires_grad_(True) if with_res else None
+    r = torch.randn(b, c, t).cuda()
+    y = ln(x, res=res)
+    (y * r).sum().backward()
+    xo = x.detach().cpu().requires_grad_(True)
+    ro = res.detach().cpu().requires_grad_(True) if with_res else None
+    go, bo = ln.gamma.detach().cpu().requires_grad_(True), ln.beta.detach().cpu().requires_grad_(True)
+    yo = O.channel_layer_norm(xo + ro if with_res else xo, go, bo)
+    (yo * r.cpu()).sum().backward()
+    assert_close(y, yo, what="y", rtol=1e-4, atol=1e-5)
+    assert_close(x.grad, xo.grad, what="dx", rtol=1e-4, atol=2e-5)
+    if with_res:
+        assert_close(res.grad, ro.grad, what="dres", rtol=1e-4, atol=2e-5)
+    assert_close(ln.gamma.grad, go.grad, what="dgamma", rtol=2e-4, atol=2e-4)
+    assert_close(ln.beta.grad, bo.grad, what="dbeta", rtol=2e-4, atol=2e-4)

@@ -55,11 +55,11 @@ def bwd_data1():
 
 
 def wrw5():
-    call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, ptr(dwp5), None, B, H, 2 * H, T, 5, 1, 2)
+    call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp5), None, B, H, 2 * H, T, 5, 1, 2)
 
 
 def wrw1():
-    call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, ptr(dwp1), None, B, H, 2 * H, T, 1, 1, 0)
+    call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp1), None, B, H, 2 * H, T, 1, 1, 0)
 
 
 def start():
