@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     return ap.parse_args()
 
 
@@ -125,7 +126,7 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://")
 
     from glow_tts_train import _hip, config, models, parallel
-    from glow_tts_train.train import train_batch
+    from glow_tts_train.train import GraphedTrainStep, train_batch
 
     _hip.load()
     B, T_mel = args.batch, args.t_mel
@@ -162,8 +163,20 @@ def main():
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
+    # single GPU: the step is captured into a hipGraph (hand-written + library kernels alike) and replayed; with a
+    # process group the collectives stay outside a graph and the step is launched eagerly
+    step_fn = lambda: train_batch(model, opt, batch, cfg.grad_clip, reducer)      # noqa: E731
+    mode = "eager"
+    if world == 1 and not args.no_graph:
+        try:
+            graphed = GraphedTrainStep(model, opt, cfg.grad_clip, batch, warmup=2)
+            step_fn = lambda: graphed()                                            # noqa: E731
+            mode = "hipgraph"
+        except Exception as exc:                                                   # capture unsupported: say so, run eagerly
+            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+    log(f"step mode: {mode}")
     for i in range(args.warmup):
-        train_batch(model, opt, batch, cfg.grad_clip, reducer)
+        step_fn()
         torch.cuda.synchronize()
         log(f"warm-up step {i + 1}/{args.warmup} done")
 
@@ -177,7 +190,7 @@ def main():
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
-        loss = train_batch(model, opt, batch, cfg.grad_clip, reducer)
+        loss = step_fn()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -196,7 +209,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: full training step, per-GPU B={B}, T_text={T_text}, T_mel={T_mel}, "
                                f"80 mels, {args.blocks} flow blocks, n_split=4, n_sqz=2, H=192, fp32, dropout 0.1/0.05, "
                                "random-init weights, synthetic resident batch",
-                   "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": loss_val},
+                   "global_batch": world * B, "parallelism": f"dp{world}", "launch": mode, "final_loss": loss_val},
     }
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region

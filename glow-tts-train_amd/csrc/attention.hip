@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
         float sv[15], sk[15];
 #pragma unroll
         for (int r = 0; r < 15; ++r) { sv[r] = 0.f; sk[r] = 0.f; }
+#pragma unroll 4
         for (int i = lane; i < T; i += 64) {
             const float ov = orow[i], qv = qrow[i];
 #pragma unroll
@@ -459,9 +460,13 @@ static int attn_launch(AttnParams &p, hipStream_t s) {
     p.TP = ((p.T + 15) / 16) * 16 + 4;
     const size_t lds = attn_lds(p.dk, p.TP);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("glowtts_rel_attn: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error("glowtts_rel_attn: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
     dim3 grid((p.T + 63) / 64, p.H, p.B);
     hipLaunchKernelGGL((attn_qblock_kernel<MODE>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
@@ -507,9 +512,13 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
     d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
     const size_t lds = ((size_t)2 * dk * kBP + (size_t)2 * 64 * kAP) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_dkv_kernel),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_dkv_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
     hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
     if (emb_k) {
         const size_t lds_r = (size_t)2 * (2 * window + 1) * T * sizeof(float);

@@ -858,9 +858,13 @@ static int launch_convgemm(ConvGemmParams &p, hipStream_t s) {
     p.xp_pitch = pitch16(NT + (p.taps - 1) * p.dil);
     const size_t lds = ((size_t)p.taps * 16 * (WGR + 16) + (size_t)16 * p.xp_pitch) * sizeof(float);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_conv: %d taps x dilation %d needs %zu B of LDS", p.taps, p.dil, lds);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kernel<RTW, NCT, EPI>),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kernel<RTW, NCT, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
@@ -878,9 +882,13 @@ static int launch_convgemm_kp(ConvGemmParams &p, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
@@ -915,9 +923,13 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
 template <int TAPS, int CT>
 static int launch_wrw_pipe(ConvWrwParams &p, hipStream_t s) {
     constexpr size_t lds = 2 * ((size_t)64 * cpitch2(CT + 16) + (size_t)64 * cpitch2(CT)) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_pipe_kernel<TAPS, CT>),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_pipe_kernel<TAPS, CT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);
     int splits = (640 + tiles - 1) / tiles;
     if (splits > p.B) splits = p.B;

@@ -181,11 +181,15 @@ static int launch_mas(const float *value, float *path, const int32_t *t_x, const
     const size_t bytes = fixed + (size_t)2 * (1 << log2tc) * (R * 64 + 1) * 4;
     GLOWTTS_CHECK_ARG(bytes <= 160 * 1024, "glowtts_mas_path: lattice %dx%d needs %zu B of LDS (> 160 KiB)", Tx, Ty,
                       bytes);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mas_kernel<R>),
+    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    if ((size_t)bytes > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mas_kernel<R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) {
+        if (e != hipSuccess) {
         set_error("glowtts_mas_path: cannot reserve %zu B LDS: %s", bytes, hipGetErrorString(e));
         return (int)e;
+    }
+        attr_max_e = (size_t)bytes;
     }
     hipLaunchKernelGGL(mas_kernel<R>, dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
                        nblk32);

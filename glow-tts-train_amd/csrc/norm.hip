@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float *__
     const bool ok = t < T;
     const long base = (long)b * C * T + t;
     float a = 0.f;
+#pragma unroll 8
     for (int c = wave; c < C; c += 4) {
         float v = 0.f;
         if (ok) { v = x[base + (long)c * T]; if (res) v += res[base + (long)c * T]; }
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float *__
     __syncthreads();
     const float mean = (s1[0][lane] + s1[1][lane] + s1[2][lane] + s1[3][lane]) / C;
     float q = 0.f;                               // two-pass variance, as the reference: mean((v - mean)^2)
+#pragma unroll 8
     for (int c = wave; c < C; c += 4) {
         float v = 0.f;
         if (ok) { v = x[base + (long)c * T]; if (res) v += res[base + (long)c * T]; }
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float *__
         stats[((long)b * 2 + 0) * T + t] = mean;
         stats[((long)b * 2 + 1) * T + t] = rstd;
     }
+#pragma unroll 8
     for (int c = wave; c < C; c += 4) {
         if (ok) {
             float v = x[base + (long)c * T];
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float *__
     const float mean = ok ? stats[((long)b * 2 + 0) * T + t] : 0.f;
     const float rstd = ok ? stats[((long)b * 2 + 1) * T + t] : 0.f;
     float a = 0.f, q = 0.f;
+#pragma unroll 8
     for (int c = wave; c < C; c += 4) {
         if (ok) {
             float v = x[base + (long)c * T];
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float *__
     __syncthreads();
     const float mg = (s1[0][lane] + s1[1][lane] + s1[2][lane] + s1[3][lane]) / C;
     const float mgx = (s2[0][lane] + s2[1][lane] + s2[2][lane] + s2[3][lane]) / C;
+#pragma unroll 4
     for (int c = wave; c < C; c += 4) {
         float dg = 0.f, db = 0.f;
         if (ok) {

@@ -711,3 +711,36 @@ def test_chan_layernorm_vs_torch(G, b, c, t, with_res):
         assert_close(res.grad, ro.grad, what="dres", rtol=1e-4, atol=2e-5)
     assert_close(ln.gamma.grad, go.grad, what="dgamma", rtol=2e-4, atol=2e-4)
     assert_close(ln.beta.grad, bo.grad, what="dbeta", rtol=2e-4, atol=2e-4)
+
+
+def test_graphed_train_step_matches_eager(G):
+    """hipGraph replay of the whole step == eager launches (same kernels, same order, same on-device schedule)."""
+    from glow_tts_train.train import GraphedTrainStep, train_batch
+    from oracle import glow_oracle as O
+
+    hp = O.HParams(n_vocab=40, hidden_channels=32, filter_channels=64, filter_channels_dp=32, n_layers_enc=1,
+                   n_blocks_dec=2, n_block_layers=2)
+    torch.manual_seed(3)
+    b, tx, ty = 2, 8, 32
+    x = torch.randint(1, 40, (b, tx)).cuda()
+    xl = torch.tensor([8, 5]).cuda()
+    y = torch.randn(b, 80, ty).cuda()
+    yl = torch.tensor([32, 20]).cuda()
+    batch = (x, xl, y, yl, None)
+    losses = {}
+    finals = {}
+    for mode in ("eager", "graph"):
+        sd, model = _oracle_pair(G, hp, seed=9)
+        opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=32, warmup_steps=4000, lr=1.0)
+        if mode == "eager":
+            ls = [float(train_batch(model, opt, batch, 5.0)) for _ in range(5)]
+        else:
+            g = GraphedTrainStep(model, opt, 5.0, batch, warmup=2)        # 2 warm-up steps are real optimisation steps
+            ls = [None, None] + [float(g()) for _ in range(3)]
+        losses[mode] = ls
+        finals[mode] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        assert opt.step_num == 6 and float(opt._optim.dev_state[1]) == 6.0
+    for a, e in zip(losses["graph"][2:], losses["eager"][2:]):
+        assert abs(a - e) <= 2e-4 * abs(e), (losses)
+    worst = max(rel_err(finals["graph"][k], finals["eager"][k]) for k in finals["eager"])
+    assert worst < 1e-3, worst
