@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, = fp32 vector peak
 
 
 def parse():
@@ -216,6 +217,8 @@ def main():
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if rank == 0 and not args.no_roofline:
+        import re
+
         C = cfg.audio.mel_channels * cfg.model.n_sqz
         H = cfg.model.hidden_channels_dec
         Ts = T_mel // cfg.model.n_sqz
@@ -226,28 +229,42 @@ def main():
             train_batch(model, opt, batch, cfg.grad_clip, None)
         times = _hip.disable_timing()
         log("instrumented pass done")
-        table = {}
+        hbm, mfma = {}, {}
         for name, ms in times.items():
-            if name not in alg:
-                continue
             mean_ms = sum(ms) / len(ms)
-            table[name] = {"launches_per_step": len(ms) // n_inst, "mean_us": 1e3 * mean_ms,
-                           "total_ms_per_step": sum(ms) / n_inst, "alg_MB": alg[name] / 1e6,
-                           "GBps": alg[name] / (mean_ms * 1e-3) / 1e9}
-        dom = max(table, key=lambda k: table[k]["total_ms_per_step"])
-        sub_ms = sum(table[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in table)
-        sub_bytes = sum(alg[k] * table[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in table)
-        hip_ms = sum(v["total_ms_per_step"] for v in table.values())
-        out["roofline"] = {
-            "bound": "hbm", "kernel": dom, "achieved": table[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": table[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
-            "invertible_subset": {"ms_per_step": sub_ms, "alg_GB": sub_bytes / 1e9,
-                                  "GBps": sub_bytes / (sub_ms * 1e-3) / 1e9 if sub_ms else None,
-                                  "frac": sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sub_ms else None},
-            "hip_kernels_ms_per_step": hip_ms, "step_ms": ms_per_step,
-            "kernels": {k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                        for k, v in sorted(table.items())},
-        }
+            row = {"launches_per_step": len(ms) // n_inst, "mean_us": round(1e3 * mean_ms, 2),
+                   "total_ms_per_step": round(sum(ms) / n_inst, 3)}
+            m = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", name)
+            if m:       # dense contraction on the fp32 MFMA: algorithmic FLOPs = 2 * M * K * taps * columns
+                flops = 2.0 * int(m.group(2)) * int(m.group(3)) * int(m.group(4)) * int(m.group(5)) * int(m.group(6))
+                row.update(alg_GFLOP=round(flops / 1e9, 3), TFLOPs=round(flops / (mean_ms * 1e-3) / 1e12, 2))
+                mfma[name] = row
+            elif name in alg:
+                row.update(alg_MB=round(alg[name] / 1e6, 3), GBps=round(alg[name] / (mean_ms * 1e-3) / 1e9, 1))
+                hbm[name] = row
+        sub_ms = sum(hbm[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
+        sub_bytes = sum(alg[k] * hbm[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
+        dom = max(mfma, key=lambda k: mfma[k]["total_ms_per_step"]) if mfma else None
+        conv_ms = sum(v["total_ms_per_step"] for v in mfma.values())
+        conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
+        if dom is not None:
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+        else:
+            dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": hbm[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
+        out["roofline"].update({
+            "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
+                                  "TFLOPs": round(conv_flop / conv_ms, 2) if conv_ms else None,
+                                  "frac": round(conv_flop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None},
+            "invertible_subset": {"ms_per_step": round(sub_ms, 3), "alg_GB": round(sub_bytes / 1e9, 3),
+                                  "GBps": round(sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
+                                  "frac": round(sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sub_ms else None},
+            "step_ms": round(ms_per_step, 3),
+            "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
+            "hbm_kernels": dict(sorted(hbm.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
+        })
 
     # ---- CPU baseline leg: the oracle (a port of the reference path) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

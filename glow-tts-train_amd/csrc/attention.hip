@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
 }
 
 // embedding gradients: dE[r][d] += sum_i M[i][i + r - w] * A[d][i]   (M, A) = (Pd, dO) -> dE_v ; (dS, Q) -> dE_k
-// workgroup = one (utterance, head): the 2w+1 diagonals of Pd and dS are gathered into LDS once; then each wave takes
-// rows d, lanes walk the queries (coalesced reads of dO[d][:] / Q[d][:]) and a wave reduction finishes each (r, d).
+// workgroup = one (utterance, head): the 2w+1 diagonals of Pd / dS and the dO / Q rows of the head are staged in LDS
+// once (coalesced, 8 loads in flight per thread); then thread = one (r, d) output walks the queries out of LDS.
 __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restrict__ p, const float *__restrict__ ds,
                                                            const unsigned char *__restrict__ drop, float drop_scale,
                                                            const float *__restrict__ dout, const float *__restrict__ q,
@@ -392,8 +392,11 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
                                                            int dk, int w, int e_hs) {
     extern __shared__ __align__(16) float smem[];
     const int nr = 2 * w + 1;
-    float *dp_ = smem;              // [nr][T]  Pd[i][i+r-w]
-    float *dd_ = smem + nr * T;     // [nr][T]  dS[i][i+r-w]
+    const int TP = T + 1;               // odd pitch: threads of one wave read different rows at the same column
+    float *dp_ = smem;                  // [nr][T]   Pd[i][i+r-w]
+    float *dd_ = dp_ + nr * T;          // [nr][T]   dS[i][i+r-w]
+    float *os_ = dd_ + nr * T;          // [dk][TP]  dO rows
+    float *qs_ = os_ + dk * TP;         // [dk][TP]  Q rows
     const int h = blockIdx.x % H, b = blockIdx.x / H;
     const long cbase = ((long)b * H + h) * dk;
     const long pbase = ((long)b * H + h) * T * T;
@@ -410,35 +413,36 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
         dp_[idx] = pv;
         dd_[idx] = dv;
     }
+    const int total = dk * T;
+    for (int base = 0; base < total; base += 256 * 8) {
+        float vo[8], vq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            vo[u] = idx < total ? dout[cbase * T + idx] : 0.f;
+            vq[u] = idx < total ? q[cbase * T + idx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + threadIdx.x;
+            if (idx < total) {
+                const int d = idx / T, i = idx - d * T;
+                os_[d * TP + i] = vo[u];
+                qs_[d * TP + i] = vq[u];
+            }
+        }
+    }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int d = wave; d < dk; d += 4) {
-        const float *orow = dout + (cbase + d) * T;
-        const float *qrow = q + (cbase + d) * T;
-        float sv[15], sk[15];
-#pragma unroll
-        for (int r = 0; r < 15; ++r) { sv[r] = 0.f; sk[r] = 0.f; }
+    for (int idx = threadIdx.x; idx < nr * dk; idx += 256) {
+        const int r = idx / dk, d = idx - r * dk;
+        float sv = 0.f, sk = 0.f;
 #pragma unroll 4
-        for (int i = lane; i < T; i += 64) {
-            const float ov = orow[i], qv = qrow[i];
-#pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                if (r < nr) {
-                    sv[r] += dp_[r * T + i] * ov;
-                    sk[r] += dd_[r * T + i] * qv;
-                }
-            }
+        for (int i = 0; i < T; ++i) {
+            sv += dp_[r * T + i] * os_[d * TP + i];
+            sk += dd_[r * T + i] * qs_[d * TP + i];
         }
-#pragma unroll
-        for (int r = 0; r < 15; ++r) {
-            if (r < nr) {
-                const float a = wave_sum(sv[r]), c = wave_sum(sk[r]);
-                if (lane == 0) {
-                    atomicAdd(dev + (long)h * e_hs + r * dk + d, a);
-                    atomicAdd(dek + (long)h * e_hs + r * dk + d, c);
-                }
-            }
-        }
+        atomicAdd(dev + (long)h * e_hs + idx, sv);
+        atomicAdd(dek + (long)h * e_hs + idx, sk);
     }
 }
 
@@ -521,7 +525,14 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     }
     hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
     if (emb_k) {
-        const size_t lds_r = (size_t)2 * (2 * window + 1) * T * sizeof(float);
+        const size_t lds_r = ((size_t)2 * (2 * window + 1) * T + (size_t)2 * dk * (T + 1)) * sizeof(float);
+        static size_t attr_max_r = 0;
+        if (lds_r > attr_max_r) {
+            hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_relgrad_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+            if (er != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(er)); return (int)er; }
+            attr_max_r = lds_r;
+        }
         hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H), dim3(256), lds_r, s, p_attn, ds, drop, drop_scale, dout, q, demb_k,
                            demb_v, H, T, dk, window, p.e_hs);
     }

@@ -134,8 +134,9 @@ def disable_timing() -> dict:
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in t.items()}
 
 
-def call(name: str, *args) -> None:
-    """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure."""
+def call(name: str, *args, tag: Optional[str] = None) -> None:
+    """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure.
+    `tag` only labels the launch for the optional timing table (e.g. the GEMM shape of a conv launch)."""
     lib = load()
     cur = torch.cuda.current_stream()
     if _timing is not None:
@@ -143,7 +144,7 @@ def call(name: str, *args) -> None:
         a.record(cur)
         rc = getattr(lib, name)(*args, cur.cuda_stream)
         b.record(cur)
-        _timing.setdefault(name, []).append((a, b))
+        _timing.setdefault(name if tag is None else f"{name}[{tag}]", []).append((a, b))
     else:
         rc = getattr(lib, name)(*args, cur.cuda_stream)
     if rc != 0:
