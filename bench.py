@@ -71,6 +71,7 @@ def algorithmic_bytes(B, C, H, Ts, T_text, n_params_padded):
         "glowtts_coupling_bwd": 4 * X,          # reads x1, logs (0.5 X each) + dz (X); writes dx, dout (X each)
         "glowtts_gate_fwd": 3 * Hb,
         "glowtts_gate_bwd": 5 * Hb,
+        "glowtts_gate_bwd_ts": 5 * Hb,           # reads tanh/sigmoid (2 Hb) + dacts (Hb), writes d(pre-activation) (2 Hb)
         "glowtts_res_skip_fwd": 5.25 * Hb,       # 3 x (5..6 Hb) non-last + 1 x 3 Hb last, mean over the 4 layers
         "glowtts_res_skip_bwd": 3.5 * Hb,        # 3 x 4 Hb + 1 x 2 Hb
         "glowtts_squeeze": 2 * X,
