@@ -67,6 +67,8 @@ def algorithmic_bytes(B, C, H, Ts, T_text, n_params_padded):
         "glowtts_actnorm_bwd": 3 * X,
         "glowtts_invconv_fwd": 2 * X,
         "glowtts_invconv_bwd": 3 * X,
+        "glowtts_actnorm_invconv_fwd": 2 * X,   # the two elementwise flows of a block in one pass
+        "glowtts_actnorm_invconv_bwd": 3 * X,
         "glowtts_coupling_fwd": 3 * X,
         "glowtts_coupling_bwd": 4 * X,          # reads x1, logs (0.5 X each) + dz (X); writes dx, dout (X each)
         "glowtts_gate_fwd": 3 * Hb,
@@ -85,7 +87,8 @@ def algorithmic_bytes(B, C, H, Ts, T_text, n_params_padded):
 
 
 INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invconv_fwd", "glowtts_invconv_bwd",
-                     "glowtts_coupling_fwd", "glowtts_coupling_bwd")
+                     "glowtts_actnorm_invconv_fwd", "glowtts_actnorm_invconv_bwd", "glowtts_coupling_fwd",
+                     "glowtts_coupling_bwd")
 
 
 _T0 = time.perf_counter()
@@ -245,6 +248,7 @@ def main():
                 hbm[name] = row
         sub_ms = sum(hbm[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
         sub_bytes = sum(alg[k] * hbm[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
+        survey_gb = 3 * 6.5 * C * 4 * B * Ts * cfg.model.n_blocks_dec / 1e9
         dom = max(mfma, key=lambda k: mfma[k]["total_ms_per_step"]) if mfma else None
         conv_ms = sum(v["total_ms_per_step"] for v in mfma.values())
         conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
@@ -261,7 +265,11 @@ def main():
                                   "frac": round(conv_flop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None},
             "invertible_subset": {"ms_per_step": round(sub_ms, 3), "alg_GB": round(sub_bytes / 1e9, 3),
                                   "GBps": round(sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
-                                  "frac": round(sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sub_ms else None},
+                                  "frac": round(sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sub_ms else None,
+                                  # the un-fused per-flow byte count (6.5 C e per column per block,
+                                  # x3 for fwd+bwd) over the measured subset time -- fusing flows lowers the time only
+                                  "survey_alg_GB": round(survey_gb, 3),
+                                  "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None},
             "step_ms": round(ms_per_step, 3),
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "hbm_kernels": dict(sorted(hbm.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),

@@ -585,12 +585,11 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
     const int lrow = lane & 15, lk = lane >> 4;
     const int nkt = (p.Cin + 63) / 64;
     const int kt = blockIdx.x % nkt, mt = blockIdx.x / nkt;
-    const int b0 = blockIdx.z * p.nb;
-    const int b1 = min(p.B, b0 + p.nb);
     const int k0 = kt * 64, m0 = mt * 64;
     const int off = (4 - (p.pad & 3)) & 3;
     const int nct = (p.T + CT - 1) / CT;             // chunks per utterance
-    const int nchunks = (b1 - b0) * nct;
+    const int c0 = blockIdx.z * p.nb;                // this workgroup's range of the B * nct (utterance, chunk) pairs
+    const int nchunks = min(p.B * nct, c0 + p.nb) - c0;
 
     f32x4 acc[TAPS][4];
 #pragma unroll
@@ -604,8 +603,8 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
     const bool do_bias = (p.dbias != nullptr) && (kt == 0);
 
     auto load_chunk = [&](int c) {
-        const int b = b0 + c / nct;
-        const int tc = (c % nct) * CT;
+        const int b = (c0 + c) / nct;
+        const int tc = ((c0 + c) % nct) * CT;
         const int ts = tc - p.pad - off;
         const float *xb = p.x + (long)b * p.x_bs;
         const float *db = p.d + (long)b * p.d_bs;
@@ -930,12 +929,15 @@ static int launch_wrw_pipe(ConvWrwParams &p, hipStream_t s) {
         if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_max_e = (size_t)lds;
     }
+    // The contraction runs over B * T frames = `total` chunks of CT; it is split so that ALL workgroups are resident at
+    // once (2 per CU by LDS, 512 slots): a grid of 576 on 512 slots costs two full rounds.  p.nb = chunks per workgroup.
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);
-    int splits = (640 + tiles - 1) / tiles;
-    if (splits > p.B) splits = p.B;
+    const int total = p.B * ((p.T + CT - 1) / CT);
+    int splits = 512 / tiles;
+    if (splits > total) splits = total;
     if (splits < 1) splits = 1;
-    p.nb = (p.B + splits - 1) / splits;
-    dim3 grid(tiles, 1, (p.B + p.nb - 1) / p.nb);
+    p.nb = (total + splits - 1) / splits;
+    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
     hipLaunchKernelGGL((convwrw_pipe_kernel<TAPS, CT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
 }

@@ -292,6 +292,161 @@ __global__ __launch_bounds__(256) void invconv_bwd_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// ActNorm + InvConvNear fused (consecutive flows 3i, 3i+1 of every block, models.py:176-179): one pass over the tensor
+//   fwd : y = (bias + exp(logs) x) mask ; z = (W y) mask ; logdet[b] = (sum(logs) + logdet_w * C/n) * x_len[b]
+//   bwd : gz = dz mask ; dy = W^T gz ; dW += gz y^T ; dym = dy mask ; dx = dym exp(logs) ; dlogs += dym exp(logs) x ;
+//         dbias += dym   (+ the log-det terms)                                      traffic: fwd 2X, bwd 3X  (was 4X / 6X)
+// ------------------------------------------------------------------------------------------------------------
+template <int N, int V>
+__global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                                  const float *__restrict__ logs, const float *__restrict__ bias,
+                                                                  const float *__restrict__ w, const float *__restrict__ logdet_w,
+                                                                  const float *__restrict__ x_len, float *__restrict__ z,
+                                                                  float *__restrict__ logdet, int B, int C, int T) {
+    __shared__ float red[4];
+    const int TV = T / V;
+    const int G = C / N;
+    const long n = (long)B * G * TV;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int tv = (int)(i % TV);
+        const long bg = i / TV;
+        const int g = (int)(bg % G);
+        const int b = (int)(bg / G);
+        float wr[N * N];
+#pragma unroll
+        for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> y[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int ch = invconv_channel<N>(k, g, C);
+            const float e = expf(logs[ch]), bi = bias[ch];
+            Vec<V> xv = Vec<V>::load(x + ((long)b * C + ch) * T + (long)tv * V);
+#pragma unroll
+            for (int j = 0; j < V; ++j) y[k][j] = (bi + e * xv[j]) * mv[j];
+        }
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            Vec<V> acc;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s += wr[o * N + k] * y[k][j];
+                acc[j] = s * mv[j];
+            }
+            acc.store(z + ((long)b * C + invconv_channel<N>(o, g, C)) * T + (long)tv * V);
+        }
+    }
+    if (logdet != nullptr && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += logs[c];
+        s = block_sum_256(s, red);
+        const float ld = s + logdet_w[0] * (float)(C / N);
+        for (int b = threadIdx.x; b < B; b += 256) logdet[b] = ld * x_len[b];
+    }
+}
+
+// grid (G, slabs): every thread of a workgroup works on the same channel group, so the 2N per-channel sums and the N*N
+// matrix sums reduce inside the workgroup and leave as one atomic each.
+template <int N, int V>
+__global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                                  const float *__restrict__ logs, const float *__restrict__ bias,
+                                                                  const float *__restrict__ w, const float *__restrict__ w_inv,
+                                                                  const float *__restrict__ dz, const float *__restrict__ dlogdet,
+                                                                  const float *__restrict__ x_len, float *__restrict__ dx,
+                                                                  float *__restrict__ dlogs, float *__restrict__ dbias,
+                                                                  float *__restrict__ dw, int B, int C, int T, int nb) {
+    const int TV = T / V;
+    const int g = blockIdx.x;
+    const int b0 = blockIdx.y * nb, b1 = min(B, b0 + nb);
+    float wr[N * N], e[N], bi[N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int ch = invconv_channel<N>(k, g, C);
+        e[k] = expf(logs[ch]);
+        bi[k] = bias[ch];
+    }
+    float aw[N * N], al[N], ab[N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) aw[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { al[k] = 0.f; ab[k] = 0.f; }
+    const int items = (b1 - b0) * TV;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int b = b0 + it / TV, tv = it % TV;
+        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> xv[N], gz[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const long off = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
+            xv[k] = Vec<V>::load(x + off);
+            gz[k] = Vec<V>::load(dz + off);
+#pragma unroll
+            for (int j = 0; j < V; ++j) gz[k][j] *= mv[j];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            Vec<V> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float yk = (bi[k] + e[k] * xv[k][j]) * mv[j];
+                float dy = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < N; ++oo) {
+                    dy += wr[oo * N + k] * gz[oo][j];
+                    aw[oo * N + k] += gz[oo][j] * yk;
+                }
+                const float dym = dy * mv[j];
+                o[j] = dym * e[k];
+                al[k] += dym * e[k] * xv[k][j];
+                ab[k] += dym;
+            }
+            o.store(dx + ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V);
+        }
+    }
+    // one LDS round for all 2N + N*N sums, then ONE atomic instruction per output cache line: same-line float atomics
+    // retire serially in L2 (~13 ns each), so a workgroup must not send them one by one
+    constexpr int NS = 2 * N + N * N;
+    __shared__ float part[4][NS + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float t = 0.f;                                  // sum_b dlogdet[b] * x_len[b]: feeds dlogs (every channel) and dW
+    if (dlogdet != nullptr && wave == 0)
+        for (int b = lane; b < B; b += 64) t += dlogdet[b] * x_len[b];
+    t = wave_sum(t);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float sl = wave_sum(al[k]), sb = wave_sum(ab[k]);
+        if (lane == 0) { part[wave][k] = sl; part[wave][N + k] = sb; }
+    }
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) {
+        const float sw = wave_sum(aw[q]);
+        if (lane == 0) part[wave][2 * N + q] = sw;
+    }
+    if (threadIdx.x == 0) part[0][NS] = t;
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        const int q = threadIdx.x;
+        float v = part[0][q] + part[1][q] + part[2][q] + part[3][q];
+        const float tt = part[0][NS];
+        if (q < N) {
+            if (blockIdx.y == 0) v += tt;
+            atomicAdd(dlogs + invconv_channel<N>(q, g, C), v);
+        } else if (q < 2 * N) {
+            atomicAdd(dbias + invconv_channel<N>(q - N, g, C), v);
+        } else {
+            const int r = q - 2 * N;
+            if (g == 0 && blockIdx.y == 0 && dlogdet != nullptr) v += w_inv[(r % N) * N + r / N] * (float)(C / N) * tt;
+            atomicAdd(dw + r, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // affine coupling apply
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float coupling_logs(float raw, bool sig) {
@@ -519,7 +674,8 @@ extern "C" int glowtts_coupling_fwd(const float *x, const float *out, const floa
     const bool v4 = can_vec4(T, {x, out, mask, z});
     const long items = (long)(C / 2) * (v4 ? T / 4 : T);
     int gx = cdiv(items, 256);
-    if (gx > 64) gx = 64;
+    const int gmax = reverse ? 64 : 16;          // forward: one logdet[b] atomic per workgroup, same cache line for 16 b
+    if (gx > gmax) gx = gmax;
     dim3 grid(gx, B);
     if (reverse) {
         if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, true>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
@@ -546,4 +702,52 @@ extern "C" int glowtts_coupling_bwd(const float *x, const float *out, const floa
     if (v4) hipLaunchKernelGGL((coupling_bwd_kernel<4>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
     else    hipLaunchKernelGGL((coupling_bwd_kernel<1>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
     GLOWTTS_LAUNCH_CHECK("glowtts_coupling_bwd");
+}
+
+#define FUSED_DISPATCH(KERNEL, GRID, ...)                                                               \
+    do {                                                                                                \
+        if (n_split == 4) {                                                                             \
+            if (v4) hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+            else    hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+        } else {                                                                                        \
+            if (v4) hipLaunchKernelGGL((KERNEL<2, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+            else    hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+        }                                                                                               \
+    } while (0)
+
+extern "C" int glowtts_actnorm_invconv_fwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                           const float *w, const float *logdet_w, const float *x_len, float *z,
+                                           float *logdet, int B, int C, int T, int n_split, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && logs && bias && w && z, "glowtts_actnorm_invconv_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_actnorm_invconv_fwd: n_split=%d (fused path: 2 or 4)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_actnorm_invconv_fwd: bad shape");
+    GLOWTTS_CHECK_ARG(!logdet || (logdet_w && x_len), "glowtts_actnorm_invconv_fwd: logdet requested without logdet_w/x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, mask, z});
+    const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
+    dim3 grid(cdiv(n, 256));
+    FUSED_DISPATCH(actnorm_invconv_fwd_kernel, grid, x, mask, logs, bias, w, logdet_w, x_len, z, logdet, B, C, T);
+    GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_invconv_fwd");
+}
+
+extern "C" int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                           const float *w, const float *w_inv, const float *dz, const float *dlogdet,
+                                           const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B,
+                                           int C, int T, int n_split, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && mask && logs && bias && w && dz && dx && dlogs && dbias && dw, "glowtts_actnorm_invconv_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_actnorm_invconv_bwd: n_split=%d (fused path: 2 or 4)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_actnorm_invconv_bwd: bad shape");
+    GLOWTTS_CHECK_ARG(!dlogdet || (w_inv && x_len), "glowtts_actnorm_invconv_bwd: dlogdet given without w_inv/x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {x, mask, dz, dx});
+    const int G = C / n_split;
+    int slabs = (640 + G - 1) / G;
+    if (slabs > B) slabs = B;
+    if (slabs < 1) slabs = 1;
+    const int nb = (B + slabs - 1) / slabs;
+    dim3 grid(G, (B + nb - 1) / nb);
+    FUSED_DISPATCH(actnorm_invconv_bwd_kernel, grid, x, mask, logs, bias, w, w_inv, dz, dlogdet, x_len, dx, dlogs, dbias, dw, B, C, T, nb);
+    GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_invconv_bwd");
 }

@@ -54,14 +54,25 @@ __global__ __launch_bounds__(256) void mle_fwd_kernel(const float *__restrict__ 
                                                       float *__restrict__ acc, long nv, long nmask) {
     __shared__ float red[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        Vec<V> zv = Vec<V>::load(z + i * V);
-        Vec<V> mv = Vec<V>::load(m + i * V);
-        Vec<V> lv = Vec<V>::load(logs + i * V);
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 2 * stride) {
+        Vec<V> zv[2], mv[2], lv[2];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const float d = zv[j] - mv[j];
-            s += lv[j] + 0.5f * expf(-2.0f * lv[j]) * d * d;
+        for (int u = 0; u < 2; ++u) {
+            const bool ok = i0 + u * stride < nv;
+            const long i = ok ? i0 + u * stride : i0;
+            zv[u] = Vec<V>::load(z + i * V);
+            mv[u] = Vec<V>::load(m + i * V);
+            lv[u] = Vec<V>::load(logs + i * V);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (i0 + u * stride >= nv) continue;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = zv[u][j] - mv[u][j];
+                s += lv[u][j] + 0.5f * expf(-2.0f * lv[u][j]) * d * d;
+            }
         }
     }
     s = block_sum_256(s, red);
@@ -102,18 +113,27 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------------------------
 // clip + Adam/Noam on flat buffers
 // ------------------------------------------------------------------------------------------------------------
+// Reducing kernels end in one same-address atomic per workgroup, and those retire serially in L2 (~13 ns each): they
+// run on a small grid (reduce_grid) and get their memory-level parallelism from 4 independent vector loads per thread.
 template <int V>
 __global__ __launch_bounds__(256) void clip_kernel(float *__restrict__ g, long nv, float clip, float *__restrict__ sumsq) {
     __shared__ float red[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        Vec<V> gv = Vec<V>::load(g + i * V);
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 4 * stride) {
+        Vec<V> gv[4];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            s += gv[j] * gv[j];
-            gv[j] = fminf(fmaxf(gv[j], -clip), clip);
+        for (int u = 0; u < 4; ++u)
+            gv[u] = (i0 + u * stride < nv) ? Vec<V>::load(g + (i0 + u * stride) * V) : Vec<V>::zero();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                s += gv[u][j] * gv[u][j];
+                gv[u][j] = fminf(fmaxf(gv[u][j], -clip), clip);
+            }
+            if (i0 + u * stride < nv) gv[u].store(g + (i0 + u * stride) * V);
         }
-        gv.store(g + i * V);
     }
     s = block_sum_256(s, red);
     if (threadIdx.x == 0 && sumsq) atomicAdd(sumsq, s);
@@ -172,6 +192,13 @@ static inline int stream_grid(long nv) {
     return (int)g;
 }
 
+static inline int reduce_grid(long nv) {
+    long g = (nv + 255) / 256;
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 }  // namespace glowtts
 
 using namespace glowtts;
@@ -204,9 +231,9 @@ extern "C" int glowtts_mle_fwd(const float *z, const float *m, const float *logs
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if ((n & 3) == 0 && aligned16(z) && aligned16(m) && aligned16(logs))
-        hipLaunchKernelGGL((mle_fwd_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, z, m, logs, mask, acc, n / 4, (long)B * T);
+        hipLaunchKernelGGL((mle_fwd_kernel<4>), dim3(reduce_grid(n / 4)), dim3(256), 0, s, z, m, logs, mask, acc, n / 4, (long)B * T);
     else
-        hipLaunchKernelGGL((mle_fwd_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, z, m, logs, mask, acc, n, (long)B * T);
+        hipLaunchKernelGGL((mle_fwd_kernel<1>), dim3(reduce_grid(n)), dim3(256), 0, s, z, m, logs, mask, acc, n, (long)B * T);
     GLOWTTS_LAUNCH_CHECK("glowtts_mle_fwd");
 }
 
@@ -229,9 +256,9 @@ extern "C" int glowtts_clip_grad_value(float *g, int64_t n, float clip, float *s
     if (n == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if ((n & 3) == 0 && aligned16(g))
-        hipLaunchKernelGGL((clip_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, g, (long)(n / 4), clip, sumsq);
+        hipLaunchKernelGGL((clip_kernel<4>), dim3(reduce_grid(n / 4)), dim3(256), 0, s, g, (long)(n / 4), clip, sumsq);
     else
-        hipLaunchKernelGGL((clip_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, g, (long)n, clip, sumsq);
+        hipLaunchKernelGGL((clip_kernel<1>), dim3(reduce_grid(n)), dim3(256), 0, s, g, (long)n, clip, sumsq);
     GLOWTTS_LAUNCH_CHECK("glowtts_clip_grad_value");
 }
 

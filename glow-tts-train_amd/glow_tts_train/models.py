@@ -117,8 +117,19 @@ class FlowSpecDecoder(nn.Module):
         else:
             x_len = ops.mask_len(ops.mask2d(x_mask))
             logdet_tot = 0
-            for f in self.flows:
-                x, logdet = f(x, x_mask, g=g, reverse=False, x_len=x_len)
+            m2 = ops.mask2d(x_mask)
+            i = 0
+            while i < len(self.flows):
+                f = self.flows[i]
+                nxt = self.flows[i + 1] if i + 1 < len(self.flows) else None
+                if (isinstance(f, ActNorm) and f.initialized and isinstance(nxt, InvConvNear) and not nxt.no_jacobian
+                        and nxt.n_split in (2, 4)):
+                    # the two elementwise flows of a block in one pass over the tensor (ops.ActNormInvConvFn)
+                    x, logdet = ops.ActNormInvConvFn.apply(x, m2, f.logs, f.bias, nxt.weight, x_len, nxt.n_split)
+                    i += 2
+                else:
+                    x, logdet = f(x, x_mask, g=g, reverse=False, x_len=x_len)
+                    i += 1
                 logdet_tot = logdet_tot + logdet
         if self.n_sqz > 1:
             x, x_mask = unsqueeze(x, x_mask, self.n_sqz)

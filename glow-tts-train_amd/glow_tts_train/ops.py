@@ -122,6 +122,39 @@ class InvConvFn(Function):
         return dx, None, dw, None, None
 
 
+class ActNormInvConvFn(Function):
+    """ActNorm followed by InvConvNear (flows 3i, 3i+1 of a decoder block, models.py:176-179) in one pass each way."""
+
+    @staticmethod
+    def forward(ctx, x, m2, logs, bias, weight, x_len, n_split):
+        x = f32(_c(x))
+        B, C, T = x.shape
+        w = f32(_c(weight))
+        w_inv, logdet_w = invconv_prepare(w)
+        lg, bs = _c(logs.reshape(-1)), _c(bias.reshape(-1))
+        z = torch.empty_like(x)
+        logdet = torch.empty(B, device=x.device, dtype=torch.float32)
+        call("glowtts_actnorm_invconv_fwd", ptr(x), ptr(m2), ptr(lg), ptr(bs), ptr(w), ptr(logdet_w), ptr(x_len), ptr(z),
+             ptr(logdet), B, C, T, n_split)
+        ctx.save_for_backward(x, m2, lg, bs, w, w_inv, x_len)
+        ctx.n_split, ctx.pshape = n_split, logs.shape
+        return z, logdet
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogdet):
+        x, m2, lg, bs, w, w_inv, x_len = ctx.saved_tensors
+        B, C, T = x.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(x)
+        dx = torch.empty_like(x)
+        n = ctx.n_split
+        dpar = torch.zeros(2 * C + n * n, device=x.device, dtype=torch.float32)
+        dlogs, dbias, dw = dpar[:C], dpar[C:2 * C], dpar[2 * C:]
+        call("glowtts_actnorm_invconv_bwd", ptr(x), ptr(m2), ptr(lg), ptr(bs), ptr(w), ptr(w_inv), ptr(dz),
+             ptr(_c(dlogdet)), ptr(x_len), ptr(dx), ptr(dlogs), ptr(dbias), ptr(dw), B, C, T, n)
+        return dx, None, dlogs.view(ctx.pshape), dbias.view(ctx.pshape), dw.view(n, n), None, None
+
+
 def invconv_apply(x, m2, w, n_split):
     """Mix with an explicit matrix and no log-det (the reverse path passes the stored inverse, layers.py:254-258)."""
     x = f32(_c(x))

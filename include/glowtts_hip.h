@@ -80,6 +80,20 @@ int glowtts_invconv_bwd(const float *x, const float *mask, const float *w, const
                         const float *dlogdet, const float *x_len, float *dx, float *dw, int B, int C, int T,
                         int n_split, glowtts_stream_t stream);
 
+/* ---- ActNorm + InvConvNear in one pass (flows 3i and 3i+1 of every decoder block, models.py:176-179) ------------
+ * The two flows are consecutive and elementwise per (b, group, t); fused, the (B, C, T) tensor crosses HBM twice in
+ * forward (read x, write z) and three times in backward (read x, dz; write dx) instead of 4 / 6 times.
+ * fwd : y = (bias + exp(logs) x) mask ; z = (W y) mask ; logdet[b] = (sum(logs) + logdet_w * C/n) * x_len[b]
+ * bwd : dx, and ACCUMULATED dlogs, dbias (C each) and dw (n*n) -- the sums of the two separate backward kernels.
+ * n_split in {2, 4}; other values use the separate entry points above. */
+int glowtts_actnorm_invconv_fwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                const float *w, const float *logdet_w, const float *x_len, float *z, float *logdet,
+                                int B, int C, int T, int n_split, glowtts_stream_t stream);
+int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                const float *w, const float *w_inv, const float *dz, const float *dlogdet,
+                                const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B, int C,
+                                int T, int n_split, glowtts_stream_t stream);
+
 /* ---- affine coupling apply (attentions.py:128-142) ----------------------------------------------------------
  * x   : (B, C, T) flow input; out : (B, C, T) = end-conv output, rows [0,C/2) = m, [C/2,C) = logs
  * fwd : z[:, :C/2] = x[:, :C/2] ; z[:, C/2:] = (m + exp(logs') * x1) * mask ; logdet[b] += sum logs' * mask

@@ -174,6 +174,55 @@ def test_invconv_golden(G, name, n_split):
     assert_close(xr, g["x_rev"], what="x_rev", **TIGHT)
 
 
+@pytest.mark.parametrize("b,c,t,n_split", [(3, 8, 37, 4), (2, 8, 64, 2), (4, 160, 100, 4), (32, 160, 400, 4)])
+def test_actnorm_invconv_fused_vs_separate_and_oracle(G, b, c, t, n_split):
+    """FlowSpecDecoder runs flows 3i, 3i+1 as ONE kernel each way (ops.ActNormInvConvFn); it must equal the two
+    separate flows (golden-pinned above) and the oracle's composition (reference layers.py:196-197, 247-272)."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(b * 1000 + c + t)
+    x = torch.randn(b, c, t)
+    lens = torch.randint(t // 2, t + 1, (b,))
+    lens[0] = t
+    mask = (torch.arange(t)[None] < lens[:, None]).float()[:, None]
+    logs, bias = 0.3 * torch.randn(1, c, 1), 0.5 * torch.randn(1, c, 1)
+    w = torch.linalg.qr(torch.randn(n_split, n_split))[0] + 0.1 * torch.randn(n_split, n_split)
+    if torch.det(w) < 0:
+        w[:, 0] = -w[:, 0]
+    r, s = torch.randn(b, c, t), torch.randn(b)
+
+    def run(fused):
+        xs = x.cuda().requires_grad_(True)
+        p = [v.cuda().requires_grad_(True) for v in (logs, bias, w)]
+        m = mask.cuda()
+        m2 = G.ops.mask2d(m)
+        x_len = G.ops.mask_len(m2)
+        if fused:
+            z, ld = G.ops.ActNormInvConvFn.apply(xs, m2, p[0], p[1], p[2], x_len, n_split)
+        else:
+            y, ld1 = G.ops.ActNormFn.apply(xs, m2, p[0], p[1], x_len)
+            z, ld2 = G.ops.InvConvFn.apply(y, m2, p[2], x_len, n_split)
+            ld = ld1 + ld2
+        ((z * r.cuda()).sum() + (ld * s.cuda()).sum()).backward()
+        return [z, ld, xs.grad] + [q.grad for q in p]
+
+    names = ["z", "logdet", "dx", "dlogs", "dbias", "dw"]
+    fused, sep = run(True), run(False)
+    for n, a, bb in zip(names, fused, sep):
+        scale = float(bb.abs().max()) + 1e-6
+        assert_close(a, bb, what=f"fused vs separate {n}", rtol=1e-4, atol=2e-5 * max(1.0, scale))
+
+    xo = x.clone().requires_grad_(True)
+    po = [v.clone().requires_grad_(True) for v in (logs, bias, w)]
+    y, ld1 = O.actnorm(xo, mask, po[0], po[1])
+    z, ld2 = O.invconv(y, mask, po[2], n_split)
+    ((z * r).sum() + ((ld1 + ld2) * s).sum()).backward()
+    want = [z, ld1 + ld2, xo.grad] + [q.grad for q in po]
+    for n, a, bb in zip(names, fused, want):
+        scale = float(bb.abs().max()) + 1e-6
+        assert_close(a, bb, what=f"fused vs oracle {n}", rtol=2e-4, atol=5e-5 * max(1.0, scale))
+
+
 def test_invconv_prepare_matches_torch(G):
     torch.manual_seed(3)
     for n in (2, 4, 6, 8):
