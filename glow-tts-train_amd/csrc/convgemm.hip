@@ -28,8 +28,15 @@ namespace glowtts {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// 16 bytes of zeros in device memory: the source of every out-of-range staging load (see convgemm_kp_kernel)
+// 16 bytes of zeros in device memory: the zero source of the generic kernel's out-of-range staging loads
 __device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+#ifdef GLOWTTS_TRACE   // tuning builds only (tools/trace_conv.py): per-workgroup phase timestamps, 100 MHz wall clock
+__device__ unsigned long long g_trace[8192 * 16];
+#define GLOWTTS_TRACE_POINT(i) do { if (threadIdx.x == 0) { g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); if ((i) == 3 || (i) == 4) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 8 + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#else
+#define GLOWTTS_TRACE_POINT(i) do { } while (0)
+#endif
 
 enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_ADD = 4 };
 
@@ -305,34 +312,38 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// software-pipelined forward-type kernel, "k-packed" LDS image.
-//
-// History (profiles/, tools/mfma_rate.hip): v1 staged through run-time loops (serialised loads, 40 % of the fp32
-// MFMA peak); v2 prefetched chunk c+1 into registers behind the MFMAs of chunk c but fed every MFMA pair from
-// ds_read_b32 — 7 LDS instructions per 10 MFMAs — and the measured ceiling of that instruction mix on one wave per
-// SIMD is 69 % of peak (tools/mfma_rate.hip: 147 TF registers-only, 108 TF with the reads).  v3 (this kernel) lays
-// both operands out with 16 consecutive k per LDS row, so ONE ds_read_b128 per operand tile feeds FOUR k-steps:
-// lane (row = l & 15, slot = l >> 4) consumes k = 4*slot + j in step j for A and B alike — a relabelling of the
-// reduction index the MFMA is free to make — i.e. 7 LDS instructions per 40 MFMAs.
-//   Ws[tap][g][row][20]   : packed weights are stored [tap][g][M][16] in HBM, so staging is a straight 16-byte copy
-//   Xs[g][frame][20]      : activations arrive [k][frame]; each 16-byte load is scattered as 4 ds_write_b32 (lanes
-//                           walk k fastest: 2-way write conflicts at most); taps shift the FRAME index, i.e. the row
-// Preconditions (else the generic kernel runs): T % 4 == 0, 16-byte aligned rows, halo (TAPS-1)*dil <= 12.
+// Forward-type kernel history (profiles/, tools/mfma_rate.hip, tools/trace_conv.py):
+//   v1 staged through run-time loops (serialised loads, 40 % of the fp32 MFMA peak);
+//   v2 prefetched chunk c+1 into registers behind the MFMAs of chunk c but fed every MFMA pair from ds_read_b32 —
+//      7 LDS instructions per 10 MFMAs, a mix whose measured ceiling is 69 % of peak;
+//   v3 laid both operands out with 16 consecutive k per LDS row ("k-packed"), so ONE ds_read_b128 per operand tile
+//      feeds FOUR k-steps: lane (row = l & 15, slot = l >> 4) consumes k = 4*slot + j in step j for A and B alike — a
+//      relabelling of the reduction index the MFMA is free to make.  Weights AND activations went through LDS, 16
+//      channels per chunk, two barriers per chunk (94 TFLOP/s on the gated in-conv);
+//   v4 (below) keeps v3's activation image and takes the weights out of LDS.
 // ------------------------------------------------------------------------------------------------------------
-template <int RTW, int NCT, int EPI, int TAPS, int KG>
-__global__ __launch_bounds__(256, 2) void convgemm_kp_kernel(ConvGemmParams p) {
-    constexpr int WGR = 64 * RTW, NT = 16 * NCT, XC = NT + 16, KP = 20;
-    constexpr int W4 = TAPS * KG * WGR * 4;          // 16-byte pieces per weight chunk
-    constexpr int NW = (W4 + 255) / 256;
+// v4: weights straight from L2 into MFMA registers ("weights-direct").
+//
+// A wave's A operand (its own 16-row weight tiles) is used by no other wave, so routing it through LDS only costs LDS
+// bandwidth and ties every 16-channel step to a pair of workgroup barriers.  The packed layout [tap][g][M][16] is
+// already the MFMA A layout: lane (row = l & 15, slot = l >> 4) needs the 16 bytes at row*64 + slot*16 of a 1 KB
+// contiguous block — one fully coalesced global_load_dwordx4 per 16x16 tile and (tap, g) step, feeding 4*NCT MFMAs.
+// A 3-slot register ring keeps the load three steps ahead.  LDS then holds activations only, so a chunk can span
+// KG = 6 groups (96 channels, all taps): 2 chunks and 4 barriers for Cin = 192 instead of 12 chunks and 24 barriers.
+//   Xs[g][frame][20] : 16 consecutive channels per row, pitch 20 floats (conflict-free ds_read_b128); activations
+//                      arrive [k][frame], each 16-byte load is scattered as 4 ds_write_b32; taps shift the frame row.
+// vmcnt retires in order: the activation prefetch of chunk c+1 is issued at step 0 AFTER the weight load for step 3,
+// so no weight wait before step 4 has to drain it.
+// ------------------------------------------------------------------------------------------------------------
+template <int RTW, int NCT, int EPI, int TAPS>
+__global__ __launch_bounds__(256, 2) void convgemm_wd_kernel(ConvGemmParams p) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT, XC = NT + 16, KP = 20, KG = 6;
     constexpr int X4 = KG * 16 * (XC / 4);           // 16-byte loads per activation chunk
     constexpr int NX = (X4 + 255) / 256;
-    constexpr int WSZ = TAPS * KG * WGR * KP, XSZ = KG * XC * KP;
+    constexpr int S = KG * TAPS;                     // MFMA steps per chunk (a multiple of 3: the ring stays static)
+    static_assert(S % 3 == 0, "ring of 3");
     extern __shared__ __align__(16) float smem[];
-    // ONE LDS image (chunk c+1 waits in registers while chunk c is consumed): half the LDS of a double buffer, so two
-    // workgroups fit per CU and each SIMD hosts two waves — one wave's staging / barriers / epilogue hide behind the
-    // other's MFMAs (a single wave per SIMD left the MFMA pipe idle 40 % of the time: profiles/r01_pmc_gate_*.txt)
-    float *Ws = smem;                    // [WSZ]
-    float *Xs = smem + WSZ;              // [XSZ]
+    float *Xs = smem;                                // [KG][XC][KP]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
@@ -340,9 +351,10 @@ __global__ __launch_bounds__(256, 2) void convgemm_kp_kernel(ConvGemmParams p) {
     const int b = blockIdx.x / ntile_t;
     const int t0 = (blockIdx.x - b * ntile_t) * NT;
     const int tile_m = blockIdx.y;
-    const int off = (4 - (p.pad & 3)) & 3;      // window start ts = t0 - pad - off is a multiple of 4
+    const int off = (4 - (p.pad & 3)) & 3;           // window start ts = t0 - pad - off is a multiple of 4
     const int ts = t0 - p.pad - off;
     const int G = (p.Cin + 15) / 16;
+    const int nchunks = (G + KG - 1) / KG;
 
     auto grow = [&](int lr) -> int {
         if (EPI == EPI_GATE) return lr < 64 ? tile_m * 64 + lr : p.H + tile_m * 64 + (lr - 64);
@@ -360,125 +372,123 @@ __global__ __launch_bounds__(256, 2) void convgemm_kp_kernel(ConvGemmParams p) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- weights: buffer loads (range-checked by the hardware: an offset past the descriptor returns zeros, so rows
+    // beyond M and groups beyond G need no branch and no select of pointers — a select between two address spaces
+    // makes the compiler emit FLAT loads, which also count against lgkmcnt and stall every LDS wait behind L2 latency)
+    const int wbytes = TAPS * G * p.M * 64;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, wbytes, 0x00020000);
+    int wvo[RTW];                                    // this lane's byte offset inside a (tap, g) block, per row tile
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+        const int lr = ltile(r) * 16 + lrow;
+        wvo[r] = row_ok(lr) ? (grow(lr) * 16 + lk * 4) * 4 : wbytes;
+    }
+    const int wtap = G * p.M * 64, wgrp = p.M * 64;  // bytes
+    f32x4 a[3][RTW];
+    auto wload = [&](int c, int s, int slot) {       // weights of step s of chunk c (s may run past the chunk: next chunk)
+        if (s >= S) { s -= S; c += 1; }
+        const int g = c * KG + s / TAPS, tap = s % TAPS;
+        const int so = g < G ? tap * wtap + g * wgrp : wbytes;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+            a[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[r], so, 0));
+    };
+
+    // ---- activations: thread = (channel kk of a group, frame quad qq, group parity gsel); its 9 pieces are
+    // (group gsel + 2 gi, quad qq + 8 jq): every source / LDS offset is one per-thread base plus compile-time multiples,
+    // so the staging costs no address registers.  The mask window sits in LDS (read at store time, not from HBM).
     const float *xb = p.x + (long)b * p.x_bs;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
-    f32x4 wreg[NW], xreg[NX];
-
-    // Per-thread source pointers, LDS destinations and validity are fixed for the whole K loop (only the 16-channel
-    // group advances, by a constant stride), so they are computed ONCE; inside the loop a load is an unconditional
-    // 16-byte read from a clamped address plus a select — no address arithmetic and no exec-mask branches that would
-    // keep the wave from issuing MFMAs.
-    int wsrc[NW], wdst[NW], wgrp[NW];          // element offsets from p.wp / LDS offsets / group index (-1 = never valid)
+    float *Ms = smem + KG * XC * KP;                 // [XC]
+    constexpr int NQ = (XC / 4 + 7) / 8, NG = KG / 2;
+    static_assert(NQ * NG * 256 >= X4, "piece map covers the chunk");
+    const int kk = tid & 15, qq = (tid >> 4) & 7, gsel = tid >> 7;
+    const int xbytes = p.Cin * p.T * 4;              // channels past Cin fall outside the descriptor: zeros
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, xbytes, 0x00020000);
+    int xvo[NQ];                                     // byte offset of (channel gsel*16 + kk, frame quad qq + 8 jq)
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int idx = tid + i * 256;
-        const int q = idx & 3;
-        const int lr = (idx >> 2) % WGR;
-        const int rest = (idx >> 2) / WGR;
-        const int g = rest % KG, tap = rest / KG;
-        const bool ok = idx < W4 && row_ok(lr);
-        wgrp[i] = ok ? g : (1 << 30);
-        wdst[i] = (idx >> 2) * KP + q * 4;
-        wsrc[i] = ok ? (int)((((long)tap * G + g) * p.M + grow(lr)) * 16 + q * 4) : 0;
+    for (int jq = 0; jq < NQ; ++jq) {
+        const int t = ts + (qq + 8 * jq) * 4;
+        const bool ok = (qq + 8 * jq < XC / 4) && t >= 0 && t < p.T;
+        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * 4 : xbytes;
     }
-    int xsrc[NX], xdst[NX], xk[NX], xt[NX];    // element offsets from xb / LDS offsets / channel-in-chunk / frame
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int idx = tid + i * 256;
-        const int kk = idx & 15;
-        const int q = (idx >> 4) % (XC / 4);
-        const int g = (idx >> 4) / (XC / 4);
-        const int t = ts + q * 4;
-        const bool ok = idx < X4 && t >= 0 && t < p.T;
-        xk[i] = ok ? g * 16 + kk : (1 << 30);
-        xt[i] = ok ? t : 0;
-        xdst[i] = (g * XC + q * 4) * KP + kk;
-        xsrc[i] = ok ? (g * 16 + kk) * p.T + t : 0;
+    const int dbase = (gsel * XC + qq * 4) * KP + kk;
+    f32x4 xreg[NG][NQ];
+    if (p.mask_in && tid < XC) {
+        const int t = ts + tid;
+        Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
     }
-    const int wstride = KG * p.M * 16, xstride = KG * 16 * p.T;
+    auto xload = [&](int c) {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+                xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    xrs, xvo[jq], ((c * KG + 2 * gi) * 16) * p.T * 4, 0));
+    };
+    auto xstore = [&]() {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+                if (qq + 8 * jq < XC / 4) {
+                    f32x4 v = xreg[gi][jq];
+                    if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
+                    float *d = Xs + dbase + (2 * gi * XC + 32 * jq) * KP;
+                    d[0] = v[0]; d[KP] = v[1]; d[2 * KP] = v[2]; d[3 * KP] = v[3];
+                }
+    };
+    const float *xd = Xs + (off + lrow) * KP + lk * 4;
+    f32x4 bv[2][NCT];
+    auto bfetch = [&](int s, int slot) {
+        const int g = s / TAPS, tap = s % TAPS;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+            bv[slot][c] = *reinterpret_cast<const f32x4 *>(xd + (g * XC + c * 16 + tap * p.dil) * KP);
+    };
 
-    // Loads are PURE loads: an out-of-range piece reads 16 bytes of zeros from a __device__ constant instead of being
-    // patched with a select afterwards — any use of the loaded value before the MFMAs would put an s_waitcnt vmcnt(0)
-    // in front of them and serialise the prefetch (that is exactly what an earlier revision of this kernel did).
-    f32x4 mreg[NX];
-    auto load_chunk = [&](int g0) {
-        const int c = g0 / KG;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const bool ok = g0 + wgrp[i] < G;
-            wreg[i] = *reinterpret_cast<const f32x4 *>(ok ? p.wp + wsrc[i] + c * wstride : g_zero16);
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const bool ok = g0 * 16 + xk[i] < p.Cin;
-            xreg[i] = *reinterpret_cast<const f32x4 *>(ok ? xb + xsrc[i] + c * xstride : g_zero16);
-            if (p.mask_in) mreg[i] = *reinterpret_cast<const f32x4 *>(mk + xt[i]);
-        }
-    };
-    auto store_chunk = [&]() {
-        float *wd = Ws;
-        float *xd = Xs;
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (tid + i * 256 < W4) *reinterpret_cast<f32x4 *>(wd + wdst[i]) = wreg[i];
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (tid + i * 256 < X4) {
-                f32x4 v = xreg[i];
-                if (p.mask_in) v *= mreg[i];
-                float *d = xd + xdst[i];
-                d[0] = v[0]; d[KP] = v[1]; d[2 * KP] = v[2]; d[3 * KP] = v[3];
-            }
-    };
-    auto compute = [&]() {
-        const float *wd = Ws + lrow * KP + lk * 4;
-        const float *xd = Xs + (off + lrow) * KP + lk * 4;
-        constexpr int S = KG * TAPS;
-        f32x4 a[2][RTW], bv[2][NCT];
-        auto fetch = [&](int s, int slot) {
-            const int g = s / TAPS, tap = s % TAPS;
-#pragma unroll
-            for (int r = 0; r < RTW; ++r)
-                a[slot][r] = *reinterpret_cast<const f32x4 *>(wd + ((tap * KG + g) * WGR + ltile(r) * 16) * KP);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c)
-                bv[slot][c] = *reinterpret_cast<const f32x4 *>(xd + (g * XC + c * 16 + tap * p.dil) * KP);
-        };
-        fetch(0, 0);
+    GLOWTTS_TRACE_POINT(0);
+    wload(0, 0, 0);
+    wload(0, 1, 1);
+    wload(0, 2, 2);
+    xload(0);
+    if (p.mask_in) __syncthreads();                 // mask window visible
+    xstore();
+    __syncthreads();
+    GLOWTTS_TRACE_POINT(1);
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        bfetch(0, 0);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            if (s + 1 < S) fetch(s + 1, (s + 1) & 1);
+            if (s + 1 < S) bfetch(s + 1, (s + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);      // keep the next step's LDS reads ahead of this step's MFMAs
-            const int sl = s & 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < RTW; ++r)
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][r][j], bv[sl][c][j], acc[r][c], 0, 0, 0);
+                    for (int cc = 0; cc < NCT; ++cc)
+                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s % 3][r][j], bv[s & 1][cc][j], acc[r][cc], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(c, s + 3, s % 3);                 // refill the slot just consumed: three steps of lead
+            if (s == 0 && more) xload(c + 1);       // HBM/L2 -> registers, behind the MFMAs of this chunk
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-
-    const int nchunks = (G + KG - 1) / KG;
-    load_chunk(0);
-    store_chunk();
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = c + 1 < nchunks;
-        if (more) load_chunk((c + 1) * KG);       // HBM/L2 -> registers, in flight behind the MFMAs below
-        compute();
-        __syncthreads();                          // every wave is done reading the LDS image
+        GLOWTTS_TRACE_POINT(2 + 2 * (c & 3));
+        __syncthreads();                            // every wave is done reading the LDS image
         if (more) {
-            store_chunk();
+            xstore();
             __syncthreads();
         }
+        GLOWTTS_TRACE_POINT(3 + 2 * (c & 3));
     }
     if (p.vec_epilogue) {
         conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);   // LDS is free after the last barrier
     } else {
         conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
     }
+    GLOWTTS_TRACE_POINT(10);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -584,11 +594,19 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
     const int nkt = (p.Cin + 63) / 64;
-    const int kt = blockIdx.x % nkt, mt = blockIdx.x / nkt;
+    // XCD-aware order: hardware deals workgroup ids round-robin over the 8 XCDs (own L2 each).  All tiles of one split
+    // read the same x / d chunks, so logical work items are numbered split-major and XCD x takes a contiguous range of
+    // them: a chunk is then fetched by one or two XCDs instead of all eight.
+    const int ntiles = gridDim.x, nwg = gridDim.x * gridDim.z;
+    const int id = blockIdx.x + blockIdx.z * gridDim.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    const int tile = item % ntiles, split = item / ntiles;
+    const int kt = tile % nkt, mt = tile / nkt;
     const int k0 = kt * 64, m0 = mt * 64;
     const int off = (4 - (p.pad & 3)) & 3;
     const int nct = (p.T + CT - 1) / CT;             // chunks per utterance
-    const int c0 = blockIdx.z * p.nb;                // this workgroup's range of the B * nct (utterance, chunk) pairs
+    const int c0 = split * p.nb;                     // this workgroup's range of the B * nct (utterance, chunk) pairs
     const int nchunks = min(p.B * nct, c0 + p.nb) - c0;
 
     f32x4 acc[TAPS][4];
@@ -596,49 +614,58 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 xreg[NX], dreg[ND];
+    float4 xreg[NX], dreg[ND], mxreg[NX], mdreg[ND];
     float bsum[ND];                                   // bias gradient: running sums of this thread's D pieces
 #pragma unroll
     for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
     const bool do_bias = (p.dbias != nullptr) && (kt == 0);
 
+    // Range-checked buffer loads: a piece outside the tensor (row past Cin / M, frame outside [0, T), index past the
+    // tile) gets an offset beyond the descriptor and reads zeros — no exec-mask branch around any load, and nothing
+    // touches a loaded value before the MFMAs (masks are applied when the chunk is stored to LDS).
+    const int xbytes = (int)(((long)(p.B - 1) * p.x_bs + (long)p.Cin * p.T) * 4);
+    const int dbytes = (int)(((long)(p.B - 1) * p.d_bs + (long)p.M * p.T) * 4);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.d), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask), 0, p.mask ? p.B * p.T * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask_x), 0, p.mask_x ? p.B * p.T * 4 : 0, 0x00020000);
+    constexpr int kOOB = 0x7fffffff;                  // beyond any descriptor
+    int xrow[NX], xq[NX], drow[ND], dq[ND];           // element offset of the piece's row / frame offset in the window
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (XC / 4), r = idx / (XC / 4);
+        xq[i] = q * 4;
+        xrow[i] = (idx < X4 && k0 + r < p.Cin) ? (k0 + r) * p.T : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (CT / 4), r = idx / (CT / 4);
+        dq[i] = q * 4;
+        drow[i] = (idx < D4 && m0 + r < p.M) ? (m0 + r) * p.T : -1;
+    }
+    auto ld16 = [&](const __amdgpu_buffer_rsrc_t &rs, int byte_off) -> float4 {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+    };
     auto load_chunk = [&](int c) {
         const int b = (c0 + c) / nct;
         const int tc = ((c0 + c) % nct) * CT;
         const int ts = tc - p.pad - off;
-        const float *xb = p.x + (long)b * p.x_bs;
-        const float *db = p.d + (long)b * p.d_bs;
-        const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+        const int xb = b * (int)p.x_bs, db = b * (int)p.d_bs;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            const int q = idx % (XC / 4), r = idx / (XC / 4);
-            const int t = ts + q * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < X4 && k0 + r < p.Cin && t >= 0 && t < p.T) {
-                v = *reinterpret_cast<const float4 *>(xb + (long)(k0 + r) * p.T + t);
-                if (p.mask_x) {
-                    const float4 m = *reinterpret_cast<const float4 *>(p.mask_x + (long)b * p.T + t);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            xreg[i] = v;
+            const int t = ts + xq[i];
+            const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
+            xreg[i] = ld16(xrs, ok ? (xb + xrow[i] + t) * 4 : kOOB);
+            if (p.mask_x) mxreg[i] = ld16(mxrs, ok ? (b * p.T + t) * 4 : kOOB);
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int idx = tid + i * 256;
-            const int q = idx % (CT / 4), r = idx / (CT / 4);
-            const int t = tc + q * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < D4 && m0 + r < p.M && t < p.T) {
-                v = *reinterpret_cast<const float4 *>(db + (long)(m0 + r) * p.T + t);
-                if (mk) {
-                    const float4 m = *reinterpret_cast<const float4 *>(mk + t);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            dreg[i] = v;
-            if (do_bias) bsum[i] += (v.x + v.y) + (v.z + v.w);
+            const int t = tc + dq[i];
+            const bool ok = drow[i] >= 0 && t < p.T;
+            dreg[i] = ld16(drs, ok ? (db + drow[i] + t) * 4 : kOOB);
+            if (p.mask) mdreg[i] = ld16(mdrs, ok ? (b * p.T + t) * 4 : kOOB);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -649,9 +676,11 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
             const int idx = tid + i * 256;
             const int q = idx % (XC / 4), r = idx / (XC / 4);
             if (idx < X4) {           // pitch is even, not a multiple of 4: two 8-byte stores
+                float4 v = xreg[i];
+                if (p.mask_x) { v.x *= mxreg[i].x; v.y *= mxreg[i].y; v.z *= mxreg[i].z; v.w *= mxreg[i].w; }
                 float2 *d2 = reinterpret_cast<float2 *>(xd + r * XP + q * 4);
-                d2[0] = make_float2(xreg[i].x, xreg[i].y);
-                d2[1] = make_float2(xreg[i].z, xreg[i].w);
+                d2[0] = make_float2(v.x, v.y);
+                d2[1] = make_float2(v.z, v.w);
             }
         }
 #pragma unroll
@@ -659,9 +688,12 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
             const int idx = tid + i * 256;
             const int q = idx % (CT / 4), r = idx / (CT / 4);
             if (idx < D4) {
+                float4 v = dreg[i];
+                if (p.mask) { v.x *= mdreg[i].x; v.y *= mdreg[i].y; v.z *= mdreg[i].z; v.w *= mdreg[i].w; }
+                if (do_bias) bsum[i] += (v.x + v.y) + (v.z + v.w);
                 float2 *d2 = reinterpret_cast<float2 *>(dd + r * DP + q * 4);
-                d2[0] = make_float2(dreg[i].x, dreg[i].y);
-                d2[1] = make_float2(dreg[i].z, dreg[i].w);
+                d2[0] = make_float2(v.x, v.y);
+                d2[1] = make_float2(v.z, v.w);
             }
         }
     };
@@ -700,16 +732,27 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
         if (more) store_chunk((c + 1) & 1);
         __syncthreads();
     }
+    if (k0 + 64 <= p.Cin && m0 + 64 <= p.M) {         // whole tile inside (workgroup-uniform): no per-lane predicates
+        float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
+        for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int k = k0 + wave * 16 + lk * 4 + reg;
-                const int m = m0 + i * 16 + lrow;
-                if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
-            }
+                for (int reg = 0; reg < 4; ++reg)
+                    atomicAdd(base + ((long)tp * p.Cin + reg) * p.M + i * 16, acc[tp][i][reg]);
+    } else {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = k0 + wave * 16 + lk * 4 + reg;
+                    const int m = m0 + i * 16 + lrow;
+                    if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+                }
+    }
     if (do_bias) {      // a thread's piece i always belongs to row (tid + 256 i) / (CT/4): reduce rows in LDS, then one atomic each
         float *rowacc = smem;
         if (tid < 64) rowacc[tid] = 0.f;
@@ -872,18 +915,18 @@ static int launch_convgemm(ConvGemmParams &p, hipStream_t s) {
     GLOWTTS_LAUNCH_CHECK("glowtts_conv");
 }
 
-template <int RTW, int NCT, int EPI, int TAPS, int KG>
-static int launch_convgemm_kp(ConvGemmParams &p, hipStream_t s) {
+template <int RTW, int NCT, int EPI, int TAPS>
+static int launch_convgemm_wd(ConvGemmParams &p, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;
-    constexpr size_t lds_pipe = ((size_t)TAPS * KG * WGR * 20 + (size_t)KG * (NT + 16) * 20) * sizeof(float);
+    constexpr size_t lds_pipe = ((size_t)6 * (NT + 16) * 20 + (NT + 16)) * sizeof(float);
     constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
+    static size_t attr_max_e = 0;
     if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_wd_kernel<RTW, NCT, EPI, TAPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_max_e = (size_t)lds;
@@ -892,16 +935,16 @@ static int launch_convgemm_kp(ConvGemmParams &p, hipStream_t s) {
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
     dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
-    hipLaunchKernelGGL((convgemm_kp_kernel<RTW, NCT, EPI, TAPS, KG>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((convgemm_wd_kernel<RTW, NCT, EPI, TAPS>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv");
 }
 
 template <int RTW, int NCT, int EPI>
 static int dispatch_taps(ConvGemmParams &p, hipStream_t s, bool pipe_ok) {
     if (pipe_ok) {
-        if (p.taps == 5) return launch_convgemm_kp<RTW, NCT, EPI, 5, 1>(p, s);
-        if (p.taps == 3) return launch_convgemm_kp<RTW, NCT, EPI, 3, 1>(p, s);
-        if (p.taps == 1) return launch_convgemm_kp<RTW, NCT, EPI, 1, 2>(p, s);
+        if (p.taps == 5) return launch_convgemm_wd<RTW, NCT, EPI, 5>(p, s);
+        if (p.taps == 3) return launch_convgemm_wd<RTW, NCT, EPI, 3>(p, s);
+        if (p.taps == 1) return launch_convgemm_wd<RTW, NCT, EPI, 1>(p, s);
     }
     return launch_convgemm<RTW, NCT, EPI>(p, s);
 }
@@ -1080,3 +1123,15 @@ extern "C" int glowtts_rowsum(const float *d, long d_bs, const float *mask, floa
     hipLaunchKernelGGL(rowsum_kernel, dim3(M, (B + nb - 1) / nb), dim3(256), 0, (hipStream_t)stream, d, mask, out, d_bs, B, M, T, nb);
     GLOWTTS_LAUNCH_CHECK("glowtts_rowsum");
 }
+
+#ifdef GLOWTTS_TRACE
+extern "C" int glowtts_debug_trace_read(unsigned long long *host, int n_words, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(glowtts::g_trace), (size_t)n_words * 8);
+    if (e != hipSuccess) return (int)e;
+    if (clear) {
+        static unsigned long long zeros[8192 * 16];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(glowtts::g_trace), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
+#endif

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (ROCm 7.x, rocpd sqlite output) run into the CSVs kept under profiles/.
+
+  python tools/rocpd_summary.py kernels  <results.db> <out.csv>        per-kernel calls / total / mean / min / max (ns), % of GPU time
+  python tools/rocpd_summary.py counters <results.db> <out.csv> [substr]  per-kernel mean counter value per dispatch (PMC runs)
+
+rocprofv3 --kernel-trace --stats writes the same numbers into its `top_kernels` view; the view is used when present."""
+import csv
+import sqlite3
+import sys
+
+
+def kernels(db, out):
+    c = sqlite3.connect(db)
+    rows = c.execute(
+        "select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
+        "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+        for r in rows:
+            w.writerow([r[0][:160], r[1], r[2], round(r[3], 1), r[4], r[5], round(100.0 * r[2] / tot, 3)])
+    print(f"{out}: {len(rows)} kernels, {tot / 1e6:.2f} ms of kernel time")
+
+
+def counters(db, out, substr=""):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = c.execute(
+        f"select {name_col}, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+        f"where {name_col} like ? group by {name_col}, counter_name order by 1, 2", (f"%{substr}%",)).fetchall()
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch", "Min", "Max"])
+        w.writerows([(r[0][:160],) + tuple(r[1:]) for r in rows])
+    print(f"{out}: {len(rows)} rows")
+
+
+if __name__ == "__main__":
+    mode, db, out = sys.argv[1:4]
+    if mode == "kernels":
+        kernels(db, out)
+    else:
+        counters(db, out, sys.argv[4] if len(sys.argv) > 4 else "")

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Phase timeline of one conv-kernel launch (tuning tool; needs the trace build: `make -C glow-tts-train_amd/csrc trace`).
+Usage: GLOWTTS_HIP_LIB=tools/libglowtts_trace.bin python tools/trace_conv.py [gate|resskip|bwd_data5|bwd_data1|start]"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+os.environ.setdefault("GLOWTTS_HIP_LIB", os.path.join(ROOT, "tools", "libglowtts_trace.bin"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from glow_tts_train import _hip, convops  # noqa: E402
+from glow_tts_train._hip import call, ptr  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "gate"
+B, H, T, C = 32, 192, 400, 160
+dev = "cuda"
+torch.manual_seed(0)
+x = torch.randn(B, H, T, device=dev)
+m2 = torch.ones(B, T, device=dev)
+v_in = torch.randn(2 * H, H, 5, device=dev) * 0.03
+g_in = torch.ones(2 * H, 1, 1, device=dev)
+b_in = torch.zeros(2 * H, device=dev)
+v_rs = torch.randn(2 * H, H, 1, device=dev) * 0.07
+wf_in, wb_in, _ = convops.pack_weight(v_in, g_in)
+wf_rs, wb_rs, _ = convops.pack_weight(v_rs, None)
+acts = torch.empty(B, H, T, device=dev)
+ts = torch.empty(B, 2 * H, T, device=dev)
+xo = torch.empty(B, H, T, device=dev)
+sk = torch.empty(B, H, T, device=dev)
+d2 = torch.randn(B, 2 * H, T, device=dev)
+dx = torch.empty(B, H, T, device=dev)
+
+fns = {
+    "gate": lambda: call("glowtts_conv_gate_fwd", ptr(x), ptr(wf_in), ptr(b_in), None, None, 1.0, ptr(acts), ptr(ts), B, H, T, 5, 1, 2),
+    "resskip": lambda: call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(b_in), ptr(m2), ptr(x), ptr(sk), ptr(xo), ptr(sk), B, H, T, 0),
+    "bwd_data5": lambda: convops.conv_fwd(d2, wb_in, None, None, dx, 2 * H, H, 5, 1, 2, addend=d2[:, :H]),
+    "bwd_data1": lambda: convops.conv_fwd(d2, wb_rs, None, None, dx, 2 * H, H, 1, 1, 0),
+}
+fn = fns[which]
+lib = _hip.load()
+rd = lib.glowtts_debug_trace_read
+rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+NW = 8192 * 16
+buf = np.zeros(NW, dtype=np.uint64)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+rd(buf.ctypes.data, NW, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+fn()
+e1.record()
+torch.cuda.synchronize()
+rd(buf.ctypes.data, NW, 0)
+tr = buf.reshape(8192, 16).astype(np.int64)
+tr = tr[tr[:, 0] > 0]
+t00 = tr[:, 0].min()
+us = lambda a: (a - t00) / 100.0      # 100 MHz wall clock -> microseconds
+print(f"{which}: {len(tr)} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us, "
+      f"first start -> last end {us(tr[:, 10].max()):.1f} us")
+cols = [c for c in range(11) if (tr[:, c] > 0).all()]
+print("trace point : " + "  ".join(f"{c:>7d}" for c in cols))
+for name, f in (("min", np.min), ("median", np.median), ("max", np.max)):
+    print(f"abs {name:7s}: " + "  ".join(f"{f(us(tr[:, c])):7.1f}" for c in cols))
+prev = None
+print("phase lengths (per workgroup, us):")
+for c in cols:
+    if prev is not None:
+        d = (tr[:, c] - tr[:, prev]) / 100.0
+        print(f"  {prev:2d} -> {c:2d}: min {d.min():6.1f}  median {np.median(d):6.1f}  max {d.max():6.1f}")
+    prev = c
+if (tr[:, 11] > 0).all():
+    cyc = (tr[:, 12] - tr[:, 11]).astype(float)
+    wall = (tr[:, 4] - tr[:, 3]) / 100.0
+    print(f"shader clock over the 3 -> 4 phase: median {np.median(cyc / wall):.0f} cycles/us")
+hw = tr[:, 15]
+# HW_ID (gfx9): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13(+), ... ; XCC_ID separate register on gfx94x
+cu_key = (hw >> 8) & 0xFFFF
+print("distinct (cu, sh, se, ...) keys:", len(np.unique(cu_key)))
+order = np.argsort(cu_key, kind="stable")
+print("sample of co-resident workgroups (key, start, p1, p2, p3, p4, end):")
+for i in order[:24]:
+    print(f"  {cu_key[i]:6x} " + " ".join(f"{us(tr[i, c]):6.1f}" for c in (0, 1, 2, 3, 4, 10)))
+start = us(tr[:, 0])
+print("start-time histogram (us):", np.histogram(start, bins=8)[0].tolist(), [round(v, 1) for v in np.histogram(start, bins=8)[1].tolist()])
