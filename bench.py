@@ -12,10 +12,13 @@ T_text=160, T_mel=800, 80 mels, 12 flow blocks, n_split=4, fp32, ModelConfig def
 random-init weights, data-dependent ActNorm init done before timing.  Weak scaling: every rank gets its own B=32.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  "roofline"     : the dominant hand-written HIP kernel of the step — algorithmic bytes per launch
-                   / its mean launch duration measured with HIP events on the launch stream in an instrumented
-                   pass after the timed region — against the 8 TB/s HBM peak; plus the SURVEY.md §8d(i)
-                   invertible-subset fraction and the per-kernel table;
+  "roofline"     : the dominant hand-written HIP kernel of the step (the one with the largest total time): an fp32-MFMA
+                   implicit-GEMM convolution, so bound = "mfma": algorithmic FLOPs per launch (2*M*K*taps*columns,
+                   DESIGN.md 4a) / its mean launch duration, measured with HIP events on the launch stream in an
+                   instrumented pass after the timed region, against the 157.3 TFLOP/s dense fp32 MFMA peak;
+                   "traffic" = HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json);
+                   plus every MFMA kernel's TFLOP/s, every streaming kernel's GB/s against 8 TB/s, and the
+                   SURVEY.md 8d(i) invertible-subset fraction;
   "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) timed on this host's cores on a bounded sample.
 """
 from __future__ import annotations
@@ -89,6 +92,17 @@ def algorithmic_bytes(B, C, H, Ts, T_text, n_params_padded):
 INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invconv_fwd", "glowtts_invconv_bwd",
                      "glowtts_actnorm_invconv_fwd", "glowtts_actnorm_invconv_bwd", "glowtts_coupling_fwd",
                      "glowtts_coupling_bwd")
+
+
+def pmc_traffic(kernel_tag):
+    """HBM-side bytes per launch of `kernel_tag` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
+    collected from inside this process): profiles/r01_pmc_traffic.json, measured with tools/microbench_conv.py on the
+    same kernel and shape and corrected as MI355X_MICROARCH.md prescribes.  None when no measurement exists."""
+    try:
+        table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        return table[kernel_tag]["traffic_bytes"]
+    except Exception:
+        return None
 
 
 _T0 = time.perf_counter()
@@ -254,7 +268,8 @@ def main():
         conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
         if dom is not None:
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+                               "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS,
+                               "traffic": pmc_traffic(dom)}
         else:
             dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,

@@ -34,8 +34,10 @@ __device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f
 #ifdef GLOWTTS_TRACE   // tuning builds only (tools/trace_conv.py): per-workgroup phase timestamps, 100 MHz wall clock
 __device__ unsigned long long g_trace[8192 * 16];
 #define GLOWTTS_TRACE_POINT(i) do { if (threadIdx.x == 0) { g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); if ((i) == 3 || (i) == 4) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 8 + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#define GLOWTTS_TRACE_POINT_Z(i) do { if (threadIdx.x == 0) g_trace[((blockIdx.z * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define GLOWTTS_TRACE_POINT(i) do { } while (0)
+#define GLOWTTS_TRACE_POINT_Z(i) do { } while (0)
 #endif
 
 enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_ADD = 4 };
@@ -768,6 +770,221 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// weight gradient, "frame-packed" (dil == 1, 'same' padding): the contraction index is the frame, and the same
+// relabelling as in the forward kernel applies — lane slot lk supplies frames 16G + 4 lk + j to MFMA j of a 16-frame
+// group G, for A (x rows) and B (d rows) alike.  One ds_read_b128 per d tile then feeds 4 MFMAs, and the 5 tap shifts
+// of an x row are 12 consecutive floats = 3 aligned ds_read_b128 feeding 20 (tap, j) pairs: 7 LDS instructions per
+// 80 MFMAs instead of 36 ds_read_b32 (a mix measured at <= 80 % of the MFMA rate, tools/mfma_rate.hip).
+//   Xs[64 k-rows][XP], Ds[64 m-rows][DP], pitches == 4 (mod 8) floats: conflict-free b128 reads, and the staging
+//   store is the 16-byte load written back as one ds_write_b128.
+// One LDS image; chunk c+1 waits in registers behind the MFMAs of chunk c.  Masks go through a small LDS window.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int cpitch4(int w) { int p = (w + 3) / 4 * 4; while (p % 8 != 4) p += 4; return p; }
+
+template <int TAPS, int NGRP>
+__global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
+    constexpr int CT = 16 * NGRP, XC = CT + 16;
+    constexpr int XP = cpitch4(XC), DP = cpitch4(CT);
+    constexpr int PAD = (TAPS - 1) / 2, OFF = (4 - (PAD & 3)) & 3;
+    constexpr int NA = (3 + TAPS + OFF + 3) / 4;                 // b128 reads covering floats [0, 3 + TAPS - 1 + OFF]
+    constexpr int X4 = 64 * (XC / 4), D4 = 64 * (CT / 4);
+    constexpr int NX = (X4 + 255) / 256, ND = (D4 + 255) / 256;
+    extern __shared__ __align__(16) float smem[];
+    float *Xs = smem;                        // [64][XP]
+    float *Ds = smem + 64 * XP;              // [64][DP]
+    float *Mx = Ds + 64 * DP;                // [XC]  x-mask window of the chunk being stored
+    float *Md = Mx + XC;                     // [CT]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int nkt = (p.Cin + 63) / 64;
+    // XCD-aware order (see convwrw_pipe_kernel): split-major work items, contiguous ranges per XCD
+    const int ntiles = gridDim.x, nwg = gridDim.x * gridDim.z;
+    const int id = blockIdx.x + blockIdx.z * gridDim.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    const int tile = item % ntiles, split = item / ntiles;
+    const int kt = tile % nkt, mt = tile / nkt;
+    const int k0 = kt * 64, m0 = mt * 64;
+    const int nct = (p.T + CT - 1) / CT;
+    const int c0 = split * p.nb;
+    const int nchunks = min(p.B * nct, c0 + p.nb) - c0;
+
+    f32x4 acc[TAPS][4];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xreg[NX], dreg[ND], mreg;
+    float bsum[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
+    const bool do_bias = (p.dbias != nullptr) && (kt == 0);
+    const bool masked = (p.mask != nullptr) || (p.mask_x != nullptr);
+
+    const int xbytes = (int)(((long)(p.B - 1) * p.x_bs + (long)p.Cin * p.T) * 4);
+    const int dbytes = (int)(((long)(p.B - 1) * p.d_bs + (long)p.M * p.T) * 4);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.d), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask), 0, p.mask ? p.B * p.T * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask_x), 0, p.mask_x ? p.B * p.T * 4 : 0, 0x00020000);
+    constexpr int kOOB = 0x7fffffff;
+    auto ld16 = [&](const __amdgpu_buffer_rsrc_t &rs, int byte_off) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+    };
+    int xrow[NX], xq[NX], drow[ND], dq[ND];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (XC / 4), r = idx / (XC / 4);
+        xq[i] = q * 4;
+        xrow[i] = (idx < X4 && k0 + r < p.Cin) ? (k0 + r) * p.T : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (CT / 4), r = idx / (CT / 4);
+        dq[i] = q * 4;
+        drow[i] = (idx < D4 && m0 + r < p.M) ? (m0 + r) * p.T : -1;
+    }
+    // mask windows: thread tid < XC/4 carries 4 x-mask frames, thread 64 + j < 64 + CT/4 carries 4 d-mask frames
+    const bool mx_thread = tid < XC / 4, md_thread = tid >= 64 && tid < 64 + CT / 4;
+
+    auto load_chunk = [&](int c) {
+        const int b = (c0 + c) / nct;
+        const int tc = ((c0 + c) % nct) * CT;
+        const int ts = tc - PAD - OFF;
+        const int xb = b * (int)p.x_bs, db = b * (int)p.d_bs;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int t = ts + xq[i];
+            const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
+            xreg[i] = ld16(xrs, ok ? (xb + xrow[i] + t) * 4 : kOOB);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int t = tc + dq[i];
+            const bool ok = drow[i] >= 0 && t < p.T;
+            dreg[i] = ld16(drs, ok ? (db + drow[i] + t) * 4 : kOOB);
+        }
+        if (masked) {
+            const int tx = ts + tid * 4, td = tc + (tid - 64) * 4;
+            if (mx_thread) mreg = ld16(mxrs, (tx >= 0 && tx < p.T) ? (b * p.T + tx) * 4 : kOOB);
+            if (md_thread) mreg = ld16(mdrs, (td < p.T) ? (b * p.T + td) * 4 : kOOB);
+        }
+    };
+    auto store_chunk = [&]() {
+        if (masked) {                                   // workgroup-uniform
+            if (mx_thread) *reinterpret_cast<f32x4 *>(Mx + tid * 4) = mreg;
+            if (md_thread) *reinterpret_cast<f32x4 *>(Md + (tid - 64) * 4) = mreg;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XC / 4), r = idx / (XC / 4);
+            if (idx < X4) {
+                f32x4 v = xreg[i];
+                if (p.mask_x) v *= *reinterpret_cast<const f32x4 *>(Mx + q * 4);
+                *reinterpret_cast<f32x4 *>(Xs + r * XP + q * 4) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (CT / 4), r = idx / (CT / 4);
+            if (idx < D4) {
+                f32x4 v = dreg[i];
+                if (p.mask) v *= *reinterpret_cast<const f32x4 *>(Md + q * 4);
+                if (do_bias) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                *reinterpret_cast<f32x4 *>(Ds + r * DP + q * 4) = v;
+            }
+        }
+    };
+    const float *xa = Xs + (wave * 16 + lrow) * XP + lk * 4;
+    const float *db_ = Ds + lrow * DP + lk * 4;
+    auto compute = [&]() {
+        f32x4 av[2][NA], bv[2][4];
+        auto fetch = [&](int g, int sl) {
+#pragma unroll
+            for (int n = 0; n < NA; ++n) av[sl][n] = *reinterpret_cast<const f32x4 *>(xa + g * 16 + n * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[sl][i] = *reinterpret_cast<const f32x4 *>(db_ + i * 16 * DP + g * 16);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (g + 1 < NGRP) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int sl = g & 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[tp][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sl][(j + tp + OFF) >> 2][(j + tp + OFF) & 3],
+                                                                          bv[sl][i][j], acc[tp][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    GLOWTTS_TRACE_POINT_Z(0);
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk();
+    }
+    __syncthreads();
+    GLOWTTS_TRACE_POINT_Z(1);
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk(c + 1);
+        compute();
+        if (c == 0) GLOWTTS_TRACE_POINT_Z(2);
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+        if (c == 0) GLOWTTS_TRACE_POINT_Z(3);
+    }
+    GLOWTTS_TRACE_POINT_Z(4);
+    if (k0 + 64 <= p.Cin && m0 + 64 <= p.M) {         // whole tile inside (workgroup-uniform): no per-lane predicates
+        float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    atomicAdd(base + ((long)tp * p.Cin + reg) * p.M + i * 16, acc[tp][i][reg]);
+    } else {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = k0 + wave * 16 + lk * 4 + reg;
+                    const int m = m0 + i * 16 + lrow;
+                    if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+                }
+    }
+    if (do_bias) {
+        float *rowacc = smem;                           // the image is dead: every wave passed the last barrier
+        if (tid < 64) rowacc[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < D4) atomicAdd(rowacc + idx / (CT / 4), bsum[i]);
+        }
+        __syncthreads();
+        if (tid < 64 && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
+    }
+    GLOWTTS_TRACE_POINT_Z(10);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // weight packing (+ weight norm) and its backward; row sums for bias gradients
 // ------------------------------------------------------------------------------------------------------------
 // one workgroup per output channel o:  w[o] = v[o] * g[o] / ||v[o]||  (torch.nn.utils.weight_norm, dim 0) or w = v
@@ -962,6 +1179,30 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     return n5 ? dispatch_taps<1, 5, EPI>(p, s, pipe_ok) : dispatch_taps<1, 4, EPI>(p, s, pipe_ok);
 }
 
+template <int TAPS, int NGRP>
+static int launch_wrw_fp(ConvWrwParams &p, hipStream_t s) {
+    constexpr int CT = 16 * NGRP;
+    constexpr size_t lds = ((size_t)64 * cpitch4(CT + 16) + (size_t)64 * cpitch4(CT) + (CT + 16) + CT) * sizeof(float);
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static size_t attr_max_e = 0;
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_fp_kernel<TAPS, NGRP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
+    // all workgroups resident at once (2 per CU: 512 slots); p.nb = chunks of CT frames per workgroup
+    const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);
+    const int total = p.B * ((p.T + CT - 1) / CT);
+    int splits = 512 / tiles;
+    if (splits > total) splits = total;
+    if (splits < 1) splits = 1;
+    p.nb = (total + splits - 1) / splits;
+    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
+    hipLaunchKernelGGL((convwrw_fp_kernel<TAPS, NGRP>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
+}
+
 template <int TAPS, int CT>
 static int launch_wrw_pipe(ConvWrwParams &p, hipStream_t s) {
     constexpr size_t lds = 2 * ((size_t)64 * cpitch2(CT + 16) + (size_t)64 * cpitch2(CT)) * sizeof(float);
@@ -1056,6 +1297,12 @@ extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long 
                          (!mask || aligned16(mask)) && (!mask_x || aligned16(mask_x)) && ((taps - 1) * dil <= 12);
     if (pipe_ok && (taps == 1 || taps == 3 || taps == 5)) {
         hipStream_t s = (hipStream_t)stream;
+        if (dil == 1 && pad == (taps - 1) / 2) {         // frame-packed kernel: 80-frame chunks, or 64 when that wastes less
+            const bool n5 = (T % 80 == 0) || ((T + 79) / 80) * 80 <= ((T + 63) / 64) * 64;
+            if (taps == 5) return n5 ? launch_wrw_fp<5, 5>(p, s) : launch_wrw_fp<5, 4>(p, s);
+            if (taps == 3) return n5 ? launch_wrw_fp<3, 5>(p, s) : launch_wrw_fp<3, 4>(p, s);
+            return n5 ? launch_wrw_fp<1, 5>(p, s) : launch_wrw_fp<1, 4>(p, s);
+        }
         const bool c40 = (T % 40 == 0);
         if (taps == 5) return c40 ? launch_wrw_pipe<5, 40>(p, s) : launch_wrw_pipe<5, 32>(p, s);
         if (taps == 3) return c40 ? launch_wrw_pipe<3, 40>(p, s) : launch_wrw_pipe<3, 32>(p, s);

@@ -152,3 +152,64 @@ def call(name: str, *args, tag: Optional[str] = None) -> None:
     if rc != 0:
         msg = lib.glowtts_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class _ZeroArena:
+    """Zero-initialised scratch for ONE training step: accumulators the kernels add into with atomics (packed weight
+    gradients, log-determinants, loss sums) are carved out of one buffer that a step clears with ONE fill instead of
+    ~100 `torch.zeros` launches.  Only temporaries that die inside the step live here — never a tensor handed to
+    autograd as a parameter gradient (AccumulateGrad may keep such a tensor as `param.grad`)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.off = 0          # floats handed out in the current step
+        self.want = 0         # floats requested in the current step (sizes the buffer of the next one)
+        self.active = False
+
+    def begin(self, device) -> None:
+        if self.want and (self.buf is None or self.buf.device != torch.device(device) or self.want > self.buf.numel()):
+            if not torch.cuda.is_current_stream_capturing():
+                self.buf = torch.empty(int(self.want * 1.25) + 1024, device=device, dtype=torch.float32)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.off, self.want, self.active = 0, 0, True
+
+    def end(self) -> None:
+        self.active = False
+
+    def zeros(self, shape, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        span = (n + 63) // 64 * 64                      # 256-byte granules keep every carve-out 16-byte aligned
+        if self.active:
+            self.want += span
+            if self.buf is not None and self.buf.device == torch.device(device) and self.off + span <= self.buf.numel():
+                out = self.buf[self.off: self.off + n].view(shape)
+                self.off += span
+                return out
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+_arena = _ZeroArena()
+
+
+class zero_scope:
+    """`with zero_scope(device):` brackets one training step (train.train_batch); inside it `scratch_zeros` carves from
+    the arena, outside it is plain `torch.zeros`."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        _arena.begin(self.device)
+        return self
+
+    def __exit__(self, *exc):
+        _arena.end()
+        return False
+
+
+def scratch_zeros(shape, device) -> torch.Tensor:
+    return _arena.zeros(tuple(shape) if not isinstance(shape, int) else (shape,), device)

@@ -14,7 +14,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ._hip import call, f32, ptr
+from ._hip import call, f32, ptr, scratch_zeros
 
 # parameters whose .grad was written directly by a backward (no AccumulateGrad node runs for them); a data-parallel
 # reducer subscribes here to learn that a gradient is complete (parallel.FlowBlockReducer)
@@ -104,7 +104,7 @@ def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, 
     B, cin, T = x.shape
     cout = d.shape[1]
     if dwp is None:
-        dwp = torch.zeros(dwp_shape, device=d.device, dtype=torch.float32)
+        dwp = scratch_zeros(dwp_shape, d.device)
     call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(m2_for_x), ptr(dwp),
          None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad, tag=f"M{cout} K{cin}x{taps} N{B}x{T}")
     if not unpack:
@@ -275,7 +275,7 @@ class WNFn(Function):
         plan.pack()
         drop_all = None
         if p_drop > 0.0:
-            drop_all = (torch.rand(n_layers, B, 2 * H, T, device=dev) >= p_drop).to(torch.uint8)
+            drop_all = (torch.rand(n_layers, B, 2 * H, T, device=dev) >= p_drop).view(torch.uint8)   # bool storage is 0/1 bytes
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             taps = in_v.shape[2]

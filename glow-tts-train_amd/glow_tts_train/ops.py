@@ -173,7 +173,7 @@ class CouplingFn(Function):
         x, out = f32(_c(x)), f32(_c(out))
         B, C, T = x.shape
         z = torch.empty_like(x)
-        logdet = torch.zeros(B, device=x.device, dtype=torch.float32)
+        logdet = _hip.scratch_zeros((B,), x.device)
         call("glowtts_coupling_fwd", ptr(x), ptr(out), ptr(m2), ptr(z), ptr(logdet), B, C, T, int(sigmoid_scale), 0)
         ctx.save_for_backward(x, out, m2)
         ctx.sig = int(sigmoid_scale)
@@ -345,7 +345,7 @@ class MleLossFn(Function):
     def forward(ctx, z, m, logs, logdet, m2):
         z, m, logs = f32(_c(z)), f32(_c(m)), f32(_c(logs))
         B, C, T = z.shape
-        acc = torch.zeros(2, device=z.device, dtype=torch.float32)
+        acc = _hip.scratch_zeros((2,), z.device)
         call("glowtts_mle_fwd", ptr(z), ptr(m), ptr(logs), ptr(m2), ptr(acc), B, C, T)
         denom = acc[1] * C
         loss = (acc[0] - logdet.sum()) / denom + _HALF_LOG_2PI
@@ -390,7 +390,7 @@ class RelAttnFn(Function):
         share = int((not has_rel) or emb_k.shape[0] == 1)
         drop = None
         if p_drop > 0.0:
-            drop = (torch.rand(B, n_heads, T, T, device=q.device) >= p_drop).to(torch.uint8)
+            drop = (torch.rand(B, n_heads, T, T, device=q.device) >= p_drop).view(torch.uint8)
         p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0

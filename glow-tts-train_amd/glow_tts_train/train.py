@@ -11,6 +11,7 @@ import typing
 
 import torch
 
+from ._hip import zero_scope
 from .utils import clip_grad_value_, duration_loss, mle_loss, to_gpu
 
 
@@ -18,14 +19,16 @@ def train_batch(model, optimizer, batch, grad_clip: float, reducer=None) -> torc
     """One optimisation step on one already-resident batch; returns the (device) loss tensor, un-synchronised."""
     x, x_lengths, y, y_lengths, speaker_ids = batch
     optimizer.zero_grad()
-    (z, z_m, z_logs, logdet, z_mask), _, (_attn, logw, logw_) = model(x, x_lengths, y, y_lengths, g=speaker_ids)
-    loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, x_lengths)
-    loss.backward()
-    if reducer is not None:
-        reducer.finish()
+    with zero_scope(y.device):          # the step's atomically-accumulated temporaries share one zero fill
+        (z, z_m, z_logs, logdet, z_mask), _, (_attn, logw, logw_) = model(x, x_lengths, y, y_lengths, g=speaker_ids)
+        loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, x_lengths)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        loss = loss.detach()
     clip_grad_value_(model.parameters(), grad_clip)
     optimizer.step()
-    return loss.detach()
+    return loss
 
 
 class GraphedTrainStep:

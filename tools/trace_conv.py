@@ -38,7 +38,11 @@ fns = {
     "resskip": lambda: call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(b_in), ptr(m2), ptr(x), ptr(sk), ptr(xo), ptr(sk), B, H, T, 0),
     "bwd_data5": lambda: convops.conv_fwd(d2, wb_in, None, None, dx, 2 * H, H, 5, 1, 2, addend=d2[:, :H]),
     "bwd_data1": lambda: convops.conv_fwd(d2, wb_rs, None, None, dx, 2 * H, H, 1, 1, 0),
+    "wrw5": lambda: call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp5), None, B, H, 2 * H, T, 5, 1, 2),
+    "wrw1": lambda: call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp1), None, B, H, 2 * H, T, 1, 1, 0),
 }
+dwp5 = torch.zeros(5, H, 2 * H, device=dev)
+dwp1 = torch.zeros(1, H, 2 * H, device=dev)
 fn = fns[which]
 lib = _hip.load()
 rd = lib.glowtts_debug_trace_read
