@@ -132,24 +132,11 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")
+def build_workload(args, dev, rank):
+    """BASELINE.json configs[1] (or the sizes on the command line): random-init model + optimizer, one synthetic batch
+    resident on `dev`, data-dependent ActNorm init done.  Returns (model, optimizer, batch, cfg)."""
+    from glow_tts_train import config, models
 
-    from glow_tts_train import _hip, config, models, parallel
-    from glow_tts_train.train import GraphedTrainStep, train_batch
-
-    _hip.load()
     B, T_mel = args.batch, args.t_mel
     T_text = args.t_text or T_mel // 5
     cfg = config.TrainingConfig()
@@ -180,6 +167,31 @@ def main():
         model(x, x_lengths, y, y_lengths)
     torch.cuda.synchronize()
     log("data-dependent init forward done")
+    return model, opt, batch, cfg
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    from glow_tts_train import _hip, parallel
+    from glow_tts_train.train import GraphedTrainStep, train_batch
+
+    _hip.load()
+    model, opt, batch, cfg = build_workload(args, dev, rank)
+    B, T_mel = args.batch, args.t_mel
+    T_text = args.t_text or T_mel // 5
+    x, x_lengths, y, y_lengths, _ = batch
     reducer = parallel.FlowBlockReducer(model, opt) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_parameters(0)

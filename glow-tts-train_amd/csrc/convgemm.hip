@@ -40,7 +40,7 @@ __device__ unsigned long long g_trace[8192 * 16];
 #define GLOWTTS_TRACE_POINT_Z(i) do { } while (0)
 #endif
 
-enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_ADD = 4 };
+enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_ADD = 4, EPI_GATEBWD = 5 };
 
 struct ConvGemmParams {
     const float *x;          // (B, Cin, T) activations, batch stride x_bs elements
@@ -48,7 +48,7 @@ struct ConvGemmParams {
     const float *bias;       // [M] or null
     const float *mask;       // (B, T) or null (applied where the epilogue says so)
     const float *cond;       // EPI_GATE: (B, 2H) conditioning added before the gate, or null
-    const float *r0;         // EPI_RESSKIP: x_in (B,H,T) ; EPI_ADD: addend (B,M,T)
+    const float *r0;         // EPI_RESSKIP: x_in (B,H,T) ; EPI_ADD: addend (B,M,T) ; EPI_GATEBWD: stored tanh/sigmoid (B,2H,T)
     const float *r1;         // EPI_RESSKIP / _LAST: skip_in (B,H,T) or null
     const unsigned char *drop;  // EPI_GATE: dropout keep-mask (B,2H,T) bytes or null
     float *y0;               // PLAIN/ADD: y (B,M,T), batch stride y_bs ; GATE: acts (B,H,T) ; RESSKIP: x_out (B,H,T)
@@ -127,6 +127,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                     // last layer: all H rows go to the skip sum, and WN's final `output * x_mask` is folded in (:161-162)
                     const long o = ((long)b * p.H + row) * p.T + t;
                     p.y1[o] = ((p.r1 ? p.r1[o] : 0.f) + v) * m;
+                } else if (EPI == EPI_GATEBWD) {
+                    // v = d(acts): chain through acts = tanh * sigmoid with the STORED values, then through the
+                    // forward's dropout (utils.py:31-38, layers.py:147) -> d(pre-activation) rows ch and H + ch
+                    const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
+                    const float th = p.r0[ot], sg = p.r0[os];
+                    float dt = v * sg * (1.0f - th * th), ds = v * th * sg * (1.0f - sg);
+                    if (p.drop) {
+                        dt = p.drop[ot] ? dt * p.drop_scale : 0.f;
+                        ds = p.drop[os] ? ds * p.drop_scale : 0.f;
+                    }
+                    p.y0[ot] = dt;
+                    p.y0[os] = ds;
                 }
             }
         }
@@ -309,6 +321,27 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
             const long o = ((long)b * p.H + row) * p.T + t;
             const float4 si = p.r1 ? ld4(p.r1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             st4(p.y1 + o, make_float4((si.x + v.x) * m.x, (si.y + v.y) * m.y, (si.z + v.z) * m.z, (si.w + v.w) * m.w));
+        } else if (EPI == EPI_GATEBWD) {
+            const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
+            const float4 th4 = ld4(p.r0 + ot), sg4 = ld4(p.r0 + os);
+            const float go[4] = {v.x, v.y, v.z, v.w}, th[4] = {th4.x, th4.y, th4.z, th4.w}, sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+            float dt[4], ds[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dt[j] = go[j] * sg[j] * (1.0f - th[j] * th[j]);
+                ds[j] = go[j] * th[j] * sg[j] * (1.0f - sg[j]);
+            }
+            if (p.drop) {
+                const uchar4 kt = *reinterpret_cast<const uchar4 *>(p.drop + ot), ks = *reinterpret_cast<const uchar4 *>(p.drop + os);
+                const unsigned char kta[4] = {kt.x, kt.y, kt.z, kt.w}, ksa[4] = {ks.x, ks.y, ks.z, ks.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dt[j] = kta[j] ? dt[j] * p.drop_scale : 0.f;
+                    ds[j] = ksa[j] ? ds[j] * p.drop_scale : 0.f;
+                }
+            }
+            st4(p.y0 + ot, make_float4(dt[0], dt[1], dt[2], dt[3]));
+            st4(p.y0 + os, make_float4(ds[0], ds[1], ds[2], ds[3]));
         }
     }
 }
@@ -1282,6 +1315,19 @@ extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, con
     p.x_bs = (long)H * T; p.B = B; p.Cin = H; p.M = M; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
     return last ? dispatch_convgemm<EPI_RESSKIP_LAST>(p, (hipStream_t)stream)
                 : dispatch_convgemm<EPI_RESSKIP>(p, (hipStream_t)stream);
+}
+
+extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *wp_b, const float *ts, const unsigned char *drop,
+                                     float drop_scale, float *d_pre, int B, int M_rs, int H, int T,
+                                     glowtts_stream_t stream) {
+    if (int rc = check_conv_common("glowtts_conv_gate_bwd", d_rs, wp_b, B, M_rs, H, T, 1, 1, 0)) return rc;
+    GLOWTTS_CHECK_ARG(ts && d_pre, "glowtts_conv_gate_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(H % 4 == 0, "glowtts_conv_gate_bwd: hidden width %d must be a multiple of 4", H);
+    if ((long)B * T == 0) return 0;
+    ConvGemmParams p{};
+    p.x = d_rs; p.wp = wp_b; p.r0 = ts; p.drop = drop; p.drop_scale = drop_scale; p.y0 = d_pre;
+    p.x_bs = (long)M_rs * T; p.B = B; p.Cin = M_rs; p.M = H; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
+    return dispatch_convgemm<EPI_GATEBWD>(p, (hipStream_t)stream);
 }
 
 extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask,

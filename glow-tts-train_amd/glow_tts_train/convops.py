@@ -275,7 +275,7 @@ class WNFn(Function):
         plan.pack()
         drop_all = None
         if p_drop > 0.0:
-            drop_all = (torch.rand(n_layers, B, 2 * H, T, device=dev) >= p_drop).view(torch.uint8)   # bool storage is 0/1 bytes
+            drop_all = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             taps = in_v.shape[2]
@@ -337,17 +337,22 @@ class WNFn(Function):
                 dskip = d_rs                          # d(skip_in) of the last layer carries the folded mask
             _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3), sink.buf(6 * i + 4),
                           sink.buf(6 * i + 5), 1, 1, 0, dwp=plan.dwp_view(2 * i + 1), unpack=not sink.direct)
-            d_acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
-            conv_fwd(d_rs, wb_rs, None, None, d_acts, m_rs, H, 1, 1, 0)
             d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
-            call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), ptr(drops[i]), scale, ptr(d_xin), B, H, T)
-            if has_cond:
-                if drops[i] is None:
+            if has_cond and drops[i] is not None:
+                # conditioning is added after the dropout: its gradient is the un-dropped pre-activation gradient, so
+                # d(acts) is needed twice and is materialised
+                d_acts = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+                conv_fwd(d_rs, wb_rs, None, None, d_acts, m_rs, H, 1, 1, 0)
+                call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), ptr(drops[i]), scale, ptr(d_xin), B, H, T)
+                tmp = torch.empty_like(d_xin)
+                call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), None, 1.0, ptr(tmp), B, H, T)
+                dconds[i] = tmp.sum(-1)
+            else:
+                # d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs): one kernel, d(acts) stays on chip
+                call("glowtts_conv_gate_bwd", ptr(d_rs), ptr(wb_rs), ptr(ts), ptr(drops[i]), scale, ptr(d_xin), B, m_rs, H, T,
+                     tag=f"M{H} K{m_rs}x1 N{B}x{T}")
+                if has_cond:
                     dconds[i] = d_xin.sum(-1)
-                else:  # conditioning is added after the dropout: its gradient is the un-dropped pre-activation gradient
-                    tmp = torch.empty_like(d_xin)
-                    call("glowtts_gate_bwd_ts", ptr(ts), ptr(d_acts), None, 1.0, ptr(tmp), B, H, T)
-                    dconds[i] = tmp.sum(-1)
             _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i), sink.buf(6 * i + 1),
                           sink.buf(6 * i + 2), taps, dil, pad, dwp=plan.dwp_view(2 * i), unpack=not sink.direct)
             dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)

@@ -390,7 +390,7 @@ class RelAttnFn(Function):
         share = int((not has_rel) or emb_k.shape[0] == 1)
         drop = None
         if p_drop > 0.0:
-            drop = (torch.rand(B, n_heads, T, T, device=q.device) >= p_drop).view(torch.uint8)
+            drop = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
         p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0

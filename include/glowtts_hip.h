@@ -145,7 +145,10 @@ int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *m
  *                 and, if dbias != NULL, dbias[m] += sum_{b,t} d[b,m,t] (* mask)  (the bias gradient, same pass)
  * unpack_weight_grad : packed gradient -> dv (+= , weight layout [Cout][Cin][taps]) and dg (+=) through the weight norm
  * rowsum        : out[m] += sum_{b,t} d[b,m,t] (* mask)                                  (bias gradients, accumulated)
- * gate_bwd_ts   : da (B,2H,T) from dacts (B,H,T) and the saved ts; the forward's dropout mask is re-applied */
+ * gate_bwd_ts   : da (B,2H,T) from dacts (B,H,T) and the saved ts; the forward's dropout mask is re-applied
+ * conv_gate_bwd : the backward of "res/skip 1x1 conv after the gate" in one kernel (layers.py:152-156 backwards):
+ *                 dacts = W_rs^T d_rs (backward-data of the 1x1 conv, packed wp_b, d_rs is (B, M_rs, T)), then
+ *                 gate_bwd_ts in the epilogue -> d_pre (B,2H,T); dacts never reaches HBM */
 int glowtts_conv_fwd(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
                      const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T, int taps,
                      int dil, int pad, int mask_in, int mask_out, int mask_add, glowtts_stream_t stream);
@@ -155,6 +158,8 @@ int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, co
 int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
                               const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B, int H, int T,
                               int last, glowtts_stream_t stream);
+int glowtts_conv_gate_bwd(const float *d_rs, const float *wp_b, const float *ts, const unsigned char *drop,
+                          float drop_scale, float *d_pre, int B, int M_rs, int H, int T, glowtts_stream_t stream);
 int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, const float *mask_x,
                      float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
                      glowtts_stream_t stream);

@@ -651,7 +651,7 @@ def test_wn_dropout_path_matches_manual_mask(G):
     (out * r).sum().backward()
     # manual: same RNG stream, same order
     torch.manual_seed(99)
-    keeps = list((torch.rand(L, b, 2 * H, t, device="cuda") >= p).float())      # one generator call for all layers
+    keeps = list(torch.empty(L, b, 2 * H, t, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p).float())  # one generator call
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in wn.state_dict().items()}
     xo = x.detach().cpu().clone().requires_grad_(True)
     cur, skip = xo, 0
@@ -689,7 +689,7 @@ def test_attention_dropout_matches_manual_mask(G):
     got = [x.grad.clone()] + [p_.grad.clone() for p_ in f.parameters()]
     # reference: the general torch path with nn.Dropout replaced by the same keep mask
     torch.manual_seed(77)
-    keep = (torch.rand(b, 2, t, t, device="cuda") >= p).float() / (1 - p)
+    keep = torch.empty(b, 2, t, t, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p).float() / (1 - p)
     x.grad = None
     f.zero_grad()
 
