@@ -178,11 +178,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo with fewer GPUs than ranks is a rehearsal of the N>1 control flow on a
+    # one-GPU box (ranks share the card, collectives staged by gloo) — never a measurement
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPUs visible")
+    local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=backend, init_method="env://")
 
     from glow_tts_train import _hip, parallel
     from glow_tts_train.train import GraphedTrainStep, train_batch

@@ -255,7 +255,24 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
     auto ld4 = [](const float *q) { return *reinterpret_cast<const float4 *>(q); };
     auto st4 = [](float *q, float4 v) { *reinterpret_cast<float4 *>(q) = v; };
     if (EPI == EPI_GATE) {
-        for (int idx = tid; idx < 64 * Q; idx += 256) {
+        constexpr int NG = (64 * Q) / 256;               // = NCT items per thread; keep-mask bytes are fetched up front
+        unsigned int kt[NG], ks[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
+            const int lr = idx / Q, q = idx - lr * Q;
+            const int ch = tile_m * 64 + lr, t = t0 + q * 4;
+            const bool ok = ch < p.H && t < p.T;
+            const long ot = ((long)b * 2 * p.H + (ok ? ch : 0)) * p.T + (ok ? t : 0);
+            kt[i] = ks[i] = 0x01010101u;
+            if (p.drop) {
+                kt[i] = *reinterpret_cast<const unsigned int *>(p.drop + ot);
+                ks[i] = *reinterpret_cast<const unsigned int *>(p.drop + ot + (long)p.H * p.T);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
             const int lr = idx / Q, q = idx - lr * Q;
             const int ch = tile_m * 64 + lr;
             const int t = t0 + q * 4;
@@ -266,14 +283,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
             const long os = ot + (long)p.H * p.T;
             float pt[4] = {vt.x + bt, vt.y + bt, vt.z + bt, vt.w + bt};
             float ps[4] = {vs.x + bs, vs.y + bs, vs.z + bs, vs.w + bs};
-            if (p.drop) {
-                const uchar4 kt = *reinterpret_cast<const uchar4 *>(p.drop + ot);
-                const uchar4 ks = *reinterpret_cast<const uchar4 *>(p.drop + os);
-                const unsigned char kta[4] = {kt.x, kt.y, kt.z, kt.w}, ksa[4] = {ks.x, ks.y, ks.z, ks.w};
+            if (p.drop) {   // dropout on the pre-activation (layers.py:147), keep-mask generated by the host RNG
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pt[j] = kta[j] ? pt[j] * p.drop_scale : 0.f;
-                    ps[j] = ksa[j] ? ps[j] * p.drop_scale : 0.f;
+                    pt[j] = ((kt[i] >> (8 * j)) & 0xffu) ? pt[j] * p.drop_scale : 0.f;
+                    ps[j] = ((ks[i] >> (8 * j)) & 0xffu) ? ps[j] * p.drop_scale : 0.f;
                 }
             }
             if (p.cond) {
@@ -292,52 +306,82 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         }
         return;
     }
-    for (int idx = tid; idx < WGR * Q; idx += 256) {
+    // WGR * Q = 256 * RTW * NCT float4 items, NI per thread.  Phase 1 issues EVERY global read of the epilogue (residual
+    // inputs, stored tanh / sigmoid, masks) back to back; phase 2 combines them with the LDS tile and stores.  (As one
+    // run-time loop the compiler kept a single load in flight per iteration: 10 serial HBM round trips = 10 us on the
+    // res/skip conv, more than its MFMA time.)
+    constexpr int NI = RTW * NCT;
+    float4 ra[NI], rb[NI], rm[NI];
+    unsigned int ka[NI], kb[NI];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + i * 256;
         const int lr = idx / Q, q = idx - lr * Q;
-        const int row = tile_m * WGR + lr;
-        const int t = t0 + q * 4;
+        const int row = tile_m * WGR + lr, t = t0 + q * 4;
+        const bool ok = row < p.M && t < p.T;
+        const int rc = ok ? row : 0, tc = ok ? t : 0;               // clamped: always a valid address
+        ra[i] = zero4; rb[i] = zero4; ka[i] = 0x01010101u; kb[i] = 0x01010101u;
+        rm[i] = mk ? ld4(mk + tc) : one4;
+        if (EPI == EPI_ADD) {
+            ra[i] = ld4(p.r0 + (long)b * p.r_bs + (long)rc * p.T + tc);
+        } else if (EPI == EPI_RESSKIP) {
+            const bool res = rc < p.H;
+            const long o = ((long)b * p.H + (res ? rc : rc - p.H)) * p.T + tc;
+            const float *src = res ? p.r0 : (p.r1 ? p.r1 : p.r0);
+            ra[i] = ld4(src + o);
+            if (!res && !p.r1) ra[i] = zero4;
+        } else if (EPI == EPI_RESSKIP_LAST) {
+            if (p.r1) ra[i] = ld4(p.r1 + ((long)b * p.H + rc) * p.T + tc);
+        } else if (EPI == EPI_GATEBWD) {
+            const long ot = ((long)b * 2 * p.H + rc) * p.T + tc, os = ot + (long)p.H * p.T;
+            ra[i] = ld4(p.r0 + ot);
+            rb[i] = ld4(p.r0 + os);
+            if (p.drop) {
+                ka[i] = *reinterpret_cast<const unsigned int *>(p.drop + ot);
+                kb[i] = *reinterpret_cast<const unsigned int *>(p.drop + os);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int idx = tid + i * 256;
+        const int lr = idx / Q, q = idx - lr * Q;
+        const int row = tile_m * WGR + lr, t = t0 + q * 4;
         if (row >= p.M || t >= p.T) continue;
         float4 v = ld4(Ls + lr * LP + q * 4);
         if (p.bias) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
-        float4 m = mk ? ld4(mk + t) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 m = rm[i], a = ra[i];
         if (EPI == EPI_PLAIN) {
             if (p.mask_out) { v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
             st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, v);
         } else if (EPI == EPI_ADD) {
-            float4 a = ld4(p.r0 + (long)b * p.r_bs + (long)row * p.T + t);
-            if (p.mask_add) { a.x *= m.x; a.y *= m.y; a.z *= m.z; a.w *= m.w; }
-            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w));
+            float4 ad = a;
+            if (p.mask_add) { ad.x *= m.x; ad.y *= m.y; ad.z *= m.z; ad.w *= m.w; }
+            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w));
         } else if (EPI == EPI_RESSKIP) {
             if (row < p.H) {
                 const long o = ((long)b * p.H + row) * p.T + t;
-                const float4 xi = ld4(p.r0 + o);
-                st4(p.y0 + o, make_float4((xi.x + v.x) * m.x, (xi.y + v.y) * m.y, (xi.z + v.z) * m.z, (xi.w + v.w) * m.w));
+                st4(p.y0 + o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
             } else {
                 const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
-                const float4 si = p.r1 ? ld4(p.r1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-                st4(p.y1 + o, make_float4(si.x + v.x, si.y + v.y, si.z + v.z, si.w + v.w));
+                st4(p.y1 + o, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
             }
         } else if (EPI == EPI_RESSKIP_LAST) {
             const long o = ((long)b * p.H + row) * p.T + t;
-            const float4 si = p.r1 ? ld4(p.r1 + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            st4(p.y1 + o, make_float4((si.x + v.x) * m.x, (si.y + v.y) * m.y, (si.z + v.z) * m.z, (si.w + v.w) * m.w));
+            st4(p.y1 + o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
         } else if (EPI == EPI_GATEBWD) {
+            // v = d(acts): chain through acts = tanh * sigmoid with the STORED values, then through the forward's dropout
             const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
-            const float4 th4 = ld4(p.r0 + ot), sg4 = ld4(p.r0 + os);
-            const float go[4] = {v.x, v.y, v.z, v.w}, th[4] = {th4.x, th4.y, th4.z, th4.w}, sg[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+            const float go[4] = {v.x, v.y, v.z, v.w}, th[4] = {a.x, a.y, a.z, a.w}, sg[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
             float dt[4], ds[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dt[j] = go[j] * sg[j] * (1.0f - th[j] * th[j]);
-                ds[j] = go[j] * th[j] * sg[j] * (1.0f - sg[j]);
-            }
-            if (p.drop) {
-                const uchar4 kt = *reinterpret_cast<const uchar4 *>(p.drop + ot), ks = *reinterpret_cast<const uchar4 *>(p.drop + os);
-                const unsigned char kta[4] = {kt.x, kt.y, kt.z, kt.w}, ksa[4] = {ks.x, ks.y, ks.z, ks.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dt[j] = kta[j] ? dt[j] * p.drop_scale : 0.f;
-                    ds[j] = ksa[j] ? ds[j] * p.drop_scale : 0.f;
+            for (int jj = 0; jj < 4; ++jj) {
+                dt[jj] = go[jj] * sg[jj] * (1.0f - th[jj] * th[jj]);
+                ds[jj] = go[jj] * th[jj] * sg[jj] * (1.0f - sg[jj]);
+                if (p.drop) {
+                    dt[jj] = ((ka[i] >> (8 * jj)) & 0xffu) ? dt[jj] * p.drop_scale : 0.f;
+                    ds[jj] = ((kb[i] >> (8 * jj)) & 0xffu) ? ds[jj] * p.drop_scale : 0.f;
                 }
             }
             st4(p.y0 + ot, make_float4(dt[0], dt[1], dt[2], dt[3]));
