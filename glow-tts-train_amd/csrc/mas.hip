@@ -14,8 +14,8 @@
 //     Waves 1..3 therefore stage 64-column tiles through LDS with coalesced 256-byte row reads, transposing on
 //     the LDS write (odd row pitch => conflict-free), double-buffered so staging tile k+1 overlaps the DP on k;
 //   * the back-pointer of cell (x, y) is one bit; each lane packs 32 columns per row into a register and spills
-//     one word per 32 columns to LDS, so the backtrack is a single lane chasing bits in LDS and only re-reads a
-//     word when its row or 32-column block changes;
+//     one word per 32 columns to LDS; the backtrack is a single lane that jumps from row change to row change with
+//     clz on those words (~Tx + Ty/32 steps) and records the first frame of every text row;
 //   * the 0/1 path is written by all four waves with coalesced 16-byte stores (no pre-zeroing pass).
 //
 // HBM traffic (algorithmic): 4 B read per in-band cell + 4 B written per path cell.
@@ -25,11 +25,14 @@ namespace glowtts {
 
 constexpr float kMasNeg = -1e9f;
 
-__device__ __forceinline__ float dpp_wave_shr1(float v) {
-    // v_mov_b32_dpp wave_shr:1 — lane i receives lane i-1's value (lane 0 keeps `old` = 0).
-    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false);
-    return __int_as_float(r);
-}
+#ifdef GLOWTTS_TRACE   // tuning builds only: phase timestamps per utterance (100 MHz wall clock)
+__device__ unsigned long long g_mas_trace[1024 * 8];
+#define MAS_TRACE(i) do { if (threadIdx.x == 0) g_mas_trace[(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MAS_TRACE(i) do { } while (0)
+#endif
+
+// v_mov_b32_dpp wave_shr:1 (control 0x138): lane i receives lane i-1's value, lane 0 keeps the `old` operand.
 
 template <int R>
 __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ value, float *__restrict__ path,
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     const int TC = 1 << log2tc;
     float *tile = reinterpret_cast<float *>(smem);                                // [2][TC][ROWPAD]
     uint32_t *dirs = reinterpret_cast<uint32_t *>(tile + 2 * TC * ROWPAD);        // [R][nblk32][64]
-    short *idx = reinterpret_cast<short *>(dirs + R * nblk32 * 64);               // [Ty]
+    int *first = reinterpret_cast<int *>(dirs + R * nblk32 * 64);                 // [Tx + 1]: first frame of every text row
 
     const int b = blockIdx.x;
     int tx = t_xs[b], ty = t_ys[b];
@@ -69,49 +72,92 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
         }
     };
 
-    if (wave != 0 && ntiles > 0) stage(0);
+    // 16-byte variant (Ty % 4 == 0, aligned rows, TC >= 16): a lane fetches 4 consecutive frames of one row, 64 / (TC/4)
+    // rows per wave-instruction, and EVERY load of the tile is issued before the first LDS write — one HBM round trip
+    // per tile instead of one per 8 rows (the scalar loop above made the staging, not the DP, the critical path:
+    // 160 rows / 3 waves / 8 in flight = 7 round trips x 13 tiles).
+    const bool vec_ok = ((Ty & 3) == 0) && ((reinterpret_cast<uintptr_t>(value) & 15u) == 0) && (log2tc >= 4);
+    auto stage4 = [&](int k) {
+        constexpr int MAXL = 16;                       // loads in flight per lane (covers Tx <= 768 at TC = 64)
+        const int y0 = k << log2tc;
+        int xlo = tx + y0 - ty;
+        xlo = xlo < 0 ? 0 : xlo;
+        int xhi = y0 + TC;
+        xhi = xhi > tx ? tx : xhi;
+        const int qpr = TC >> 2;                       // float4 per tile row
+        const int rpi = 64 / qpr;                      // rows per wave-instruction
+        const int sub = lane / qpr, q = lane - sub * qpr;
+        const int y = y0 + q * 4;
+        float *dst = tile + ((k & 1) * TC + q * 4) * ROWPAD;
+        const int xstart = xlo + (wave - 1) * rpi + sub, xstep = 3 * rpi;
+        for (int xb = xstart; xb < xhi; xb += MAXL * xstep) {
+            float4 t[MAXL];
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int x = xb + i * xstep;
+                t[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (x < xhi && y < Ty) t[i] = *reinterpret_cast<const float4 *>(val + (size_t)x * Ty + y);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int x = xb + i * xstep;
+                if (x < xhi) {
+                    float *d = dst + (x % R) * 64 + x / R;
+                    d[0] = (y + 0 < ty) ? t[i].x : 0.0f;
+                    d[ROWPAD] = (y + 1 < ty) ? t[i].y : 0.0f;
+                    d[2 * ROWPAD] = (y + 2 < ty) ? t[i].z : 0.0f;
+                    d[3 * ROWPAD] = (y + 3 < ty) ? t[i].w : 0.0f;
+                }
+            }
+        }
+    };
+    auto stage_any = [&](int k) { if (vec_ok) stage4(k); else stage(k); };
+
+    MAS_TRACE(0);
+    if (wave != 0 && ntiles > 0) stage_any(0);
 
     // ---- forward DP on wave 0 ---------------------------------------------------------------------------------
     float v[R];
     uint32_t dw[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { v[r] = 0.0f; dw[r] = 0u; }
-    // self-check of the DPP shift direction (wave-uniform); fall back to ds_bpermute if it is not "from lane-1"
-    const int probe = __builtin_amdgcn_update_dpp(0, lane, 0x138, 0xf, 0xf, false);
-    const bool dpp_ok = __all((lane == 0) || (probe == lane - 1));
 
     for (int k = 0; k < ntiles; ++k) {
         __syncthreads();
         if (wave != 0) {
-            if (k + 1 < ntiles) stage(k + 1);
+            if (k + 1 < ntiles) stage_any(k + 1);
         } else {
             const int y0 = k << log2tc;
             int ncols = ty - y0;
             ncols = ncols > TC ? TC : ncols;
             const float *tbase = tile + (k & 1) * TC * ROWPAD;
+            // Only in-band cells are ever read back: an in-band (x, y) takes v[x][y-1] and v[x-1][y-1], both in band (or the
+            // x == y / x == 0 sentinels), and the backtrack never leaves the band.  So rows outside the band may carry
+            // garbage values and bits, and the loop needs no band test at all — 8 vector instructions per row and column.
+            float cnext[R];                              // next column's cells, fetched one column ahead of their use
+#pragma unroll
+            for (int r = 0; r < R; ++r) cnext[r] = tbase[r * 64 + lane];
+            const float *trow = tbase + lane;
             for (int yl = 0; yl < ncols; ++yl) {
                 const int y = y0 + yl;
-                int lo = tx + y - ty;
-                lo = lo < 0 ? 0 : lo;
-                int hi = y + 1;
-                hi = hi > tx ? tx : hi;
-                const float *trow = tbase + yl * ROWPAD;
                 float cell[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) cell[r] = trow[r * 64 + lane];
-                const float up = dpp_ok ? dpp_wave_shr1(v[R - 1]) : __shfl_up(v[R - 1], 1, 64);
+                for (int r = 0; r < R; ++r) cell[r] = cnext[r];
+                if (yl + 1 < TC) trow += ROWPAD;
+#pragma unroll
+                for (int r = 0; r < R; ++r) cnext[r] = trow[r * 64];
+                // v[x-1] of this lane's first row: ONE DPP; lane 0 (x = 0) receives the sentinel of core.pyx:24-27
+                const float edge = (y == 0) ? 0.0f : kMasNeg;
+                const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v[R - 1]),
+                                                                            0x138, 0xf, 0xf, false));
 #pragma unroll
                 for (int r = R - 1; r >= 0; --r) {
                     const int x = lane * R + r;
-                    float vprev = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-                    if (x == 0) vprev = (y == 0) ? 0.0f : kMasNeg;
+                    const float vprev = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
                     const float vcur = (x == y) ? kMasNeg : v[r];
                     const bool take_prev = vprev > vcur;
-                    const float nv = (take_prev ? vprev : vcur) + cell[r];
-                    const bool inb = (x >= lo) && (x < hi);
-                    const bool move = inb && (x != 0) && (y > 0) && ((x == y) || take_prev);
-                    v[r] = inb ? nv : v[r];
-                    dw[r] |= (move ? 1u : 0u) << (y & 31);
+                    v[r] = (take_prev ? vprev : vcur) + cell[r];
+                    dw[r] |= ((x == y) || take_prev ? 1u : 0u) << (y & 31);
                 }
                 if ((y & 31) == 31 || y == ty - 1) {
 #pragma unroll
@@ -123,58 +169,82 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
             }
         }
     }
+    MAS_TRACE(1);
     __syncthreads();
+    MAS_TRACE(2);
 
-    // ---- backtrack: one lane chases the back-pointer bits (core.pyx:32-35) -----------------------------------
-    if (threadIdx.x == 0) {
-        int index = tx - 1;
-        int cblk = -1, cidx = -1;
-        uint32_t word = 0u;
-        for (int y = ty - 1; y >= 0; --y) {
-            idx[y] = (short)index;
-            if (index > 0 && y > 0) {
-                const int blk = y >> 5;
-                if (blk != cblk || index != cidx) {
-                    word = dirs[((index % R) * nblk32 + blk) * 64 + index / R];
-                    cblk = blk;
-                    cidx = index;
-                }
-                index -= (int)((word >> (y & 31)) & 1u);
+    // ---- backtrack (core.pyx:32-35).  The path is monotone: text row x owns the frames [first[x], first[x+1]).  One lane
+    // walks it row change by row change — the next frame at which the path steps down is the highest set bit at or
+    // below the current frame in the row's 32-frame bit word (clz), so the walk takes ~Tx + Ty/32 steps, not Ty; the
+    // word of the row below is fetched while the current row is walked.
+    for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = x >= tx ? ty : 0;
+    __syncthreads();
+    if (threadIdx.x == 0 && tx > 0 && ty > 0) {
+        auto word_of = [&](int row, int blk) -> uint32_t {
+            return row > 0 ? dirs[((row % R) * nblk32 + blk) * 64 + row / R] : 0u;
+        };
+        int index = tx - 1, y = ty - 1, blk = y >> 5;
+        uint32_t word = word_of(index, blk), below = word_of(index - 1, blk);
+        while (index > 0 && y > 0) {
+            uint32_t m = word & (0xffffffffu >> (31 - (y & 31)));
+            if (blk == 0) m &= ~1u;                       // no step at frame 0 (core.pyx:34 needs y > 0 ... index - 1 at y - 1)
+            if (m == 0) {                                 // the path stays on this row for the rest of the 32-frame block
+                if (blk == 0) break;
+                y = (blk << 5) - 1;
+                --blk;
+                word = word_of(index, blk);
+                below = word_of(index - 1, blk);
+                continue;
             }
+            y = (blk << 5) + (31 - __clz(m));             // frame at which the path leaves row `index` downwards
+            first[index] = y;
+            --index;
+            --y;
+            word = below;
+            if ((y >> 5) != blk) {                        // stepped across a block boundary (y >= 0 here)
+                blk = y >> 5;
+                word = word_of(index, blk);
+            }
+            below = word_of(index - 1, blk);
         }
     }
+    MAS_TRACE(3);
     __syncthreads();
 
     // ---- path write: all waves, coalesced -------------------------------------------------------------------------
     float *pb = path + (size_t)b * Tx * Ty;
     if ((Ty & 3) == 0 && ((reinterpret_cast<uintptr_t>(path) & 15u) == 0)) {
+        // thread = one quad of frames: its 4 path rows are read from LDS ONCE, then every text row gets one 16-byte
+        // store (consecutive threads -> consecutive addresses within a row)
         const int ty4 = Ty >> 2;
-        const int n4 = Tx * ty4;
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            const int x = i / ty4;
-            const int y = (i - x * ty4) << 2;
-            float4 o;
-            o.x = (y + 0 < ty && idx[y + 0] == x) ? 1.0f : 0.0f;
-            o.y = (y + 1 < ty && idx[y + 1] == x) ? 1.0f : 0.0f;
-            o.z = (y + 2 < ty && idx[y + 2] == x) ? 1.0f : 0.0f;
-            o.w = (y + 3 < ty && idx[y + 3] == x) ? 1.0f : 0.0f;
-            reinterpret_cast<float4 *>(pb)[i] = o;
+        for (int q = threadIdx.x; q < ty4; q += 256) {
+            const int y = q << 2;
+            float4 *dst = reinterpret_cast<float4 *>(pb) + q;
+            int lo = first[0];
+#pragma unroll 4
+            for (int x = 0; x < Tx; ++x) {
+                const int hi = first[x + 1];               // same address in every lane: an LDS broadcast
+                dst[(size_t)x * ty4] = make_float4((y + 0 >= lo && y + 0 < hi) ? 1.0f : 0.0f, (y + 1 >= lo && y + 1 < hi) ? 1.0f : 0.0f,
+                                                   (y + 2 >= lo && y + 2 < hi) ? 1.0f : 0.0f, (y + 3 >= lo && y + 3 < hi) ? 1.0f : 0.0f);
+                lo = hi;
+            }
         }
     } else {
         const int n = Tx * Ty;
         for (int i = threadIdx.x; i < n; i += 256) {
             const int x = i / Ty;
             const int y = i - x * Ty;
-            pb[i] = (y < ty && idx[y] == x) ? 1.0f : 0.0f;
+            pb[i] = (y >= first[x] && y < first[x + 1]) ? 1.0f : 0.0f;
         }
     }
+    MAS_TRACE(4);
 }
 
 template <int R>
 static int launch_mas(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B, int Tx,
                       int Ty, hipStream_t stream) {
     const int nblk32 = (Ty + 31) / 32;
-    const size_t fixed = (size_t)R * nblk32 * 64 * 4 + (((size_t)Ty * 2 + 15) & ~(size_t)15);
+    const size_t fixed = (size_t)R * nblk32 * 64 * 4 + (((size_t)(Tx + 1) * 4 + 15) & ~(size_t)15);
     const size_t budget = 150 * 1024;
     int log2tc = 6;
     while (log2tc > 3 && fixed + (size_t)2 * (1 << log2tc) * (R * 64 + 1) * 4 > budget) --log2tc;
@@ -218,3 +288,9 @@ extern "C" int glowtts_mas_path(const float *value, float *path, const int32_t *
         default: return launch_mas<8>(value, path, t_x, t_y, B, Tx, Ty, s);
     }
 }
+
+#ifdef GLOWTTS_TRACE
+extern "C" int glowtts_debug_mas_trace_read(unsigned long long *host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(glowtts::g_mas_trace), (size_t)n_words * 8);
+}
+#endif
