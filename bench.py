@@ -265,7 +265,7 @@ def main():
             train_batch(model, opt, batch, cfg.grad_clip, None)
         times = _hip.disable_timing()
         log("instrumented pass done")
-        hbm, mfma = {}, {}
+        hbm, mfma, other = {}, {}, {}
         for name, ms in times.items():
             mean_ms = sum(ms) / len(ms)
             row = {"launches_per_step": len(ms) // n_inst, "mean_us": round(1e3 * mean_ms, 2),
@@ -278,6 +278,8 @@ def main():
             elif name in alg:
                 row.update(alg_MB=round(alg[name] / 1e6, 3), GBps=round(alg[name] / (mean_ms * 1e-3) / 1e9, 1))
                 hbm[name] = row
+            else:
+                other[name] = row
         sub_ms = sum(hbm[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
         sub_bytes = sum(alg[k] * hbm[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
         survey_gb = 3 * 6.5 * C * 4 * B * Ts * cfg.model.n_blocks_dec / 1e9
@@ -306,6 +308,7 @@ def main():
             "step_ms": round(ms_per_step, 3),
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "hbm_kernels": dict(sorted(hbm.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
+            "other_kernels": dict(sorted(other.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
         })
 
     # ---- CPU baseline leg: the oracle (a port of the reference path) on this host's cores, bounded sample

@@ -61,16 +61,17 @@ class CouplingBlock(nn.Module):
         nn.init.zeros_(self.end.weight)
         nn.init.zeros_(self.end.bias)
         self.wn = WN(in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, p_dropout)
+        self._conv_group = convops.ConvGroup([self.start, self.end])   # one pack / un-pack launch for the two 1x1 convs
 
     def forward(self, x, x_mask=None, reverse: bool = False, g=None, **kwargs):
         if x_mask is None:
             x_mask = torch.ones(x.size(0), 1, x.size(2), device=x.device, dtype=x.dtype)
         m2 = ops.mask2d(x_mask)
-        sv, sg, sb = WN._conv_params(self.start)
         # the 1x1 convs consume the channel slice in place (batch stride C*T) and fold bias and mask into the epilogue
-        h = convops.Conv1dFn.apply(x[:, : self.in_channels // 2], sv, sg, sb, m2, False, True, 1)
+        self._conv_group.begin()
+        h = convops.conv1d(self.start, x[:, : self.in_channels // 2], m2, mask_out=True)
         h = self.wn(h, x_mask, g, m2=m2)
-        out = convops.Conv1dFn.apply(h, self.end.weight, None, self.end.bias, m2, False, False, 1)
+        out = convops.conv1d(self.end, h, m2)
         if reverse:
             return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
         return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale)

@@ -119,12 +119,16 @@ class Conv1dFn(Function):
     `mask_in` / `mask_out` fold the reference's `conv(x * x_mask)` / `conv(...) * x_mask` into the kernel."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, m2, mask_in, mask_out, dil):
+    def forward(ctx, x, v, g, bias, m2, mask_in, mask_out, dil, group=None, gidx=0):
         x = _dense(f32(x))
         B, cin, T = x.shape
         cout, _, taps = v.shape
         pad = (taps * dil - dil) // 2
-        wp_f, wp_b, inv = pack_weight(v, g)
+        if group is not None:
+            wp_f, wp_b, inv = group.packed(gidx)         # (conv1d counted this use in group.pending: grad mode is off in here)
+        else:
+            wp_f, wp_b, inv = pack_weight(v, g)
+        ctx.group = (group, gidx)
         y = torch.empty(B, cout, T, device=x.device, dtype=torch.float32)
         b1 = None if bias is None else f32(bias.detach().contiguous())
         conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_in=bool(mask_in), mask_out=bool(mask_out))
@@ -142,15 +146,26 @@ class Conv1dFn(Function):
         dy = _dense(dy)
         B, cin, T = x.shape
         cout = dy.shape[1]
-        sink = _GradSink([v, g, bias])
-        _weight_grads(x, dy, m2 if mask_out else None, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2),
-                      taps, dil, pad, m2_for_x=m2 if mask_in else None)
+        group, gidx = ctx.group
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
             conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out, mask_out=mask_in)
+        if group is not None:
+            # packed weight gradient into the group's accumulator (un-packed once, by the group's last backward); the bias
+            # gradient rides along with the same launch, straight into bias.grad
+            _weight_grads(x, dy, m2 if mask_out else None, (taps, cin, cout), v, g, inv, None, None,
+                          None if bias is None else bias.grad, taps, dil, pad, dwp=group.dwp(gidx), unpack=False,
+                          m2_for_x=m2 if mask_in else None)
+            if bias is not None:
+                _notify([bias])
+            group.finish_one()
+            return dx, None, None, None, None, None, None, None, None, None
+        sink = _GradSink([v, g, bias])
+        _weight_grads(x, dy, m2 if mask_out else None, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2),
+                      taps, dil, pad, m2_for_x=m2 if mask_in else None)
         dv, dg, db = sink.results()
-        return dx, dv, dg, db, None, None, None, None
+        return dx, dv, dg, db, None, None, None, None, None, None
 
 
 def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = None, mask_in: bool = False,
@@ -160,7 +175,12 @@ def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = 
         v, g = conv.weight_v, conv.weight_g
     else:
         v, g = conv.weight, None
-    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0])
+    group, gidx = getattr(conv, "_glowtts_group", (None, 0))
+    if group is not None and not group.active:
+        group = None
+    if group is not None and torch.is_grad_enabled() and (v.requires_grad or x.requires_grad):
+        group.pending += 1                               # one backward call to wait for before the group un-packs
+    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0], group, gidx)
 
 
 class ChanLayerNormFn(Function):
@@ -203,14 +223,16 @@ class WNPackPlan:
         self.key = None
         self.gkey = None
 
-    def ensure(self, params, n_layers):
+    def ensure(self, params, n_layers=None, n_convs=None):
+        """params: (v, g, bias) per convolution; a WN stack passes n_layers (2 convolutions per layer)."""
+        n_convs = 2 * n_layers if n_convs is None else n_convs
         key = tuple(0 if p is None else p.data_ptr() for p in params) + tuple(None if p is None else tuple(p.shape) for p in params)
         if key == self.key:
             return
         dev = params[0].device
         self.convs = []          # (v, g, wp_f, wp_b, inv, cout, cin, taps, dwp_offset)
         rows, off = [0], 0
-        for i in range(2 * n_layers):
+        for i in range(n_convs):
             v, g = params[3 * i], params[3 * i + 1]
             cout, cin, taps = v.shape
             gi, go = (cin + 15) // 16, (cout + 15) // 16
@@ -247,6 +269,85 @@ class WNPackPlan:
             self.gdesc = torch.tensor(rows, dtype=torch.int64).to(self.dwp.device)
             self.gkey = gkey
         call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
+
+
+_active_groups: List = []
+
+
+class ConvGroup:
+    """The plain (non-WN) convolutions of one module — a coupling block's start / end convs, the whole text encoder —
+    share ONE weight-norm + packing launch per forward and ONE un-packing launch per backward (each conv otherwise costs
+    a pack and an unpack launch of its own: ~140 launches per step at config 2).
+
+    `begin()` at the top of the owner's forward packs everything; `conv1d` / `Conv1dFn` then take the packed weights from
+    the group, accumulate the packed weight gradient into the group's buffer and count down; the last backward of the
+    group un-packs into `param.grad` and announces the gradients.  Needs every gradient to exist already (the flat-buffer
+    optimizer keeps them allocated); otherwise the group stays inactive and every conv packs for itself."""
+
+    def __init__(self, convs):
+        self.modules = list(convs)
+        self.plan = WNPackPlan()
+        self.index = {}
+        self.active = False
+        self.pending = 0
+        self.touched = False
+        for i, m in enumerate(self.modules):
+            m._glowtts_group = (self, i)
+
+    def _params(self):
+        out = []
+        for m in self.modules:
+            if hasattr(m, "weight_v"):
+                out += [m.weight_v, m.weight_g, m.bias]
+            else:
+                out += [m.weight, None, m.bias]
+        return out
+
+    def begin(self) -> None:
+        params = self._params()
+        tensors = [p for p in params if p is not None]
+        self.active = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in tensors)
+        if self.active and torch.is_grad_enabled() and any(p.requires_grad for p in tensors):
+            self.active = all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
+                                                        and p.grad.dtype == torch.float32) for p in tensors)
+        if not self.active:
+            return
+        if self.pending > 0 and self.touched:            # a previous backward never completed: do not lose its gradients
+            self.flush()
+        self.params = params
+        self.plan.ensure(params, n_convs=len(self.modules))
+        self.plan.pack()
+        self.pending, self.touched = 0, False
+
+    def packed(self, i):
+        return self.plan.convs[i][2:5]                   # wp_f, wp_b, inv
+
+    def dwp(self, i):
+        if not self.touched:                             # first weight gradient of this backward: clear the accumulator
+            self.plan.dwp.zero_()
+            self.touched = True
+            if self not in _active_groups:
+                _active_groups.append(self)
+        return self.plan.dwp_view(i)
+
+    def finish_one(self) -> None:
+        self.pending -= 1
+        if self.pending <= 0 and self.touched:
+            self.flush()
+
+    def flush(self) -> None:
+        self.plan.unpack_into_grads(self.params)
+        _notify([p for j, p in enumerate(self.params) if p is not None and j % 3 != 2])
+        self.pending, self.touched = 0, False
+        if self in _active_groups:
+            _active_groups.remove(self)
+
+
+def flush_groups() -> None:
+    """Un-pack whatever weight gradients are still waiting in a ConvGroup (a conv whose backward never ran leaves its
+    group counting); `train.train_batch` calls this after `loss.backward()`."""
+    for g in list(_active_groups):
+        g.flush()
 
 
 class WNFn(Function):

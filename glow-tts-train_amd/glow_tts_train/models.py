@@ -68,8 +68,12 @@ class TextEncoder(nn.Module):
         if not mean_only:
             self.proj_s = nn.Conv1d(hidden_channels, out_channels, 1)
         self.proj_w = DurationPredictor(hidden_channels + gin_channels, filter_channels_dp, kernel_size, p_dropout)
+        # every convolution of the encoder (q/k/v/o, FFN, prenet, projections, duration predictor): one weight-packing
+        # launch per forward and one gradient un-packing launch per backward instead of one each per conv
+        self._conv_group = convops.ConvGroup([m for m in self.modules() if isinstance(m, nn.Conv1d)])
 
     def forward(self, x, x_lengths, g=None):
+        self._conv_group.begin()
         h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)          # [b, h, t]
         x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
         if self.prenet:
