@@ -137,6 +137,31 @@ def disable_timing() -> dict:
     return {k: [a.elapsed_time(b) for a, b in v] for k, v in t.items()}
 
 
+_side_streams: dict = {}
+
+
+def side_stream_enabled() -> bool:
+    """The text encoder may run on a second stream next to the flow decoder (models.FlowGenerator.forward), but only
+    inside a training step bracketed by `zero_scope` (train.train_batch joins the stream again after backward — gradients
+    the operators write straight into `.grad` never pass an AccumulateGrad node, so autograd's own end-of-backward stream
+    sync does not cover them).  Off while per-launch timings are collected (overlapped kernels would time each other)
+    and when GLOWTTS_SIDE_STREAM=0."""
+    return _arena.active and _timing is None and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"
+
+
+def join_side_streams() -> None:
+    """Make the current stream wait for everything queued on the side streams (after backward, before the optimizer)."""
+    for s in _side_streams.values():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
 def call(name: str, *args, tag: Optional[str] = None) -> None:
     """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure.
     `tag` only labels the launch for the optional timing table (e.g. the GEMM shape of a conv launch)."""

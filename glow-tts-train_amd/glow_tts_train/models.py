@@ -13,7 +13,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import convops, monotonic_align, ops
+from . import _hip, convops, monotonic_align, ops
 from .attentions import CouplingBlock, Encoder
 from .layers import ActNorm, ConvReluNorm, InvConvNear, LayerNorm
 from .optimize import OptimizerType
@@ -199,7 +199,18 @@ class FlowGenerator(nn.Module):
     def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, gen=False, noise_scale=1.0, length_scale=1.0):
         if g is not None:
             g = F.normalize(self.emb_g(g)).unsqueeze(-1)                        # [b, gin, 1]
-        x_m, x_logs, logw, x_mask = self.encoder(x, x_lengths, g=g)
+        # Training: the text encoder and the flow decoder do not depend on each other until the alignment search, and the
+        # encoder's kernels (T_text-sized attention / LayerNorm / small convs) leave most of the GPU idle.  It runs on a
+        # second stream next to the decoder; autograd replays each branch's backward on the stream of its forward.
+        overlap = (not gen) and y is not None and x.is_cuda and _hip.side_stream_enabled()
+        if overlap:
+            main = torch.cuda.current_stream(x.device)
+            side = _hip.side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                x_m, x_logs, logw, x_mask = self.encoder(x, x_lengths, g=g)
+        else:
+            x_m, x_logs, logw, x_mask = self.encoder(x, x_lengths, g=g)
 
         if gen:
             w_ceil = torch.ceil(torch.exp(logw) * x_mask * length_scale)
@@ -209,9 +220,9 @@ class FlowGenerator(nn.Module):
             y_max_length = y.size(2)
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y_max_length)
         z_mask = sequence_mask(y_lengths, y_max_length).unsqueeze(1).to(x_mask.dtype)
-        attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
 
         if gen:
+            attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
             attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
             z_m = self._expand_by_alignment(attn, x_m)
             z_logs = self._expand_by_alignment(attn, x_logs)
@@ -220,7 +231,15 @@ class FlowGenerator(nn.Module):
             y, logdet = self.decoder(z, z_mask, g=g, reverse=True)
             return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
 
-        z, logdet = self.decoder(y, z_mask, g=g, reverse=False)
+        if overlap:
+            # y-side preparation above only needs x_mask's dtype; everything that reads encoder outputs comes after the join
+            z, logdet = self.decoder(y, z_mask, g=g, reverse=False)
+            main.wait_stream(side)
+            for t in (x_m, x_logs, logw, x_mask):
+                t.record_stream(main)
+        else:
+            z, logdet = self.decoder(y, z_mask, g=g, reverse=False)
+        attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
         with torch.no_grad():
             logp = self._pairwise_log_likelihood(x_m, x_logs, z)
             # device-resident search; lengths are what the reference would read back off attn_mask

@@ -11,7 +11,7 @@ import typing
 
 import torch
 
-from ._hip import zero_scope
+from ._hip import join_side_streams, zero_scope
 from .convops import flush_groups
 from .utils import clip_grad_value_, duration_loss, mle_loss, to_gpu
 
@@ -24,6 +24,7 @@ def train_batch(model, optimizer, batch, grad_clip: float, reducer=None) -> torc
         (z, z_m, z_logs, logdet, z_mask), _, (_attn, logw, logw_) = model(x, x_lengths, y, y_lengths, g=speaker_ids)
         loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, x_lengths)
         loss.backward()
+        join_side_streams()             # the encoder branch ran (forward and backward) on a second stream
         flush_groups()                  # weight gradients still packed in a ConvGroup (none, unless a backward was skipped)
         if reducer is not None:
             reducer.finish()
