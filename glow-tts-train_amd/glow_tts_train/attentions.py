@@ -69,12 +69,18 @@ class CouplingBlock(nn.Module):
         m2 = ops.mask2d(x_mask)
         # the 1x1 convs consume the channel slice in place (batch stride C*T) and fold bias and mask into the epilogue
         self._conv_group.begin()
-        h = convops.conv1d(self.start, x[:, : self.in_channels // 2], m2, mask_out=True)
+        link = None
+        if not reverse and torch.is_grad_enabled() and x.requires_grad and x.is_contiguous():
+            link = ops.GradLink()                       # x feeds the start conv AND the affine apply: one gradient buffer
+            link.armed = True
+            h = convops.conv1d(self.start, x, m2, mask_out=True, link=link)
+        else:
+            h = convops.conv1d(self.start, x[:, : self.in_channels // 2], m2, mask_out=True)
         h = self.wn(h, x_mask, g, m2=m2)
         out = convops.conv1d(self.end, h, m2)
         if reverse:
             return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
-        return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale)
+        return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale, link)
 
     def store_inverse(self):
         self.wn.remove_weight_norm()

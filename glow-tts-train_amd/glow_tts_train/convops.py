@@ -66,7 +66,7 @@ def conv_fwd(x, wp, bias, m2, y, cin, cout, taps, dil, pad, mask_in=False, mask_
     B, _, T = x.shape
     call("glowtts_conv_fwd", ptr_rows(x), x.stride(0), ptr(wp), ptr(bias), ptr(m2),
          None if addend is None else ptr_rows(addend), 0 if addend is None else addend.stride(0),
-         ptr(y), y.stride(0), B, cin, cout, T, taps, dil, pad, int(mask_in), int(mask_out), int(mask_add),
+         ptr_rows(y), y.stride(0), B, cin, cout, T, taps, dil, pad, int(mask_in), int(mask_out), int(mask_add),
          tag=f"M{cout} K{cin}x{taps} N{B}x{T}")
     return y
 
@@ -119,7 +119,14 @@ class Conv1dFn(Function):
     `mask_in` / `mask_out` fold the reference's `conv(x * x_mask)` / `conv(...) * x_mask` into the kernel."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, m2, mask_in, mask_out, dil, group=None, gidx=0):
+    def forward(ctx, x, v, g, bias, m2, mask_in, mask_out, dil, group=None, gidx=0, link=None):
+        # link (ops.GradLink): x is the FULL tensor of a coupling block, the conv reads its first Cin channels; in backward
+        # the input gradient is added in place into the buffer the affine apply left in the link
+        ctx.link = link
+        ctx.x_full_shape = None
+        if link is not None:
+            ctx.x_full_shape = tuple(x.shape)
+            x = x[:, : v.shape[1]]
         x = _dense(f32(x))
         B, cin, T = x.shape
         cout, _, taps = v.shape
@@ -149,8 +156,19 @@ class Conv1dFn(Function):
         group, gidx = ctx.group
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
-            conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out, mask_out=mask_in)
+            link = ctx.link
+            if link is not None:
+                full = link.buf                         # gradient of the other consumer of x (None if it did not run)
+                link.buf = None
+                if full is None:
+                    full = torch.zeros(ctx.x_full_shape, device=dy.device, dtype=torch.float32)
+                part = full[:, :cin]
+                conv_fwd(dy, wp_b, None, m2, part, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out,
+                         mask_out=mask_in, addend=part)
+                dx = full
+            else:
+                dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
+                conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out, mask_out=mask_in)
         if group is not None:
             # packed weight gradient into the group's accumulator (un-packed once, by the group's last backward); the bias
             # gradient rides along with the same launch, straight into bias.grad
@@ -160,16 +178,16 @@ class Conv1dFn(Function):
             if bias is not None:
                 _notify([bias])
             group.finish_one()
-            return dx, None, None, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None, None, None
         sink = _GradSink([v, g, bias])
         _weight_grads(x, dy, m2 if mask_out else None, (taps, cin, cout), v, g, inv, sink.buf(0), sink.buf(1), sink.buf(2),
                       taps, dil, pad, m2_for_x=m2 if mask_in else None)
         dv, dg, db = sink.results()
-        return dx, dv, dg, db, None, None, None, None, None, None
+        return dx, dv, dg, db, None, None, None, None, None, None, None
 
 
 def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = None, mask_in: bool = False,
-           mask_out: bool = False) -> torch.Tensor:
+           mask_out: bool = False, link=None) -> torch.Tensor:
     """Run an nn.Conv1d (optionally weight-normed, 'same' padding) through the MFMA kernels."""
     if hasattr(conv, "weight_v"):
         v, g = conv.weight_v, conv.weight_g
@@ -180,7 +198,7 @@ def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = 
         group = None
     if group is not None and torch.is_grad_enabled() and (v.requires_grad or x.requires_grad):
         group.pending += 1                               # one backward call to wait for before the group un-packs
-    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0], group, gidx)
+    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0], group, gidx, link)
 
 
 class ChanLayerNormFn(Function):

@@ -120,7 +120,7 @@ class FlowSpecDecoder(nn.Module):
             logdet_tot = None
         else:
             x_len = ops.mask_len(ops.mask2d(x_mask))
-            logdet_tot = 0
+            logdets = []                               # summed once at the end: one stack + one sum instead of 24 adds
             m2 = ops.mask2d(x_mask)
             i = 0
             while i < len(self.flows):
@@ -134,7 +134,8 @@ class FlowSpecDecoder(nn.Module):
                 else:
                     x, logdet = f(x, x_mask, g=g, reverse=False, x_len=x_len)
                     i += 1
-                logdet_tot = logdet_tot + logdet
+                logdets.append(logdet)
+            logdet_tot = torch.stack(logdets, 0).sum(0) if len(logdets) > 1 else (logdets[0] if logdets else 0)
         if self.n_sqz > 1:
             x, x_mask = unsqueeze(x, x_mask, self.n_sqz)
         return x, logdet_tot

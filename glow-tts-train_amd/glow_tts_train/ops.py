@@ -169,7 +169,7 @@ class CouplingFn(Function):
     """attentions.py:128-142: z = [x_0 ; (m + exp(logs) x_1) mask], logdet = sum logs mask; (m, logs) = `out` halves."""
 
     @staticmethod
-    def forward(ctx, x, out, m2, sigmoid_scale):
+    def forward(ctx, x, out, m2, sigmoid_scale, link=None):
         x, out = f32(_c(x)), f32(_c(out))
         B, C, T = x.shape
         z = torch.empty_like(x)
@@ -177,6 +177,7 @@ class CouplingFn(Function):
         call("glowtts_coupling_fwd", ptr(x), ptr(out), ptr(m2), ptr(z), ptr(logdet), B, C, T, int(sigmoid_scale), 0)
         ctx.save_for_backward(x, out, m2)
         ctx.sig = int(sigmoid_scale)
+        ctx.link = link
         return z, logdet
 
     @staticmethod
@@ -189,7 +190,20 @@ class CouplingFn(Function):
         dout = torch.empty_like(out)
         call("glowtts_coupling_bwd", ptr(x), ptr(out), ptr(m2), ptr(dz), ptr(_c(dlogdet)), ptr(dx), ptr(dout), B, C, T,
              ctx.sig)
-        return dx, dout, None, None
+        if ctx.link is not None and ctx.link.armed:
+            # x also feeds the start conv (through its first half); that conv's backward runs later, adds its part into
+            # this buffer in place and hands the sum to autograd — no zeros / slice-copy / add launches for the fan-out
+            ctx.link.buf = dx
+            return None, dout, None, None, None
+        return dx, dout, None, None, None
+
+
+class GradLink:
+    """Side channel between the two consumers of a coupling block's input (the affine apply and the start conv)."""
+
+    def __init__(self):
+        self.buf = None
+        self.armed = False
 
 
 def coupling_reverse(x, out, m2, sigmoid_scale):
