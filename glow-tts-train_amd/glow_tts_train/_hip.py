@@ -155,8 +155,9 @@ def join_side_streams() -> None:
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
-def side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index
+def side_stream(device, role: str = "encoder") -> "torch.cuda.Stream":
+    """One extra stream per (device, role): "encoder" (the text-encoder branch) and "wgrad" (weight-gradient kernels)."""
+    key = (torch.device(device).index, role)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device)
     return _side_streams[key]
