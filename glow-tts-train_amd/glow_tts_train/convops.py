@@ -511,10 +511,16 @@ class WNFn(Function):
             conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
                      addend=None if last else d_rs[:, :H])
             dx_next = dx
-        wgrad.join()
-        if sink.direct:                                 # every un-packing (through the weight norm) in one launch
-            plan.unpack_into_grads(params)
         dcond = None
         if has_cond:
             dcond = torch.cat(dconds, 1).unsqueeze(-1)
-        return (dx_next, None, dcond, None, None, None, None, *sink.results())
+        if sink.direct:
+            # every un-packing (through the weight norm) in one launch, queued BEHIND the weight-gradient kernels on their
+            # stream: the main stream does not wait here (train_batch joins the side streams after backward; a gradient
+            # listener — the DP reducer — is told inside the side stream's context, so its collective waits on that stream)
+            results = []
+            wgrad.run(lambda: (plan.unpack_into_grads(params), results.extend(sink.results())))
+        else:
+            wgrad.join()
+            results = sink.results()
+        return (dx_next, None, dcond, None, None, None, None, *results)
