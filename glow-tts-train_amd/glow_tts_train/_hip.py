@@ -163,21 +163,30 @@ def side_stream(device, role: str = "encoder") -> "torch.cuda.Stream":
     return _side_streams[key]
 
 
-def call(name: str, *args, tag: Optional[str] = None) -> None:
+_fn_cache: dict = {}
+
+
+def call(name: str, *args, tag=None) -> None:
     """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure.
-    `tag` only labels the launch for the optional timing table (e.g. the GEMM shape of a conv launch)."""
-    lib = load()
-    cur = torch.cuda.current_stream()
-    if _timing is not None:
+    `tag` only labels the launch for the optional timing table: a string, or a (format, *values) tuple that is formatted
+    only when timings are being collected.  This function runs ~1 100 times per training step, so the untimed path does
+    nothing but look up the cached ctypes entry and the raw stream handle."""
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    if _timing is None:
+        rc = fn(*args, torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    else:
+        cur = torch.cuda.current_stream()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(cur)
-        rc = getattr(lib, name)(*args, cur.cuda_stream)
+        rc = fn(*args, cur.cuda_stream)
         b.record(cur)
+        if isinstance(tag, tuple):
+            tag = tag[0] % tag[1:]
         _timing.setdefault(name if tag is None else f"{name}[{tag}]", []).append((a, b))
-    else:
-        rc = getattr(lib, name)(*args, cur.cuda_stream)
     if rc != 0:
-        msg = lib.glowtts_last_error().decode("utf-8", "replace")
+        msg = load().glowtts_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")
 
 

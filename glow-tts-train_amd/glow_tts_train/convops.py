@@ -68,7 +68,7 @@ def conv_fwd(x, wp, bias, m2, y, cin, cout, taps, dil, pad, mask_in=False, mask_
     call("glowtts_conv_fwd", ptr_rows(x), x.stride(0), ptr(wp), ptr(bias), ptr(m2),
          None if addend is None else ptr_rows(addend), 0 if addend is None else addend.stride(0),
          ptr_rows(y), y.stride(0), B, cin, cout, T, taps, dil, pad, int(mask_in), int(mask_out), int(mask_add),
-         tag=f"M{cout} K{cin}x{taps} N{B}x{T}")
+         tag=("M%d K%dx%d N%dx%d", cout, cin, taps, B, T))
     return y
 
 
@@ -135,7 +135,7 @@ def _weight_grads(x, d, m2_for_d, dwp_shape, v, g, inv, dv_buf, dg_buf, db_buf, 
     if dwp is None:
         dwp = scratch_zeros(dwp_shape, d.device)
     call("glowtts_conv_wrw", ptr_rows(x), x.stride(0), ptr_rows(d), d.stride(0), ptr(m2_for_d), ptr(m2_for_x), ptr(dwp),
-         None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad, tag=f"M{cout} K{cin}x{taps} N{B}x{T}")
+         None if db_buf is None else ptr(db_buf), B, cin, cout, T, taps, dil, pad, tag=("M%d K%dx%d N%dx%d", cout, cin, taps, B, T))
     if not unpack:
         return
     gg = None if g is None else g.detach().reshape(-1).contiguous()
@@ -436,13 +436,13 @@ class WNFn(Function):
             c_i = None if cond is None else f32(cond[:, 2 * H * i: 2 * H * (i + 1)].reshape(B, 2 * H).contiguous())
             call("glowtts_conv_gate_fwd", ptr(cur), ptr(wf_in), ptr(f32(in_b.detach().contiguous())), ptr(c_i), ptr(drop),
                  1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, ptr(acts), ptr(ts), B, H, T, taps, dil, pad,
-                 tag=f"M{2 * H} K{H}x{taps} N{B}x{T}")
+                 tag=("M%d K%dx%d N%dx%d", 2 * H, H, taps, B, T))
             last = i == n_layers - 1
             skip_out = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             nxt = None if last else torch.empty(B, H, T, device=dev, dtype=torch.float32)
             call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(f32(rs_b.detach().contiguous())), ptr(m2),
                  None if last else ptr(cur), ptr(skip), None if last else ptr(nxt), ptr(skip_out), B, H, T, int(last),
-                 tag=f"M{H if last else 2 * H} K{H}x1 N{B}x{T}")
+                 tag=("M%d K%dx1 N%dx%d", H if last else 2 * H, H, B, T))
             saved += [cur, acts, ts]
             skip = skip_out
             if not last:
@@ -500,7 +500,7 @@ class WNFn(Function):
             else:
                 # d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs): one kernel, d(acts) stays on chip
                 call("glowtts_conv_gate_bwd", ptr(d_rs), ptr(wb_rs), ptr(ts), ptr(drops[i]), scale, ptr(d_xin), B, m_rs, H, T,
-                     tag=f"M{H} K{m_rs}x1 N{B}x{T}")
+                     tag=("M%d K%dx1 N%dx%d", H, m_rs, B, T))
                 if has_cond:
                     dconds[i] = d_xin.sum(-1)
             wgrad.run(lambda: _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i),

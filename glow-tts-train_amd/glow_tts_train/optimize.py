@@ -66,21 +66,50 @@ class FlatAdam(torch.optim.Optimizer):
         return [(o, p.numel()) for p, o in zip(self._params, self.offsets)]
 
     # -- torch.optim surface ------------------------------------------------------------------------------------
+    def _grad_views(self):
+        """The gradient views handed out by zero_grad, kept so that "is .grad still ours?" is an identity test per
+        parameter (this runs three times per step over ~500 parameters: pointer arithmetic there cost milliseconds)."""
+        views = getattr(self, "_views", None)
+        if views is None:
+            views = self._views = [None] * len(self._params)
+        return views
+
     def zero_grad(self, set_to_none: bool = False):
         # the gradients must stay views of the flat buffer: one memset, never `grad = None`
         self.flat_g.zero_()
-        for p, o in zip(self._params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        views = self._grad_views()
+        for i, p in enumerate(self._params):
+            if p.grad is not views[i] or views[i] is None:
+                o = self.offsets[i]
+                views[i] = self.flat_g[o:o + p.numel()].view(p.shape)
+                p.grad = views[i]
+
+    def grads_in_place(self) -> bool:
+        views = self._grad_views()
+        return all(p.grad is v for p, v in zip(self._params, views))
+
+    def clip_grad_value_(self, clip_value: float):
+        """utils.clip_grad_value_ over the whole flat gradient buffer in one launch; None if a gradient has been replaced by
+        a foreign tensor (the caller then takes the general path)."""
+        if not self.grads_in_place():
+            return None
+        from .utils import _FlatGradView
+        sumsq = torch.zeros(1, device=self.flat_g.device, dtype=torch.float32)
+        call("glowtts_clip_grad_value", ptr(self.flat_g), self.flat_g.numel(), float(clip_value), ptr(sumsq))
+        return _FlatGradView(sumsq, 2.0)
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FlatAdam.step: closures are not supported")
-        for p, o in zip(self._params, self.offsets):  # a foreign hook may have replaced .grad: fold it back in
-            if p.grad is not None and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
-                self.flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
-                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        if not self.grads_in_place():                 # a foreign hook may have replaced .grad: fold it back in
+            views = self._grad_views()
+            for i, (p, o) in enumerate(zip(self._params, self.offsets)):
+                if p.grad is not None and p.grad is not views[i] and p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                    self.flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                if p.grad is not views[i]:
+                    views[i] = self.flat_g[o:o + p.numel()].view(p.shape)
+                    p.grad = views[i]
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         call("glowtts_adam_noam", ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v),

@@ -29,7 +29,9 @@ def train_batch(model, optimizer, batch, grad_clip: float, reducer=None) -> torc
         if reducer is not None:
             reducer.finish()
         loss = loss.detach()
-    clip_grad_value_(model.parameters(), grad_clip)
+    flat = getattr(optimizer, "_optim", optimizer)
+    if not (hasattr(flat, "clip_grad_value_") and flat.clip_grad_value_(grad_clip) is not None):
+        clip_grad_value_(model.parameters(), grad_clip)
     optimizer.step()
     return loss
 
