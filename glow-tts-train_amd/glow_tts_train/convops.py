@@ -380,7 +380,9 @@ class ConvGroup:
     def finish_one(self) -> None:
         self.pending -= 1
         if self.pending <= 0 and self.touched:
-            self.flush()
+            # last backward of the group: un-pack behind the weight-gradient stream's queue instead of on the dx chain
+            # (the stream first waits for the current one, i.e. for this group's own wrw launches)
+            _WgradStream(self.plan.dwp.device).run(self.flush)
 
     def flush(self) -> None:
         self.plan.unpack_into_grads(self.params)

@@ -762,6 +762,45 @@ def test_chan_layernorm_vs_torch(G, b, c, t, with_res):
     assert_close(ln.beta.grad, bo.grad, what="dbeta", rtol=2e-4, atol=2e-4)
 
 
+def test_coupling_block_grouped_and_linked_paths_match_plain_autograd(G):
+    """With pre-allocated .grad tensors (the flat-buffer optimizer's situation) a coupling block packs its start / end convs
+    in one launch, un-packs their gradients in one launch (convops.ConvGroup) and shares ONE input-gradient buffer between
+    the affine apply and the start conv (ops.GradLink).  Same block, same inputs, gradients left to plain autograd
+    (.grad = None): every gradient must agree."""
+    torch.manual_seed(21)
+    blk = G.attentions.CouplingBlock(160, 192, kernel_size=5, dilation_rate=1, n_layers=4, p_dropout=0.0).cuda()
+    with torch.no_grad():
+        blk.end.weight.normal_(0, 0.02)
+        blk.end.bias.normal_(0, 0.02)
+    b, t = 4, 96
+    x0 = torch.randn(b, 160, t, device="cuda")
+    lens = torch.tensor([96, 80, 64, 50], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float()[:, None]
+    r, s = torch.randn(b, 160, t, device="cuda"), torch.randn(b, device="cuda")
+
+    def run(prealloc):
+        for p in blk.parameters():
+            p.grad = torch.zeros_like(p) if prealloc else None
+        x = (x0 * mask).clone().requires_grad_(True)
+        z, ld = blk(x, mask)
+        ((z * r).sum() + (ld * s).sum()).backward()
+        G.hip.join_side_streams()
+        from glow_tts_train import convops
+        convops.flush_groups()
+        torch.cuda.synchronize()
+        return z.detach(), ld.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    z0, l0, dx0, g0 = run(False)
+    assert not blk._conv_group.active
+    z1, l1, dx1, g1 = run(True)
+    assert blk._conv_group.active
+    assert_close(z1, z0, what="z", rtol=1e-6, atol=1e-6)
+    assert_close(l1, l0, what="logdet", rtol=1e-6, atol=1e-5)
+    assert_close(dx1, dx0, what="dx", rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
+    for k in g0:
+        assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
+
+
 def test_graphed_train_step_matches_eager(G):
     """hipGraph replay of the whole step == eager launches (same kernels, same order, same on-device schedule)."""
     from glow_tts_train.train import GraphedTrainStep, train_batch

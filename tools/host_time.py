@@ -28,3 +28,31 @@ for _ in range(10):
     total.append((t2 - t0) * 1e3)
 print("host enqueue ms/step:", " ".join(f"{h:.1f}" for h in host))
 print("step (sync to sync) ms:", " ".join(f"{h:.1f}" for h in total))
+
+# split: forward / backward / optimizer enqueue time
+from glow_tts_train.utils import duration_loss, mle_loss  # noqa: E402
+from glow_tts_train._hip import zero_scope, join_side_streams  # noqa: E402
+from glow_tts_train.convops import flush_groups  # noqa: E402
+
+x, xl, y, yl, sp = batch
+f, b, o = [], [], []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    with zero_scope(y.device):
+        (z, z_m, z_logs, logdet, z_mask), _, (_a, logw, logw_) = model(x, xl, y, yl, g=sp)
+        loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, xl)
+        t1 = time.perf_counter()
+        loss.backward()
+        join_side_streams()
+        flush_groups()
+    t2 = time.perf_counter()
+    flat = opt._optim
+    flat.clip_grad_value_(cfg.grad_clip)
+    opt.step()
+    t3 = time.perf_counter()
+    f.append((t1 - t0) * 1e3); b.append((t2 - t1) * 1e3); o.append((t3 - t2) * 1e3)
+print("forward enqueue ms :", " ".join(f"{v:.1f}" for v in f))
+print("backward enqueue ms:", " ".join(f"{v:.1f}" for v in b))
+print("optimizer enqueue ms:", " ".join(f"{v:.2f}" for v in o))
