@@ -99,9 +99,9 @@ class _WgradStream:
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
             fn()
-        for t in reads:                       # allocated on the main stream, read on the side stream
-            if t is not None:
-                t.record_stream(self.side)
+        for t in reads:                       # allocated on the main stream, read on the side stream: the caching allocator
+            if t is not None:                 # must not hand the block out again (saved tensors are freed as soon as this
+                t.record_stream(self.side)    # backward returns) before the side stream is done with it
 
     def join(self):
         if self.enabled:
@@ -488,7 +488,7 @@ class WNFn(Function):
                 dskip = d_rs                          # d(skip_in) of the last layer carries the folded mask
             wgrad.run(lambda: _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3),
                                             sink.buf(6 * i + 4), sink.buf(6 * i + 5), 1, 1, 0, dwp=plan.dwp_view(2 * i + 1),
-                                            unpack=not sink.direct), d_rs)
+                                            unpack=not sink.direct), d_rs, acts)
             d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
             if has_cond and drops[i] is not None:
                 # conditioning is added after the dropout: its gradient is the un-dropped pre-activation gradient, so
@@ -507,7 +507,7 @@ class WNFn(Function):
                     dconds[i] = d_xin.sum(-1)
             wgrad.run(lambda: _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i),
                                             sink.buf(6 * i + 1), sink.buf(6 * i + 2), taps, dil, pad, dwp=plan.dwp_view(2 * i),
-                                            unpack=not sink.direct), d_xin)
+                                            unpack=not sink.direct), d_xin, x_i)
             dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
             # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
             conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
