@@ -62,7 +62,17 @@ _SIGNATURES = {
     "glowtts_clip_grad_value": [_P, _L, _F, _P],
     "glowtts_adam_noam": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F],
     "glowtts_adam_advance": [_P, _F, _F, _F],
+    # whole WN stack per call (csrc/wn_stack.hip); the first argument is a HOST array of WnLayer
+    "glowtts_wn_fwd": [_P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "glowtts_wn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
+
+
+class WnLayer(ctypes.Structure):
+    """struct glowtts_wn_layer (include/glowtts_hip.h): device pointers of one WN layer's packed weights and gradients."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wf_in", "wb_in", "b_in", "wf_rs", "wb_rs", "b_rs", "dwp_in", "dwp_rs",
+                                                 "db_in", "db_rs")]
+
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version"])
 
@@ -149,17 +159,23 @@ def side_stream_enabled() -> bool:
     return _arena.active and _timing is None and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"
 
 
+def timing_off() -> bool:
+    """False while per-launch timings are collected: multi-launch native executors then yield to the per-kernel path."""
+    return _timing is None
+
+
 def join_side_streams() -> None:
     """Make the current stream wait for everything queued on the side streams (after backward, before the optimizer)."""
     for s in _side_streams.values():
         torch.cuda.current_stream(s.device).wait_stream(s)
 
 
-def side_stream(device, role: str = "encoder") -> "torch.cuda.Stream":
-    """One extra stream per (device, role): "encoder" (the text-encoder branch) and "wgrad" (weight-gradient kernels)."""
+def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda.Stream":
+    """One extra stream per (device, role): "encoder" (the text-encoder branch), "wgrad" (weight-gradient kernels) and
+    "chain" (high priority: the decoder's dependency chain, see train.train_batch)."""
     key = (torch.device(device).index, role)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device)
+        _side_streams[key] = torch.cuda.Stream(device, priority=priority)
     return _side_streams[key]
 
 

@@ -296,6 +296,7 @@ class WNPackPlan:
             [[v.data_ptr(), 0 if g is None else g.data_ptr(), f.data_ptr(), b.data_ptr(), 0 if inv is None else inv.data_ptr(),
               cout, cin, taps] for (v, g, f, b, inv, cout, cin, taps, _) in self.convs], dtype=torch.int64).to(dev)
         self.key, self.gkey = key, None
+        self.version = getattr(self, "version", 0) + 1
 
     def pack(self):
         call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
@@ -304,19 +305,50 @@ class WNPackPlan:
         cout, cin, taps, off = self.convs[i][5:9]
         return self.dwp[off: off + taps * cin * cout]
 
+    def layer_table(self, params, n_layers):
+        """Host-side `glowtts_wn_layer[n_layers]` for the native executor (csrc/wn_stack.hip): packed weights from this
+        plan, biases and gradient targets from the parameters (which must have contiguous fp32 .grad).  Cached."""
+        key = (self.version, tuple(0 if p is None else p.data_ptr() for p in params),
+               tuple(0 if (p is None or p.grad is None) else p.grad.data_ptr() for p in params))
+        if getattr(self, "_ltab_key", None) != key:
+            tab = (_hip.WnLayer * n_layers)()
+            for i in range(n_layers):
+                in_b, rs_b = params[6 * i + 2], params[6 * i + 5]
+                ci, cr = self.convs[2 * i], self.convs[2 * i + 1]
+                tab[i].wf_in, tab[i].wb_in, tab[i].b_in = ci[2].data_ptr(), ci[3].data_ptr(), in_b.data_ptr()
+                tab[i].wf_rs, tab[i].wb_rs, tab[i].b_rs = cr[2].data_ptr(), cr[3].data_ptr(), rs_b.data_ptr()
+                tab[i].dwp_in, tab[i].dwp_rs = self.dwp_view(2 * i).data_ptr(), self.dwp_view(2 * i + 1).data_ptr()
+                tab[i].db_in = 0 if in_b.grad is None else in_b.grad.data_ptr()
+                tab[i].db_rs = 0 if rs_b.grad is None else rs_b.grad.data_ptr()
+            self._ltab, self._ltab_key = tab, key
+        return self._ltab
+
+    def unpack_tables(self, params):
+        """Device descriptor table of `unpack_into_grads` without launching it (the native executor launches it)."""
+        gkey = tuple(0 if p is None else p.grad.data_ptr() for p in params)
+        if gkey != self.gkey:
+            self._build_gdesc(params, gkey)
+        return self.gdesc, self.prefix
+
+    def _build_gdesc(self, params, gkey):
+        rows = []
+        for i, (v, g, _, _, inv, cout, cin, taps, off) in enumerate(self.convs):
+            pv, pg = params[3 * i], params[3 * i + 1]
+            rows.append([self.dwp.data_ptr() + 4 * off, v.data_ptr(), 0 if g is None else g.data_ptr(),
+                         0 if inv is None else inv.data_ptr(), pv.grad.data_ptr(), 0 if pg is None else pg.grad.data_ptr(),
+                         cout, cin, taps])
+        self.gdesc = torch.tensor(rows, dtype=torch.int64).to(self.dwp.device)
+        self.gkey = gkey
+
     def unpack_into_grads(self, params):
         gkey = tuple(0 if p is None else p.grad.data_ptr() for p in params)
         if gkey != self.gkey:
-            rows = []
-            for i, (v, g, _, _, inv, cout, cin, taps, off) in enumerate(self.convs):
-                pv, pg = params[3 * i], params[3 * i + 1]
-                rows.append([self.dwp.data_ptr() + 4 * off, v.data_ptr(), 0 if g is None else g.data_ptr(),
-                             0 if inv is None else inv.data_ptr(), pv.grad.data_ptr(), 0 if pg is None else pg.grad.data_ptr(),
-                             cout, cin, taps])
-            self.gdesc = torch.tensor(rows, dtype=torch.int64).to(self.dwp.device)
-            self.gkey = gkey
+            self._build_gdesc(params, gkey)
         call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
 
+
+# WN stack executor: "fwd" (default) = native forward (csrc/wn_stack.hip), layer-by-layer backward; "both"; "off"
+_WN_NATIVE = __import__("os").environ.get("GLOWTTS_WN_NATIVE", "fwd")
 
 _active_groups: List = []
 
@@ -399,6 +431,14 @@ def flush_groups() -> None:
         g.flush()
 
 
+def _wn_layers_from_slabs(x, xs, acts, ts, n_layers):
+    """Per-layer (x_i, acts_i, ts_i) views of the native executor's slabs, in the order the Python backward expects."""
+    out = []
+    for i in range(n_layers):
+        out += [x if i == 0 else xs[i - 1], acts[i], ts[i]]
+    return out
+
+
 class WNFn(Function):
     """The whole WN stack (reference layers.py:138-162) as one autograd node.
 
@@ -426,6 +466,23 @@ class WNFn(Function):
         drop_all = None
         if p_drop > 0.0:
             drop_all = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
+        ctx.native = False
+        if cond is None and _hip.timing_off() and _WN_NATIVE != "off" and all(params[3 * j + 2] is not None for j in range(2 * n_layers)):
+            # the whole launch sequence of the stack in one native call (csrc/wn_stack.hip): four allocations, one ctypes
+            # call, instead of two launches + four allocations per layer driven from here
+            import ctypes
+            taps = params[0].shape[2]
+            acts = torch.empty(n_layers, B, H, T, device=dev, dtype=torch.float32)
+            ts = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.float32)
+            xs = torch.empty(n_layers - 1, B, H, T, device=dev, dtype=torch.float32) if n_layers > 1 else None
+            skip = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+            tab = plan.layer_table(params, n_layers)
+            call("glowtts_wn_fwd", ctypes.addressof(tab), n_layers, ptr(x), ptr(m2), ptr(drop_all),
+                 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, ptr(xs), ptr(acts), ptr(ts), ptr(skip), B, H, T, taps, dil_rate)
+            ctx.save_for_backward(m2, x, acts, ts, *([] if xs is None else [xs]), *([] if drop_all is None else [drop_all]))
+            ctx.params, ctx.plan, ctx.native = params, plan, True
+            ctx.cfg = (n_layers, dil_rate, float(p_drop), False, B, H, T)
+            return skip
         for i in range(n_layers):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             taps = in_v.shape[2]
@@ -461,8 +518,15 @@ class WNFn(Function):
         n_layers, dil_rate, p_drop, has_cond, B, H, T = ctx.cfg
         sv = ctx.saved_tensors
         m2 = sv[0]
+        if ctx.native:
+            return WNFn._backward_native(ctx, dout)
         saved = sv[1: 1 + 3 * n_layers]
         drops = list(sv[1 + 3 * n_layers]) if p_drop > 0 else [None] * n_layers
+        return WNFn._backward_layers(ctx, dout, m2, saved, drops)
+
+    @staticmethod
+    def _backward_layers(ctx, dout, m2, saved, drops):
+        n_layers, dil_rate, p_drop, has_cond, B, H, T = ctx.cfg
         params, plan = ctx.params, ctx.plan
         dev = dout.device
         sink = _GradSink(params)
@@ -526,3 +590,45 @@ class WNFn(Function):
             wgrad.join()
             results = sink.results()
         return (dx_next, None, dcond, None, None, None, None, *results)
+
+    @staticmethod
+    def _backward_native(ctx, dout):
+        import ctypes
+        n_layers, dil_rate, p_drop, _, B, H, T = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        m2, x, acts, ts = sv[:4]
+        rest = sv[4:]
+        xs = rest.pop(0) if n_layers > 1 else None
+        drop_all = rest.pop(0) if p_drop > 0 else None
+        params, plan = ctx.params, ctx.plan
+        dev = dout.device
+        sink = _GradSink(params)
+        if not sink.direct or _WN_NATIVE != "both":
+            # Default: the backward is driven layer by layer from here.  The native backward (GLOWTTS_WN_NATIVE=both) saves
+            # 3.5 ms of host time per step but measured 0.5-1.1 ms SLOWER on the GPU at config 2: it needs per-layer
+            # workspaces for the whole stack at once (200 MB per block), which falls out of the 256 MB Infinity Cache that
+            # the layer-by-layer path's recycled buffers stay in.  Also taken when gradients do not exist yet.
+            ctx.native = False
+            saved = _wn_layers_from_slabs(x, xs, acts, ts, n_layers)
+            return WNFn._backward_layers(ctx, dout, m2, saved, [None] * n_layers if drop_all is None else list(drop_all))
+        taps = params[0].shape[2]
+        dskip = dout.contiguous()
+        d_rs = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.float32)
+        d_xin = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.float32)
+        dx = torch.empty(n_layers, B, H, T, device=dev, dtype=torch.float32)
+        plan.dwp.zero_()
+        tab = plan.layer_table(params, n_layers)
+        gdesc, prefix = plan.unpack_tables(params)
+        wgrad = _WgradStream(dev)
+        call("glowtts_wn_bwd", ctypes.addressof(tab), n_layers, ptr(x), ptr(xs), ptr(acts), ptr(ts), ptr(m2), ptr(drop_all),
+             1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, ptr(dskip), ptr(d_rs), ptr(d_xin), ptr(dx), ptr(gdesc), ptr(prefix),
+             len(plan.convs), plan.total_rows, B, H, T, taps, dil_rate, wgrad.side.cuda_stream if wgrad.enabled else None)
+        if wgrad.enabled:
+            for t in (x, xs, acts, d_rs, d_xin):        # read by the weight-gradient stream after this call returns
+                if t is not None:
+                    t.record_stream(wgrad.side)
+            with torch.cuda.stream(wgrad.side):         # listeners (the DP reducer) must wait on the stream that un-packs
+                results = sink.results()
+        else:
+            results = sink.results()
+        return (dx[0], None, None, None, None, None, None, *results)

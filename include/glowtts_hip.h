@@ -179,6 +179,32 @@ int glowtts_unpack_weight_grad_multi(const long long *desc, const int *row_prefi
 int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale, float *da,
                         int B, int H, int T, glowtts_stream_t stream);
 
+/* ---- a whole WN stack per call (csrc/wn_stack.hip): the host-side launch sequence of layers.py:134-162 ------------
+ * One coupling block's gated conv stack without conditioning input (g == None): n_layers x [k-tap dilated conv + gate,
+ * 1x1 res/skip conv], dilation dil_rate^i, 'same' padding, hidden width H.  `layers` is a HOST array.
+ * fwd : x (B,H,T) -> skip (B,H,T) = WN output (mask folded in); slabs written for the backward:
+ *       xs (n_layers-1, B,H,T) inputs of layers 1.., acts (n_layers, B,H,T), ts (n_layers, B,2H,T) stored tanh / sigmoid;
+ *       drop (n_layers, B,2H,T) keep-mask bytes or NULL, drop_scale = 1/(1-p)
+ * bwd : dskip (B,H,T) = gradient of the output -> dx slab (n_layers, B,H,T), dx[0] = gradient of x; workspaces
+ *       d_rs, d_xin (n_layers, B,2H,T); packed weight gradients accumulate into layers[i].dwp_* (zeroed by the caller),
+ *       bias gradients into layers[i].db_*; the weight-gradient kernels and, if unpack_desc != NULL, the final
+ *       glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows) run on wgrad_stream behind
+ *       events (NULL: everything on `stream`).  The caller keeps every buffer alive until wgrad_stream has drained. */
+typedef struct glowtts_wn_layer {
+    const float *wf_in, *wb_in, *b_in;   /* packed forward / backward-data weights and bias of the k-tap in-conv */
+    const float *wf_rs, *wb_rs, *b_rs;   /* ... of the 1x1 res/skip conv (2H rows, H in the last layer) */
+    float *dwp_in, *dwp_rs;              /* packed weight-gradient accumulators [taps][H][2H] / [1][H][2H or H] */
+    float *db_in, *db_rs;                /* bias gradients, accumulated */
+} glowtts_wn_layer;
+int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask,
+                   const unsigned char *drop, float drop_scale, float *xs, float *acts, float *ts, float *skip, int B,
+                   int H, int T, int taps, int dil_rate, glowtts_stream_t stream);
+int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *xs, const float *acts,
+                   const float *ts, const float *mask, const unsigned char *drop, float drop_scale, const float *dskip,
+                   float *d_rs, float *d_xin, float *dx, const long long *unpack_desc, const int *unpack_prefix,
+                   int n_conv, int total_rows, int B, int H, int T, int taps, int dil_rate, glowtts_stream_t wgrad_stream,
+                   glowtts_stream_t stream);
+
 /* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
  * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)
  * (head h = channels [h*dk, (h+1)*dk)); emb_k / emb_v: (1 or H, 2*window+1, dk) or NULL (no relative terms);

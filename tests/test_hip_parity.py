@@ -801,6 +801,42 @@ def test_coupling_block_grouped_and_linked_paths_match_plain_autograd(G):
         assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+def test_wn_native_executor_matches_layer_by_layer_path(G):
+    """csrc/wn_stack.hip queues a whole WN stack from C (forward by default, backward with GLOWTTS_WN_NATIVE=both); the
+    same stack driven launch by launch from Python ("off") is the reference.  Dropout on, ragged mask, pre-allocated grads."""
+    from glow_tts_train import convops
+
+    torch.manual_seed(31)
+    wn = G.layers.WN(160, 192, kernel_size=5, dilation_rate=1, n_layers=4, p_dropout=0.05).cuda().train()
+    b, t = 3, 112
+    x0 = torch.randn(b, 192, t, device="cuda")
+    lens = torch.tensor([112, 90, 57], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float()[:, None]
+    r = torch.randn(b, 192, t, device="cuda")
+    old = convops._WN_NATIVE
+    outs = {}
+    try:
+        for mode in ("off", "fwd", "both"):
+            convops._WN_NATIVE = mode
+            for p in wn.parameters():
+                p.grad = torch.zeros_like(p)
+            torch.manual_seed(77)                                   # same dropout masks in every mode
+            x = (x0 * mask).clone().requires_grad_(True)
+            y = wn(x, mask)
+            (y * r).sum().backward()
+            torch.cuda.synchronize()
+            outs[mode] = (y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in wn.named_parameters()})
+    finally:
+        convops._WN_NATIVE = old
+    y0, dx0, g0 = outs["off"]
+    for mode in ("fwd", "both"):
+        y1, dx1, g1 = outs[mode]
+        assert_close(y1, y0, what=f"{mode}: y", rtol=1e-6, atol=1e-6)
+        assert_close(dx1, dx0, what=f"{mode}: dx", rtol=1e-5, atol=1e-6 * max(1.0, float(dx0.abs().max())))
+        for k in g0:
+            assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
+
+
 def test_graphed_train_step_matches_eager(G):
     """hipGraph replay of the whole step == eager launches (same kernels, same order, same on-device schedule)."""
     from glow_tts_train.train import GraphedTrainStep, train_batch
