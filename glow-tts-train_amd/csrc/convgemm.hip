@@ -44,6 +44,9 @@ enum { EPI_PLAIN = 0, EPI_GATE = 1, EPI_RESSKIP = 2, EPI_RESSKIP_LAST = 3, EPI_A
 
 struct ConvGemmParams {
     const float *x;          // (B, Cin, T) activations, batch stride x_bs elements
+    const float *x2;         // optional second source: channels [x_split, Cin) come from x2 (B, Cin - x_split, T), batch
+    long x2_bs;              //   stride x2_bs — a "virtual concat" of two tensors (x_split a multiple of 96); else null
+    int x_split;
     const float *wp;         // packed weights [taps][G = ceil(Cin/16)][M][16]: 16 consecutive input channels per row
     const float *bias;       // [M] or null
     const float *mask;       // (B, T) or null (applied where the epilogue says so)
@@ -113,7 +116,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                     p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v;
                 } else if (EPI == EPI_ADD) {
                     const float add = p.r0[(long)b * p.r_bs + (long)row * p.T + t];
-                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v + (p.mask_add ? add * m : add);
+                    const float sum = v + (p.mask_add ? add * m : add);
+                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = p.mask_out ? sum * m : sum;
                 } else if (EPI == EPI_RESSKIP) {
                     // rows [0,H): residual -> next layer input ; rows [H,2H): skip accumulation  (layers.py:157-159)
                     if (row < p.H) {
@@ -358,7 +362,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         } else if (EPI == EPI_ADD) {
             float4 ad = a;
             if (p.mask_add) { ad.x *= m.x; ad.y *= m.y; ad.z *= m.z; ad.w *= m.w; }
-            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w));
+            float4 o = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
+            if (p.mask_out) { o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, o);
         } else if (EPI == EPI_RESSKIP) {
             if (row < p.H) {
                 const long o = ((long)b * p.H + row) * p.T + t;
@@ -482,14 +488,18 @@ __global__ __launch_bounds__(256, 2) void convgemm_wd_kernel(ConvGemmParams p) {
     constexpr int NQ = (XC / 4 + 7) / 8, NG = KG / 2;
     static_assert(NQ * NG * 256 >= X4, "piece map covers the chunk");
     const int kk = tid & 15, qq = (tid >> 4) & 7, gsel = tid >> 7;
-    const int xbytes = p.Cin * p.T * 4;              // channels past Cin fall outside the descriptor: zeros
+    const int c_first = p.x2 ? p.x_split : p.Cin;    // channels served by the first source
+    const int xbytes = c_first * p.T * 4;            // channels past the source's count fall outside the descriptor: zeros
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, xbytes, 0x00020000);
+    const int x2bytes = p.x2 ? (p.Cin - p.x_split) * p.T * 4 : 0;
+    const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x2 ? p.x2 + (long)b * p.x2_bs : xb), 0, x2bytes, 0x00020000);
     int xvo[NQ];                                     // byte offset of (channel gsel*16 + kk, frame quad qq + 8 jq)
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) {
         const int t = ts + (qq + 8 * jq) * 4;
         const bool ok = (qq + 8 * jq < XC / 4) && t >= 0 && t < p.T;
-        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * 4 : xbytes;
+        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * 4 : 0x7fffffff;
     }
     const int dbase = (gsel * XC + qq * 4) * KP + kk;
     f32x4 xreg[NG][NQ];
@@ -498,12 +508,15 @@ __global__ __launch_bounds__(256, 2) void convgemm_wd_kernel(ConvGemmParams p) {
         Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
     }
     auto xload = [&](int c) {
+        // a chunk (96 channels) lies entirely in one source: the choice is uniform over the workgroup
+        const bool second = p.x2 != nullptr && c * KG * 16 >= p.x_split;
+        const int cbase = c * KG * 16 - (second ? p.x_split : 0);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
             for (int jq = 0; jq < NQ; ++jq)
                 xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    xrs, xvo[jq], ((c * KG + 2 * gi) * 16) * p.T * 4, 0));
+                    second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * 4, 0));
     };
     auto xstore = [&]() {
 #pragma unroll
@@ -576,6 +589,9 @@ __global__ __launch_bounds__(256, 2) void convgemm_wd_kernel(ConvGemmParams p) {
 struct ConvWrwParams {
     const float *x;      // (B, Cin, T) forward input, batch stride x_bs
     const float *d;      // (B, M, T) output gradient, batch stride d_bs
+    const float *d2;     // optional: rows [d_split, M) come from d2 (B, M - d_split, T), batch stride d2_bs (d_split % 64 == 0)
+    long d2_bs;
+    int d_split;
     float *dwp;          // [taps][Cin][M] accumulated (atomics)
     float *dbias;        // [M] accumulated row sums of (masked) d, or null
     const float *mask;   // (B, T): multiply d by it while staging, or null
@@ -899,9 +915,14 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
     const bool masked = (p.mask != nullptr) || (p.mask_x != nullptr);
 
     const int xbytes = (int)(((long)(p.B - 1) * p.x_bs + (long)p.Cin * p.T) * 4);
-    const int dbytes = (int)(((long)(p.B - 1) * p.d_bs + (long)p.M * p.T) * 4);
+    // the 64 output-gradient rows of this workgroup lie entirely in one of the (up to) two d sources
+    const bool d_second = p.d2 != nullptr && m0 >= p.d_split;
+    const int m_rows = d_second ? p.M - p.d_split : (p.d2 ? p.d_split : p.M);   // rows of the chosen source
+    const int m_base = d_second ? m0 - p.d_split : m0;                        // first row of this tile inside it
+    const long d_bs = d_second ? p.d2_bs : p.d_bs;
+    const int dbytes = (int)(((long)(p.B - 1) * d_bs + (long)m_rows * p.T) * 4);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.d), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d_second ? p.d2 : p.d), 0, dbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t mdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask), 0, p.mask ? p.B * p.T * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask_x), 0, p.mask_x ? p.B * p.T * 4 : 0, 0x00020000);
     constexpr int kOOB = 0x7fffffff;
@@ -921,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
         const int idx = tid + i * 256;
         const int q = idx % (CT / 4), r = idx / (CT / 4);
         dq[i] = q * 4;
-        drow[i] = (idx < D4 && m0 + r < p.M) ? (m0 + r) * p.T : -1;
+        drow[i] = (idx < D4 && m_base + r < m_rows) ? (m_base + r) * p.T : -1;
     }
     // mask windows: thread tid < XC/4 carries 4 x-mask frames, thread 64 + j < 64 + CT/4 carries 4 d-mask frames
     const bool mx_thread = tid < XC / 4, md_thread = tid >= 64 && tid < 64 + CT / 4;
@@ -930,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
         const int b = (c0 + c) / nct;
         const int tc = ((c0 + c) % nct) * CT;
         const int ts = tc - PAD - OFF;
-        const int xb = b * (int)p.x_bs, db = b * (int)p.d_bs;
+        const int xb = b * (int)p.x_bs, db = b * (int)d_bs;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int t = ts + xq[i];
@@ -1361,9 +1382,9 @@ extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, con
                 : dispatch_convgemm<EPI_RESSKIP>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *wp_b, const float *ts, const unsigned char *drop,
-                                     float drop_scale, float *d_pre, int B, int M_rs, int H, int T,
-                                     glowtts_stream_t stream) {
+extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *d_rs2, const float *wp_b, const float *ts,
+                                     const unsigned char *drop, float drop_scale, float *d_pre, int B, int M_rs, int H,
+                                     int T, glowtts_stream_t stream) {
     if (int rc = check_conv_common("glowtts_conv_gate_bwd", d_rs, wp_b, B, M_rs, H, T, 1, 1, 0)) return rc;
     GLOWTTS_CHECK_ARG(ts && d_pre, "glowtts_conv_gate_bwd: null pointer");
     GLOWTTS_CHECK_ARG(H % 4 == 0, "glowtts_conv_gate_bwd: hidden width %d must be a multiple of 4", H);
@@ -1371,7 +1392,33 @@ extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *wp_b, const
     ConvGemmParams p{};
     p.x = d_rs; p.wp = wp_b; p.r0 = ts; p.drop = drop; p.drop_scale = drop_scale; p.y0 = d_pre;
     p.x_bs = (long)M_rs * T; p.B = B; p.Cin = M_rs; p.M = H; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
+    if (d_rs2) {    // d_rs = rows [0, H) as (B,H,T), d_rs2 = rows [H, 2H) as (B,H,T): never concatenated in memory
+        GLOWTTS_CHECK_ARG(M_rs == 2 * H && H % 96 == 0 && T % 4 == 0 && aligned16(d_rs) && aligned16(d_rs2),
+                          "glowtts_conv_gate_bwd: two-source input needs M_rs == 2H, H %% 96 == 0, T %% 4 == 0, 16-byte rows");
+        p.x_bs = (long)H * T; p.x2 = d_rs2; p.x2_bs = (long)H * T; p.x_split = H;
+    }
     return dispatch_convgemm<EPI_GATEBWD>(p, (hipStream_t)stream);
+}
+
+extern "C" int glowtts_conv_wrw2(const float *x, long x_bs, const float *d, long d_bs, const float *d2, long d2_bs,
+                                 int d_split, float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil,
+                                 int pad, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && d && d2 && dwp, "glowtts_conv_wrw2: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && Cin > 0 && M > 0 && T >= 0 && d_split > 0 && d_split < M, "glowtts_conv_wrw2: bad shape");
+    GLOWTTS_CHECK_ARG((taps == 1 || taps == 3 || taps == 5) && dil == 1 && pad == (taps - 1) / 2 && T % 4 == 0 &&
+                          d_split % 64 == 0 && aligned16(x) && aligned16(d) && aligned16(d2) && x_bs % 4 == 0 &&
+                          d_bs % 4 == 0 && d2_bs % 4 == 0,
+                      "glowtts_conv_wrw2: the two-source weight gradient needs taps in {1,3,5}, dilation 1, 'same' padding, "
+                      "T %% 4 == 0, d_split %% 64 == 0 and 16-byte aligned rows");
+    if ((long)B * T == 0) return 0;
+    ConvWrwParams p{};
+    p.x = x; p.d = d; p.d2 = d2; p.d2_bs = d2_bs; p.d_split = d_split; p.dwp = dwp; p.dbias = dbias; p.x_bs = x_bs; p.d_bs = d_bs;
+    p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
+    hipStream_t s = (hipStream_t)stream;
+    const bool n5 = (T % 80 == 0) || ((T + 79) / 80) * 80 <= ((T + 63) / 64) * 64;
+    if (taps == 5) return n5 ? launch_wrw_fp<5, 5>(p, s) : launch_wrw_fp<5, 4>(p, s);
+    if (taps == 3) return n5 ? launch_wrw_fp<3, 5>(p, s) : launch_wrw_fp<3, 4>(p, s);
+    return n5 ? launch_wrw_fp<1, 5>(p, s) : launch_wrw_fp<1, 4>(p, s);
 }
 
 extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask,

@@ -94,7 +94,7 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
                                     last ? 1 : 0, stream));
         if (last) dsk = drs_i;
         // d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs)
-        WN_TRY(glowtts_conv_gate_bwd(drs_i, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i, B,
+        WN_TRY(glowtts_conv_gate_bwd(drs_i, nullptr, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i, B,
                                      m_rs, H, T, stream));
         // dx_i = (residual path) d_rs[:H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
         WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, nullptr, last ? nullptr : drs_i,

@@ -43,7 +43,8 @@ _SIGNATURES = {
     "glowtts_conv_fwd": [_P, _L, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_gate_fwd": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_res_skip_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
-    "glowtts_conv_gate_bwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I],
+    "glowtts_conv_gate_bwd": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I],
+    "glowtts_conv_wrw2": [_P, _L, _P, _L, _P, _L, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_wrw": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_chan_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],

@@ -536,6 +536,10 @@ class WNFn(Function):
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         plan.dwp.zero_()                                # ONE memset for every packed weight gradient of the stack
         wgrad = _WgradStream(dev)
+        # virtual concat of d_rs (no res_skip_bwd launch, no d_rs tensor): needs the frame-packed wrw and whole 96-channel
+        # chunks per source, gradients written in place, no conditioning input and unit dilation
+        two_src = (sink.direct and not has_cond and dil_rate == 1 and H % 192 == 0 and T % 4 == 0 and _hip.timing_off()
+                   and all(params[6 * j + 5] is not None for j in range(n_layers)))
         for i in reversed(range(n_layers)):
             in_v, in_g, in_b, rs_v, rs_g, rs_b = params[6 * i: 6 * i + 6]
             x_i, acts, ts = saved[3 * i: 3 * i + 3]
@@ -546,6 +550,28 @@ class WNFn(Function):
             pad = (taps * dil - dil) // 2
             last = i == n_layers - 1
             m_rs = H if last else 2 * H
+            d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
+            if two_src and not last:
+                # d_rs = [dx_{i+1} mask ; dskip] is never written: dx_{i+1} left the layer above already masked, and the two
+                # kernels that read d_rs take its halves from the two tensors (conv_gate_bwd / conv_wrw2)
+                half = dx_next
+
+                def wg_rs(half=half, dskip=dskip, acts=acts, i=i):
+                    call("glowtts_conv_wrw2", ptr(acts), acts.stride(0), ptr(half), H * T, ptr(dskip), H * T, H,
+                         ptr(plan.dwp_view(2 * i + 1)), ptr(sink.buf(6 * i + 5)), B, H, 2 * H, T, 1, 1, 0,
+                         tag=("M%d K%dx1 N%dx%d", 2 * H, H, B, T))
+                wgrad.run(wg_rs, half, dskip, acts)
+                call("glowtts_conv_gate_bwd", ptr(half), ptr(dskip), ptr(wb_rs), ptr(ts), ptr(drops[i]), scale, ptr(d_xin), B,
+                     2 * H, H, T, tag=("M%d K%dx1 N%dx%d", H, 2 * H, B, T))
+                wgrad.run(lambda: _weight_grads(x_i, d_xin, None, (taps, H, 2 * H), in_v, in_g, inv_in, sink.buf(6 * i),
+                                                sink.buf(6 * i + 1), sink.buf(6 * i + 2), taps, dil, pad,
+                                                dwp=plan.dwp_view(2 * i), unpack=False), d_xin, x_i)
+                dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
+                # dx_i = half (residual path) + W_in^T (*) d_xin, masked on the way out unless it is the stack's own input grad
+                conv_fwd(d_xin, wb_in, None, m2 if i > 0 else None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
+                         addend=half, mask_out=i > 0)
+                dx_next = dx
+                continue
             d_rs = torch.empty(B, m_rs, T, device=dev, dtype=torch.float32)
             call("glowtts_res_skip_bwd", None if last else ptr(dx_next), ptr(dskip), ptr(m2), None, ptr(d_rs), B, H, T, int(last))
             if last:
@@ -553,7 +579,6 @@ class WNFn(Function):
             wgrad.run(lambda: _weight_grads(acts, d_rs, None, (1, H, m_rs), rs_v, rs_g, inv_rs, sink.buf(6 * i + 3),
                                             sink.buf(6 * i + 4), sink.buf(6 * i + 5), 1, 1, 0, dwp=plan.dwp_view(2 * i + 1),
                                             unpack=not sink.direct), d_rs, acts)
-            d_xin = torch.empty(B, 2 * H, T, device=dev, dtype=torch.float32)
             if has_cond and drops[i] is not None:
                 # conditioning is added after the dropout: its gradient is the un-dropped pre-activation gradient, so
                 # d(acts) is needed twice and is materialised
@@ -565,7 +590,7 @@ class WNFn(Function):
                 dconds[i] = tmp.sum(-1)
             else:
                 # d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs): one kernel, d(acts) stays on chip
-                call("glowtts_conv_gate_bwd", ptr(d_rs), ptr(wb_rs), ptr(ts), ptr(drops[i]), scale, ptr(d_xin), B, m_rs, H, T,
+                call("glowtts_conv_gate_bwd", ptr(d_rs), None, ptr(wb_rs), ptr(ts), ptr(drops[i]), scale, ptr(d_xin), B, m_rs, H, T,
                      tag=("M%d K%dx1 N%dx%d", H, m_rs, B, T))
                 if has_cond:
                     dconds[i] = d_xin.sum(-1)
@@ -573,9 +598,11 @@ class WNFn(Function):
                                             sink.buf(6 * i + 1), sink.buf(6 * i + 2), taps, dil, pad, dwp=plan.dwp_view(2 * i),
                                             unpack=not sink.direct), d_xin, x_i)
             dx = torch.empty(B, H, T, device=dev, dtype=torch.float32)
-            # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
-            conv_fwd(d_xin, wb_in, None, None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
-                     addend=None if last else d_rs[:, :H])
+            # dx_i = (residual path) d_rs[:, :H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path.  With
+            # the two-source scheme the layer below reads dx_i as the first half of ITS d_rs, so the mask goes on here.
+            mask_here = two_src and i > 0
+            conv_fwd(d_xin, wb_in, None, m2 if mask_here else None, dx, 2 * H, H, taps, dil, (taps - 1) * dil - pad,
+                     addend=None if last else d_rs[:, :H], mask_out=mask_here)
             dx_next = dx
         dcond = None
         if has_cond:

@@ -158,8 +158,15 @@ int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, co
 int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
                               const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B, int H, int T,
                               int last, glowtts_stream_t stream);
-int glowtts_conv_gate_bwd(const float *d_rs, const float *wp_b, const float *ts, const unsigned char *drop,
-                          float drop_scale, float *d_pre, int B, int M_rs, int H, int T, glowtts_stream_t stream);
+int glowtts_conv_gate_bwd(const float *d_rs, const float *d_rs2, const float *wp_b, const float *ts,
+                          const unsigned char *drop, float drop_scale, float *d_pre, int B, int M_rs, int H, int T,
+                          glowtts_stream_t stream);
+/* two-source forms: d_rs = [dx_next * mask ; dskip] of a WN layer is never concatenated in memory — conv_gate_bwd reads
+ * rows [0,H) from d_rs (B,H,T) and rows [H,2H) from d_rs2 (B,H,T) when d_rs2 != NULL, and conv_wrw2 takes the output
+ * gradient rows [0,d_split) from d and [d_split,M) from d2 (d_split % 64 == 0; dilation 1, 'same' padding, no masks) */
+int glowtts_conv_wrw2(const float *x, long x_bs, const float *d, long d_bs, const float *d2, long d2_bs, int d_split,
+                      float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
+                      glowtts_stream_t stream);
 int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, const float *mask_x,
                      float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
                      glowtts_stream_t stream);
