@@ -33,6 +33,7 @@ def dec_forward(*a, **k):
 
 model.decoder.forward = dec_forward
 rows = []
+side_rows = []
 for _ in range(12):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     ev[0].record()
@@ -43,6 +44,12 @@ for _ in range(12):
         ev[1].record()
         loss.backward()
         ev[2].record()
+        from glow_tts_train import _hip as H
+        side_ev = {}
+        for key, st in H._side_streams.items():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            side_ev[key[1]] = e
         join_side_streams()
         flush_groups()
         ev[3].record()
@@ -50,6 +57,7 @@ for _ in range(12):
     opt.step()
     ev[4].record()
     torch.cuda.synchronize()
+    side_rows.append({k: ev[1].elapsed_time(e) for k, e in side_ev.items()})
     rows.append([ev[0].elapsed_time(marks["dec0"]), marks["dec0"].elapsed_time(marks["dec1"]), marks["dec1"].elapsed_time(ev[1]),
                  ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3]), ev[3].elapsed_time(ev[4]), ev[0].elapsed_time(ev[4])])
 import numpy as np  # noqa: E402
@@ -57,3 +65,5 @@ r = np.median(np.array(rows[2:]), axis=0)
 for n, v in zip(["zero_grad+enc launch .. decoder start", "decoder forward (main)", "join enc + MAS + losses", "backward (main chain)",
                  "wait side streams", "clip + adam", "TOTAL (sync per step)"], r):
     print(f"{n:40s} {v:7.2f} ms")
+for k in side_rows[-1]:
+    print(f"backward start -> end of '{k}' stream queue   {np.median([r[k] for r in side_rows[2:]]):7.2f} ms")
