@@ -1272,6 +1272,18 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     const bool pipe_ok = (p.T % 4 == 0) && aligned16(p.x) && (p.x_bs % 4 == 0) &&
                          (!p.mask_in || aligned16(p.mask)) && ((p.taps - 1) * p.dil <= 12) &&
                          (EPI != EPI_GATE || p.H % 4 == 0);
+    // Small problems (the text encoder: T = 160) give only ~190 workgroups with 80-frame tiles — less than one per CU.
+    // 32-frame tiles fill the chip (480+ workgroups): -15..20 % on the encoder's 3-tap and 1-tap convs.  At the decoder's
+    // T' = 400 (480 workgroups already) the smaller tiles only lose operand reuse, so the switch is on the grid size.
+    if constexpr (EPI == EPI_PLAIN) if (pipe_ok) {
+        const int rows_per = big ? 128 : 64;
+        const long wg5 = (long)((p.T + 79) / 80) * p.B * ((p.M + rows_per - 1) / rows_per);
+        const int t32 = ((p.T + 31) / 32) * 32;
+        if (wg5 < 440 && t32 * 10 <= p.T * 11) {
+            if (big) return dispatch_taps<2, 2, EPI>(p, s, pipe_ok);
+            return dispatch_taps<1, 2, EPI>(p, s, pipe_ok);
+        }
+    }
     if (EPI == EPI_GATE) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);
     if (big) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);
     return n5 ? dispatch_taps<1, 5, EPI>(p, s, pipe_ok) : dispatch_taps<1, 4, EPI>(p, s, pipe_ok);
