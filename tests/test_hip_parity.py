@@ -837,6 +837,42 @@ def test_wn_native_executor_matches_layer_by_layer_path(G):
             assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+@pytest.mark.parametrize("b,h,t,k,nl,dil,prealloc", [
+    (2, 16, 37, 5, 3, 1, False),      # rows not 16-byte aligned (T % 4 != 0): generic kernels
+    (3, 48, 52, 3, 2, 2, True),       # dilation 2 (pipe wrw fallback), grads pre-allocated (direct sinks, no two-source)
+    (2, 192, 96, 5, 4, 1, True),      # the fast paths: native forward, two-source backward, wgrad un-packing
+    (1, 192, 400, 5, 2, 1, True),     # one utterance, full config-2 frame count
+    (4, 64, 160, 1, 1, 1, False),     # single layer, 1-tap "k"
+])
+def test_wn_stack_shapes_vs_oracle(G, b, h, t, k, nl, dil, prealloc):
+    """WN stack (reference layers.py:83-162) at shapes that take every kernel / host path, against the oracle (torch CPU)."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(1000 + b * 7 + h + t + k)
+    wn = G.layers.WN(2 * h, h, kernel_size=k, dilation_rate=dil, n_layers=nl, p_dropout=0.0).cuda().train()
+    x0 = torch.randn(b, h, t)
+    lens = torch.randint(max(1, t // 2), t + 1, (b,))
+    lens[0] = t
+    mask = (torch.arange(t)[None] < lens[:, None]).float()[:, None]
+    r = torch.randn(b, h, t)
+    for p in wn.parameters():
+        p.grad = torch.zeros_like(p) if prealloc else None
+    x = (x0 * mask).cuda().requires_grad_(True)
+    y = wn(x, mask.cuda())
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+
+    sd = {"wn." + k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in wn.state_dict().items()}
+    xo = (x0 * mask).clone().requires_grad_(True)
+    yo = O.wn(sd, "wn", xo, mask, None, h, nl, dil)
+    (yo * r).sum().backward()
+    assert_close(y, yo, what="y", rtol=2e-4, atol=2e-5 * max(1.0, float(yo.abs().max())))
+    assert_close(x.grad, xo.grad, what="dx", rtol=5e-4, atol=5e-5 * max(1.0, float(xo.grad.abs().max())))
+    for name, p in wn.named_parameters():
+        want = sd["wn." + name].grad
+        assert_close(p.grad, want, what=f"grad {name}", rtol=1e-3, atol=1e-4 * max(1.0, float(want.abs().max())))
+
+
 def test_graphed_train_step_matches_eager(G):
     """hipGraph replay of the whole step == eager launches (same kernels, same order, same on-device schedule)."""
     from glow_tts_train.train import GraphedTrainStep, train_batch
