@@ -579,6 +579,8 @@ def test_full_size_decoder_roundtrip_and_mas_properties(G):
     (2, 40, 72, 120, 3, 2, True, False),      # pipelined, 3 taps dilation 2, T % 40 == 0 weight-grad chunks
     (2, 192, 384, 96, 5, 2, False, False),    # pipelined 5 taps dilation 2
     (1, 16, 32, 20, 5, 4, False, False),      # halo 16 > 12: generic fallback
+    (32, 80, 192, 400, 1, 1, True, True),     # config-2 start conv: 480 workgroups -> 80-frame tiles (PLAIN epilogue)
+    (32, 192, 768, 160, 3, 1, False, False),  # config-2 encoder FFN conv: under-filled grid -> 32-frame tiles
 ])
 def test_conv1d_fn_vs_torch(G, b, cin, cout, t, k, dil, mask_out, slice_in):
     from glow_tts_train import convops
@@ -611,10 +613,12 @@ def test_conv1d_fn_vs_torch(G, b, cin, cout, t, k, dil, mask_out, slice_in):
         (y * r.cuda()).sum().backward()
         assert_close(y, y0, what="y", rtol=1e-4, atol=1e-4)
         assert_close(xf.grad, dx0, what="dx", rtol=1e-4, atol=1e-4)
-        assert_close(vv.grad, dv0, what="dv", rtol=2e-4, atol=2e-4)
-        assert_close(bb.grad, db0, what="db", rtol=2e-4, atol=2e-4)
+        # weight gradients sum B*T products in fp32 (split-K atomics here, a different order in the CPU reference):
+        # the absolute error scales with the largest entry of the reduction, not with each small entry
+        assert_close(vv.grad, dv0, what="dv", rtol=2e-4, atol=2e-4 * max(1.0, float(dv0.abs().max())))
+        assert_close(bb.grad, db0, what="db", rtol=2e-4, atol=2e-4 * max(1.0, float(db0.abs().max())))
         if use_g:
-            assert_close(gg.grad, dg0, what="dg", rtol=2e-4, atol=2e-4)
+            assert_close(gg.grad, dg0, what="dg", rtol=2e-4, atol=2e-4 * max(1.0, float(dg0.abs().max())))
 
 
 def test_conv_grads_accumulate_in_place_when_grad_exists(G):
