@@ -56,6 +56,27 @@ __device__ __forceinline__ float group16_sum(float v) {
 // The loads of one batch are independent (8 in flight per thread) — a plain `for idx` loop serialises load->store and made
 // the seven staging phases of the q-block kernel cost more than all its MFMAs.
 __device__ __forceinline__ void stage_rows64(float *dst, int pitch, const float *src, int rows, int T, int col0, int tid) {
+    if (((T | pitch | col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        // 16-byte pieces: a [96][64] tile is 6 loads per thread, ALL in flight at once — one L2 / HBM round trip per staging
+        // phase instead of three (the q-block kernel has seven such phases: they, not its MFMAs, set its duration)
+        const int total4 = rows * 16;
+        for (int base = 0; base < total4; base += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                const int r = idx >> 4, c = (idx & 15) << 2;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < total4 && col0 + c < T) v[u] = *reinterpret_cast<const float4 *>(src + (long)r * T + col0 + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total4) *reinterpret_cast<float4 *>(dst + (idx >> 4) * pitch + ((idx & 15) << 2)) = v[u];
+            }
+        }
+        return;
+    }
     const int total = rows * 64;
     for (int base = 0; base < total; base += 256 * 8) {
         float v[8];
@@ -72,6 +93,13 @@ __device__ __forceinline__ void stage_rows64(float *dst, int pitch, const float 
         }
     }
 }
+
+#ifdef GLOWTTS_TRACE   // tuning builds only (tools/trace_attn.py)
+__device__ unsigned long long g_attn_trace[1024 * 8];
+#define ATTN_TRACE(i) do { if (threadIdx.x == 0) g_attn_trace[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ATTN_TRACE(i) do { } while (0)
+#endif
 
 template <int MODE>
 __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
@@ -98,13 +126,28 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     const long pbase = ((long)b * p.H + h) * T * T;
     const bool rel = (p.e1 != nullptr) && (w >= 0);
 
+    ATTN_TRACE(0);
     // ---- stage the A block [d][64 queries] and both embedding tables --------------------------------------------------
     stage_rows64(As, kAP, Ag, dk, T, q0, tid);
-    for (int idx = tid; idx < 16 * dk; idx += 256) {
-        const int r = idx / dk, d = idx - r * dk;
-        const bool ok = rel && r <= 2 * w;
-        E1s[r * EP + d] = ok ? p.e1[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
-        E2s[r * E2P + d] = ok ? p.e2[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
+    for (int base = 0; base < 16 * dk; base += 256 * 8) {       // both tables: loads first (independent), stores after
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int r = idx / dk, d = idx - r * dk;
+            const bool ok = idx < 16 * dk && rel && r <= 2 * w;
+            v1[u] = ok ? p.e1[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
+            v2[u] = ok ? p.e2[(long)h * p.e_hs + (long)r * dk + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            const int r = idx / dk, d = idx - r * dk;
+            if (idx < 16 * dk) {
+                E1s[r * EP + d] = v1[u];
+                E2s[r * E2P + d] = v2[u];
+            }
+        }
     }
 
     // ---- phase 1: S strip (16 queries x T keys per wave) ------------------------------------------------------------------
@@ -127,6 +170,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             }
         }
     }
+    ATTN_TRACE(1);
     // ---- phase 1b: relative term R[i][r] = sum_d A[d][i] E1[r][d], added on the band j - i + w = r ----------------------
     if (rel) {
         f32x4 R = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -152,6 +196,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         }
     }
 
+    ATTN_TRACE(2);
     // ---- phase 2: softmax (MODE 0) / softmax backward (MODE 1) in registers -----------------------------------------------
     const int ntile = (T + 15) >> 4;
     float mi[4];
@@ -242,6 +287,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         }
     }
 
+    ATTN_TRACE(3);
     // ---- phase 4: O (16 queries x dk per wave) = P B2^T + PW E2 -----------------------------------------------------------
     f32x4 O[8];
 #pragma unroll
@@ -278,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         }
     }
 
+    ATTN_TRACE(4);
     // ---- phase 5: transpose O through LDS (reuse the A block) and store rows of 64 queries -----------------------------
     __syncthreads();
 #pragma unroll
@@ -291,6 +338,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         const int d = idx >> 6, i = idx & 63;
         if (q0 + i < T) og[(long)d * T + q0 + i] = As[d * kAP + i];
     }
+    ATTN_TRACE(5);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -538,3 +586,9 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     }
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn_bwd");
 }
+
+#ifdef GLOWTTS_TRACE
+extern "C" int glowtts_debug_attn_trace_read(unsigned long long *host, int n_words) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(glowtts::g_attn_trace), (size_t)n_words * 8);
+}
+#endif
