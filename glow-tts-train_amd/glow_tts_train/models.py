@@ -68,12 +68,19 @@ class TextEncoder(nn.Module):
         if not mean_only:
             self.proj_s = nn.Conv1d(hidden_channels, out_channels, 1)
         self.proj_w = DurationPredictor(hidden_channels + gin_channels, filter_channels_dp, kernel_size, p_dropout)
-        # every convolution of the encoder (q/k/v/o, FFN, prenet, projections, duration predictor): one weight-packing
-        # launch per forward and one gradient un-packing launch per backward instead of one each per conv
-        self._conv_group = convops.ConvGroup([m for m in self.modules() if isinstance(m, nn.Conv1d)])
+        # every convolution of the encoder (q/k/v/o, FFN, prenet, projections, duration predictor): a handful of weight-packing
+        # launches per forward and gradient un-packing launches per backward instead of one each per conv
+        # (one group per transformer layer + one for the rest: a layer's gradients are un-packed — and, under data
+        # parallelism, its bucket reduced — as soon as its backward is through, not when the whole encoder's is)
+        convs_of = lambda mod: [m for m in mod.modules() if isinstance(m, nn.Conv1d)]                     # noqa: E731
+        layered = [convs_of(a) + convs_of(f) for a, f in zip(self.encoder.attn_layers, self.encoder.ffn_layers)]
+        taken = {id(m) for grp in layered for m in grp}
+        rest = [m for m in convs_of(self) if id(m) not in taken]
+        self._conv_groups = [convops.ConvGroup(grp) for grp in layered + [rest] if grp]
 
     def forward(self, x, x_lengths, g=None):
-        self._conv_group.begin()
+        for grp in self._conv_groups:
+            grp.begin()
         h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)          # [b, h, t]
         x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
         if self.prenet:

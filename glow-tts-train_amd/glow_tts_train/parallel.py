@@ -10,8 +10,9 @@ default width), so
   * a block's all-reduce is issued the moment its last gradient has been accumulated, i.e. while the backward of
     the blocks below it (and then of the encoder) is still running; RCCL runs on its own stream, so the
     collective overlaps the remaining flow backward;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): twelve 7 MB messages + one 29 MB encoder message keep
-    each ring step large enough to be bandwidth- rather than latency-bound without delaying the first launch.
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): twelve 7 MB messages + nine 1.5-3.6 MB encoder messages keep
+    each ring step large enough to be bandwidth- rather than latency-bound without delaying the first launch, and leave
+    only the lowest encoder layers' buckets (~10 MB) in flight when backward ends.
 
 Semantics match DDP: gradients are averaged over ranks (each rank normalises its loss by its own mask sums,
 utils.py:19-21,27) and parameters are broadcast from rank 0 once at start (which is also what makes rank 0's
@@ -28,14 +29,27 @@ import torch.distributed as dist
 from . import convops
 
 _FLOW_RE = re.compile(r"^(?:module\.)?decoder\.flows\.(\d+)\.")
+_ENC_FFN_RE = re.compile(r"^(?:module\.)?encoder\.encoder\.ffn_layers\.(\d+)\.")
 
 
 def default_bucket_key(name: str) -> str:
+    """One bucket per flow block (7.1 MB).  The text encoder (28.8 MB) is cut where its parameters are contiguous in
+    construction order: embedding + prenet, the attention layers (3.6 MB together), one bucket per FFN layer (3.5 MB each:
+    a layer's gradients are complete, and un-packed, as soon as its backward is through — layer 5 first), and the tail
+    (projections, duration predictor).  Only the buckets of the lowest layers are still in flight when backward ends."""
     m = _FLOW_RE.match(name)
     if m:
         return f"dec{int(m.group(1)) // 3:03d}"
-    if name.startswith("encoder.") or name.startswith("module.encoder."):
-        return "enc"
+    m = _ENC_FFN_RE.match(name)
+    if m:
+        return f"enc.ffn{int(m.group(1))}"
+    core = name[len("module."):] if name.startswith("module.") else name
+    if core.startswith("encoder."):
+        if core.startswith("encoder.emb.") or core.startswith("encoder.pre."):
+            return "enc.head"
+        if core.startswith("encoder.encoder.attn_layers.") or core.startswith("encoder.encoder.norm_layers_1."):
+            return "enc.attn"
+        return "enc.tail"
     return "misc"
 
 

@@ -266,7 +266,7 @@ def test_flow_block_reducer_gloo_world2():
         assert p.exitcode == 0
     (_, keys0, l0, p0, g0), (_, keys1, l1, p1, g1) = res
     p0, g0, p1, g1 = (torch.from_numpy(a) for a in (p0, g0, p1, g1))
-    assert keys0 == ["enc", "dec000", "dec001", "misc"] == keys1     # 6 flows -> 2 blocks of 3
+    assert keys0 == ["enc.tail", "dec000", "dec001", "misc"] == keys1     # 6 flows -> 2 blocks of 3; toy encoder = one run
     assert l0 >= 2 and l1 >= 2          # decoder buckets were reduced while backward was still running
     assert torch.equal(p0, p1), "parameters differ after broadcast"
     assert torch.equal(g0, g1), "averaged gradients differ between ranks"
@@ -293,7 +293,28 @@ def test_reducer_single_process_is_a_noop():
     red.finish()
     red.broadcast_parameters()
     sizes = [(b.key, b.hi - b.lo) for b in red.buckets]
-    assert sizes[0][0] == "enc" and all(s > 0 for _, s in sizes)
+    assert sizes[0][0].startswith("enc") and all(s > 0 for _, s in sizes)
     # buckets tile the flat buffer in order without overlap
     for a, b in zip(red.buckets, red.buckets[1:]):
         assert a.hi <= b.lo
+
+
+def test_default_bucket_keys_cut_the_encoder_per_ffn_layer():
+    """DP buckets: one per flow block, and inside the text encoder one per FFN layer / attention stack / head / tail —
+    contiguous runs of the parameter order, so each is a slice of the flat gradient buffer."""
+    from glow_tts_train import config, models, parallel
+
+    cfg = config.TrainingConfig()
+    cfg.model.num_symbols = 148
+    model, _ = models.setup_model(cfg, use_cuda=False, create_optimizer=False)
+    runs = []
+    for name, p in model.named_parameters():
+        k = parallel.default_bucket_key(name)
+        if not runs or runs[-1][0] != k:
+            runs.append([k, 0])
+        runs[-1][1] += p.numel()
+    keys = [k for k, _ in runs]
+    assert len(keys) == len(set(keys)), "a bucket key must name ONE contiguous run of parameters"
+    assert keys[:9] == ["enc.head", "enc.attn"] + [f"enc.ffn{i}" for i in range(6)] + ["enc.tail"]
+    assert keys[9:] == [f"dec{i:03d}" for i in range(12)]
+    assert sum(n for _, n in runs) == sum(p.numel() for p in model.parameters())
