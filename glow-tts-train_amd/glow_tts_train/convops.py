@@ -453,7 +453,7 @@ class WNFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, *params):
+    def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, drop_pre, *params):
         # params: per layer (in_v, in_g, in_b, rs_v, rs_g, rs_b); plan: the module's WNPackPlan
         x = f32(x.contiguous())
         B, H, T = x.shape
@@ -465,7 +465,10 @@ class WNFn(Function):
         plan.pack()
         drop_all = None
         if p_drop > 0.0:
-            drop_all = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
+            if drop_pre is not None and tuple(drop_pre.shape) == (n_layers, B, 2 * H, T) and drop_pre.is_contiguous():
+                drop_all = drop_pre                     # drawn by the caller (one generator launch for all coupling blocks)
+            else:
+                drop_all = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
         ctx.native = False
         if cond is None and _hip.timing_off() and _WN_NATIVE != "off" and all(params[3 * j + 2] is not None for j in range(2 * n_layers)):
             # the whole launch sequence of the stack in one native call (csrc/wn_stack.hip): four allocations, one ctypes
@@ -616,7 +619,7 @@ class WNFn(Function):
         else:
             wgrad.join()
             results = sink.results()
-        return (dx_next, None, dcond, None, None, None, None, *results)
+        return (dx_next, None, dcond, None, None, None, None, None, *results)
 
     @staticmethod
     def _backward_native(ctx, dout):
@@ -658,4 +661,4 @@ class WNFn(Function):
                 results = sink.results()
         else:
             results = sink.results()
-        return (dx[0], None, None, None, None, None, None, *results)
+        return (dx[0], None, None, None, None, None, None, None, *results)

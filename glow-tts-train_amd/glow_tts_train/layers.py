@@ -115,7 +115,8 @@ class WN(nn.Module):
         p_drop = float(self.p_dropout) if self.training else 0.0
         if not hasattr(self, "_pack_plan"):
             self._pack_plan = convops.WNPackPlan()
-        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, *flat)
+        drop_pre, self._drop_pre = getattr(self, "_drop_pre", None), None     # keep-masks drawn ahead by FlowSpecDecoder
+        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, drop_pre, *flat)
 
     def remove_weight_norm(self):
         if self.gin_channels != 0:

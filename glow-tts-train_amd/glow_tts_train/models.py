@@ -129,6 +129,17 @@ class FlowSpecDecoder(nn.Module):
             x_len = ops.mask_len(ops.mask2d(x_mask))
             logdets = []                               # summed once at the end: one stack + one sum instead of 24 adds
             m2 = ops.mask2d(x_mask)
+            # dropout keep-masks of EVERY coupling block's WN stack from one generator launch (12 launches of 20 MB each
+            # sat on the forward's dependency chain: 0.26 ms per step); block k takes slice k
+            blocks = [f for f in self.flows if isinstance(f, CouplingBlock)]
+            if (x.is_cuda and self.training and blocks and self.p_dropout > 0
+                    and all(f.wn.n_layers == blocks[0].wn.n_layers and f.wn.hidden_channels == blocks[0].wn.hidden_channels
+                            and f.wn.p_dropout == blocks[0].wn.p_dropout and f.wn.training for f in blocks)):
+                wn0 = blocks[0].wn
+                masks = torch.empty(len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2), device=x.device,
+                                    dtype=torch.uint8).bernoulli_(1.0 - float(wn0.p_dropout))
+                for k, f in enumerate(blocks):
+                    f.wn._drop_pre = masks[k]
             i = 0
             while i < len(self.flows):
                 f = self.flows[i]
