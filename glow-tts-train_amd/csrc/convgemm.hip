@@ -874,18 +874,19 @@ __global__ __launch_bounds__(256) void convwrw_pipe_kernel(ConvWrwParams p) {
 // ------------------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int cpitch4(int w) { int p = (w + 3) / 4 * 4; while (p % 8 != 4) p += 4; return p; }
 
-template <int TAPS, int NGRP>
-__global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
+template <int TAPS, int NGRP, int MT>      // MT = 16-row output-gradient tiles per wave: workgroup tile 64 k x 16*MT m
+__global__ __launch_bounds__(256, (MT <= 2 ? 3 : 2)) void convwrw_fp_kernel(ConvWrwParams p) {
+    constexpr int MR = 16 * MT;
     constexpr int CT = 16 * NGRP, XC = CT + 16;
     constexpr int XP = cpitch4(XC), DP = cpitch4(CT);
     constexpr int PAD = (TAPS - 1) / 2, OFF = (4 - (PAD & 3)) & 3;
     constexpr int NA = (3 + TAPS + OFF + 3) / 4;                 // b128 reads covering floats [0, 3 + TAPS - 1 + OFF]
-    constexpr int X4 = 64 * (XC / 4), D4 = 64 * (CT / 4);
+    constexpr int X4 = 64 * (XC / 4), D4 = MR * (CT / 4);
     constexpr int NX = (X4 + 255) / 256, ND = (D4 + 255) / 256;
     extern __shared__ __align__(16) float smem[];
     float *Xs = smem;                        // [64][XP]
-    float *Ds = smem + 64 * XP;              // [64][DP]
-    float *Mx = Ds + 64 * DP;                // [XC]  x-mask window of the chunk being stored
+    float *Ds = smem + 64 * XP;              // [MR][DP]
+    float *Mx = Ds + MR * DP;                // [XC]  x-mask window of the chunk being stored
     float *Md = Mx + XC;                     // [CT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
@@ -897,16 +898,16 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
     const int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
     const int tile = item % ntiles, split = item / ntiles;
     const int kt = tile % nkt, mt = tile / nkt;
-    const int k0 = kt * 64, m0 = mt * 64;
+    const int k0 = kt * 64, m0 = mt * MR;
     const int nct = (p.T + CT - 1) / CT;
     const int c0 = split * p.nb;
     const int nchunks = min(p.B * nct, c0 + p.nb) - c0;
 
-    f32x4 acc[TAPS][4];
+    f32x4 acc[TAPS][MT];
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xreg[NX], dreg[ND], mreg;
     float bsum[ND];
 #pragma unroll
@@ -1001,12 +1002,12 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
     const float *xa = Xs + (wave * 16 + lrow) * XP + lk * 4;
     const float *db_ = Ds + lrow * DP + lk * 4;
     auto compute = [&]() {
-        f32x4 av[2][NA], bv[2][4];
+        f32x4 av[2][NA], bv[2][MT];
         auto fetch = [&](int g, int sl) {
 #pragma unroll
             for (int n = 0; n < NA; ++n) av[sl][n] = *reinterpret_cast<const f32x4 *>(xa + g * 16 + n * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[sl][i] = *reinterpret_cast<const f32x4 *>(db_ + i * 16 * DP + g * 16);
+            for (int i = 0; i < MT; ++i) bv[sl][i] = *reinterpret_cast<const f32x4 *>(db_ + i * 16 * DP + g * 16);
         };
         fetch(0, 0);
 #pragma unroll
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
 #pragma unroll
                 for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MT; ++i)
                         acc[tp][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sl][(j + tp + OFF) >> 2][(j + tp + OFF) & 3],
                                                                           bv[sl][i][j], acc[tp][i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1046,12 +1047,12 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
         if (c == 0) GLOWTTS_TRACE_POINT_Z(3);
     }
     GLOWTTS_TRACE_POINT_Z(4);
-    if (k0 + 64 <= p.Cin && m0 + 64 <= p.M) {         // whole tile inside (workgroup-uniform): no per-lane predicates
+    if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {         // whole tile inside (workgroup-uniform): no per-lane predicates
         float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg)
                     atomicAdd(base + ((long)tp * p.Cin + reg) * p.M + i * 16, acc[tp][i][reg]);
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int k = k0 + wave * 16 + lk * 4 + reg;
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
     }
     if (do_bias) {
         float *rowacc = smem;                           // the image is dead: every wave passed the last barrier
-        if (tid < 64) rowacc[tid] = 0.f;
+        if (tid < MR) rowacc[tid] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_fp_kernel(ConvWrwParams p) {
             if (idx < D4) atomicAdd(rowacc + idx / (CT / 4), bsum[i]);
         }
         __syncthreads();
-        if (tid < 64 && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
+        if (tid < MR && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
     }
     GLOWTTS_TRACE_POINT_Z(10);
 }
@@ -1289,28 +1290,38 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     return n5 ? dispatch_taps<1, 5, EPI>(p, s, pipe_ok) : dispatch_taps<1, 4, EPI>(p, s, pipe_ok);
 }
 
-template <int TAPS, int NGRP>
-static int launch_wrw_fp(ConvWrwParams &p, hipStream_t s) {
-    constexpr int CT = 16 * NGRP;
-    constexpr size_t lds = ((size_t)64 * cpitch4(CT + 16) + (size_t)64 * cpitch4(CT) + (CT + 16) + CT) * sizeof(float);
+template <int TAPS, int NGRP, int MT>
+static int launch_wrw_fp_mt(ConvWrwParams &p, hipStream_t s) {
+    constexpr int CT = 16 * NGRP, MR = 16 * MT;
+    constexpr size_t lds = ((size_t)64 * cpitch4(CT + 16) + (size_t)MR * cpitch4(CT) + (CT + 16) + CT) * sizeof(float);
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     static size_t attr_max_e = 0;
     if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_fp_kernel<TAPS, NGRP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_fp_kernel<TAPS, NGRP, MT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
         attr_max_e = (size_t)lds;
     }
     // all workgroups resident at once (2 per CU: 512 slots); p.nb = chunks of CT frames per workgroup
-    const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);
+    const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
     const int total = p.B * ((p.T + CT - 1) / CT);
-    int splits = 512 / tiles;
+    int splits = (MT <= 2 ? 768 : 512) / tiles;
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
     dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
-    hipLaunchKernelGGL((convwrw_fp_kernel<TAPS, NGRP>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((convwrw_fp_kernel<TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
+}
+
+template <int TAPS, int NGRP>
+static int launch_wrw_fp(ConvWrwParams &p, hipStream_t s) {
+    // 5 taps: 64 k x 32 m tiles — 40 accumulator registers per lane instead of 80, so THREE workgroups fit a CU (168
+    // VGPRs, 36 KB LDS) and hide each other's prologue / atomics epilogue: 107 -> 96 us at config 2.  With 3 taps or 1 the
+    // 64 x 64 tile already leaves room for three, and the smaller tile only costs operand reuse.
+    if constexpr (TAPS == 5)
+        if (p.M % 32 == 0 && (!p.d2 || p.d_split % 32 == 0)) return launch_wrw_fp_mt<TAPS, NGRP, 2>(p, s);
+    return launch_wrw_fp_mt<TAPS, NGRP, 4>(p, s);
 }
 
 template <int TAPS, int CT>
