@@ -38,6 +38,7 @@ fns = {
     "resskip": lambda: call("glowtts_conv_res_skip_fwd", ptr(acts), ptr(wf_rs), ptr(b_in), ptr(m2), ptr(x), ptr(sk), ptr(xo), ptr(sk), B, H, T, 0),
     "bwd_data5": lambda: convops.conv_fwd(d2, wb_in, None, None, dx, 2 * H, H, 5, 1, 2, addend=d2[:, :H]),
     "bwd_data1": lambda: convops.conv_fwd(d2, wb_rs, None, None, dx, 2 * H, H, 1, 1, 0),
+    "gate_bwd": lambda: call("glowtts_conv_gate_bwd", ptr(d2), None, ptr(wb_rs), ptr(ts), None, 1.0, ptr(torch.empty_like(d2)), B, 2 * H, H, T),
     "wrw5": lambda: call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp5), None, B, H, 2 * H, T, 5, 1, 2),
     "wrw1": lambda: call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp1), None, B, H, 2 * H, T, 1, 1, 0),
 }
