@@ -183,6 +183,11 @@ def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda
 _fn_cache: dict = {}
 
 
+def all_side_streams(device):
+    idx = torch.device(device).index
+    return [s for (d, _), s in _side_streams.items() if d == idx]
+
+
 def call(name: str, *args, tag=None) -> None:
     """Launch `name` on PyTorch's current stream; raise RuntimeError with the library's message on failure.
     `tag` only labels the launch for the optional timing table: a string, or a (format, *values) tuple that is formatted

@@ -21,6 +21,26 @@ from ._hip import call, f32, ptr, scratch_zeros
 # reducer subscribes here to learn that a gradient is complete (parallel.FlowBlockReducer)
 _grad_ready_listeners: List = []
 
+# Operators add weight gradients straight into an existing `.grad` (no autograd add, no AccumulateGrad node).  A wrapper
+# that relies on AccumulateGrad hooks for EVERY parameter — torch's DistributedDataParallel — must switch this off
+# (`set_direct_grads(False)` or GLOWTTS_DIRECT_GRADS=0); `parallel.FlowBlockReducer` listens to `_notify` instead.
+_DIRECT_GRADS = __import__("os").environ.get("GLOWTTS_DIRECT_GRADS", "1") != "0"
+
+
+def set_direct_grads(enabled: bool) -> None:
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(enabled)
+
+
+def _mark_direct(params, flag: bool) -> None:
+    """Tell gradient listeners which signal to trust for a parameter.  Autograd runs a parameter's AccumulateGrad node —
+    and its post-accumulate hooks — even when an operator returns None for it, i.e. right after that operator's backward
+    returns and possibly BEFORE the in-place gradient is complete (a ConvGroup un-packs later, on another stream).  For a
+    marked parameter only `_notify` counts (parallel.FlowBlockReducer skips the hook)."""
+    for p in params:
+        if p is not None:
+            p._glowtts_direct = flag
+
 
 def add_grad_ready_listener(fn) -> None:
     _grad_ready_listeners.append(fn)
@@ -113,8 +133,10 @@ class _GradSink:
 
     def __init__(self, params):
         self.params = list(params)
-        self.direct = all(p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32)
-                          for p in self.params)
+        self.direct = _DIRECT_GRADS and all(
+            p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32)
+            for p in self.params)
+        _mark_direct(self.params, self.direct)
         self.bufs = [None if p is None else (p.grad if self.direct else torch.zeros_like(p)) for p in self.params]
 
     def buf(self, i):
@@ -387,8 +409,9 @@ class ConvGroup:
         tensors = [p for p in params if p is not None]
         self.active = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in tensors)
         if self.active and torch.is_grad_enabled() and any(p.requires_grad for p in tensors):
-            self.active = all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
+            self.active = _DIRECT_GRADS and all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
                                                         and p.grad.dtype == torch.float32) for p in tensors)
+        _mark_direct(tensors, self.active and torch.is_grad_enabled())
         if not self.active:
             return
         if self.pending > 0 and self.touched:            # a previous backward never completed: do not lose its gradients

@@ -20,13 +20,14 @@ data-dependent ActNorm initialisation win).
 """
 from __future__ import annotations
 
+import contextlib
 import re
 import typing
 
 import torch
 import torch.distributed as dist
 
-from . import convops
+from . import _hip, convops
 
 _FLOW_RE = re.compile(r"^(?:module\.)?decoder\.flows\.(\d+)\.")
 _ENC_FFN_RE = re.compile(r"^(?:module\.)?encoder\.encoder\.ffn_layers\.(\d+)\.")
@@ -100,11 +101,12 @@ class FlowBlockReducer:
         self._launched = [False] * len(self.buckets)
         self._works: typing.List[typing.Any] = []
         self._hooks = []
+        self._seen: typing.Set[int] = set()
         if self.world > 1:
             for _, p in named:
                 if p.requires_grad:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-            # gradients the conv operators write straight into .grad never pass an AccumulateGrad node
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_hook))
+            # gradients the conv operators write straight into .grad are announced by the operators themselves
             convops.add_grad_ready_listener(self._on_grad)
 
     # -- collectives ------------------------------------------------------------------------------------------
@@ -116,17 +118,39 @@ class FlowBlockReducer:
     def _launch(self, i: int):
         b = self.buckets[i]
         view = self.flat.flat_g[b.lo:b.hi]
-        if self._use_avg:
-            work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        if view.is_cuda:
+            # A bucket's gradients come from several streams (dx chain, weight-gradient stream, encoder stream) and the
+            # announcement that completes it arrives in the context of only ONE of them.  The collective is therefore issued
+            # from a launch stream that first waits for all of them — the compute streams themselves never wait.
+            comm = _hip.side_stream(view.device, "comm")
+            comm.wait_stream(torch.cuda.current_stream(view.device))
+            for s in _hip.all_side_streams(view.device):
+                if s is not comm:
+                    comm.wait_stream(s)
+            ctx = torch.cuda.stream(comm)
         else:
-            view.div_(self.world)
-            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self._use_avg:
+                work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:
+                view.div_(self.world)
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._works.append(work)
         self._launched[i] = True
 
-    def _on_grad(self, p: torch.Tensor):
-        if id(p) not in self._bucket_of:
+    def _on_hook(self, p: torch.Tensor):
+        # AccumulateGrad hooks also fire for parameters whose gradient an operator writes in place (it hands autograd None),
+        # and they fire when that operator's backward RETURNS — before a deferred un-packing on another stream has run.
+        # For those parameters (convops._mark_direct) only the operator's own announcement counts.
+        if getattr(p, "_glowtts_direct", False):
             return
+        self._on_grad(p)
+
+    def _on_grad(self, p: torch.Tensor):
+        if id(p) not in self._bucket_of or id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
         if self._pending[i] == 0 and not self._launched[i]:
@@ -141,7 +165,10 @@ class FlowBlockReducer:
                     self._launch(i)
             for w in self._works:
                 w.wait()
+            if self.flat.flat_g.is_cuda:                 # (the non-AVG path divides on the launch stream before reducing)
+                torch.cuda.current_stream(self.flat.flat_g.device).wait_stream(_hip.side_stream(self.flat.flat_g.device, "comm"))
         self._works.clear()
+        self._seen.clear()
         self._pending = [b.n_params for b in self.buckets]
         self._launched = [False] * len(self.buckets)
 

@@ -805,6 +805,44 @@ def test_coupling_block_grouped_and_linked_paths_match_plain_autograd(G):
         assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+def test_direct_grads_switch_routes_gradients_through_autograd(G):
+    """`convops.set_direct_grads(False)` (what a DistributedDataParallel wrap needs): every parameter gradient comes back
+    through autograd's AccumulateGrad — hooks fire for all of them — and equals the in-place path's result."""
+    from glow_tts_train import convops
+
+    torch.manual_seed(41)
+    blk = G.attentions.CouplingBlock(32, 48, kernel_size=3, dilation_rate=1, n_layers=2, p_dropout=0.0).cuda()
+    with torch.no_grad():
+        blk.end.weight.normal_(0, 0.05)
+    x0 = torch.randn(2, 32, 40, device="cuda")
+    mask = torch.ones(2, 1, 40, device="cuda")
+    r = torch.randn(2, 32, 40, device="cuda")
+    fired = set()
+    hooks = [p.register_post_accumulate_grad_hook(lambda p_, n=n: fired.add(n)) for n, p in blk.named_parameters()]
+    res = {}
+    try:
+        for direct in (True, False):
+            convops.set_direct_grads(direct)
+            fired.clear()
+            for p in blk.parameters():
+                p.grad = torch.zeros_like(p)
+            x = x0.clone().requires_grad_(True)
+            z, ld = blk(x, mask)
+            ((z * r).sum() + ld.sum()).backward()
+            convops.flush_groups()
+            torch.cuda.synchronize()
+            res[direct] = ({k: p.grad.clone() for k, p in blk.named_parameters()}, set(fired))
+    finally:
+        convops.set_direct_grads(True)
+        for h in hooks:
+            h.remove()
+    names = {n for n, _ in blk.named_parameters()}
+    assert res[False][1] == names, f"no AccumulateGrad event for {sorted(names - res[False][1])}"
+    for k in names:
+        want = res[True][0][k]
+        assert_close(res[False][0][k], want, what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(want.abs().max())))
+
+
 def test_wn_native_executor_matches_layer_by_layer_path(G):
     """csrc/wn_stack.hip queues a whole WN stack from C (forward by default, backward with GLOWTTS_WN_NATIVE=both); the
     same stack driven launch by launch from Python ("off") is the reference.  Dropout on, ragged mask, pre-allocated grads."""
