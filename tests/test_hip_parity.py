@@ -915,6 +915,57 @@ def test_wn_stack_shapes_vs_oracle(G, b, h, t, k, nl, dil, prealloc):
         assert_close(p.grad, want, what=f"grad {name}", rtol=1e-3, atol=1e-4 * max(1.0, float(want.abs().max())))
 
 
+def test_multi_stream_step_matches_single_stream_step(G):
+    """train_batch overlaps the text encoder, the weight-gradient kernels and the dx chain on three streams.  Three optimisation
+    steps with the overlap must leave the same parameters as three steps with everything on one stream (GLOWTTS_SIDE_STREAM=0);
+    only the order of float atomics differs.  Production widths, so the kernels are long enough for a missing dependency
+    or a recycled buffer to show."""
+    import os
+
+    from glow_tts_train.train import train_batch
+
+    def run(side):
+        old = os.environ.get("GLOWTTS_SIDE_STREAM")
+        os.environ["GLOWTTS_SIDE_STREAM"] = "1" if side else "0"
+        try:
+            torch.manual_seed(77)
+            model = G.models.FlowGenerator(n_vocab=148, hidden_channels=192, filter_channels=768, filter_channels_dp=256,
+                                           out_channels=80, kernel_size=3, n_heads=2, n_layers_enc=3, p_dropout=0.0,
+                                           n_blocks_dec=4, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
+                                           p_dropout_dec=0.0, n_split=4, n_sqz=2, window_size=4, mean_only=True,
+                                           prenet=True).cuda().train()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+            with torch.no_grad():
+                for f in model.decoder.flows:
+                    if hasattr(f, "end"):
+                        f.end.weight.normal_(0, 0.01)
+            opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=192, warmup_steps=4000, lr=1.0,
+                                  betas=(0.9, 0.98), eps=1e-9)
+            g = torch.Generator().manual_seed(5)
+            b, tx, ty = 8, 48, 240
+            x = torch.randint(1, 148, (b, tx), generator=g).cuda()
+            xl = torch.linspace(tx, tx // 2, b).long().cuda()
+            y = torch.randn(b, 80, ty, generator=g).cuda()
+            yl = torch.linspace(ty, ty // 2, b).long().cuda()
+            losses = [float(train_batch(model, opt, (x, xl, y, yl, None), 5.0)) for _ in range(3)]
+            torch.cuda.synchronize()
+            return losses, opt._optim.flat_p.detach().clone(), opt._optim.flat_g.detach().clone()
+        finally:
+            if old is None:
+                os.environ.pop("GLOWTTS_SIDE_STREAM", None)
+            else:
+                os.environ["GLOWTTS_SIDE_STREAM"] = old
+
+    l1, p1, g1 = run(True)
+    l0, p0, g0 = run(False)
+    assert all(abs(a - b) <= 1e-4 * max(1.0, abs(b)) for a, b in zip(l1, l0)), (l1, l0)
+    assert_close(g1, g0, what="last step's gradients", rtol=1e-3, atol=1e-4 * float(g0.abs().max()))
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size, so compare the update, not the weight
+    assert float((p1 - p0).abs().max()) <= 2e-3 * float(p0.abs().max()) + 1e-6
+
+
 def test_graphed_train_step_matches_eager(G):
     """hipGraph replay of the whole step == eager launches (same kernels, same order, same on-device schedule)."""
     from glow_tts_train.train import GraphedTrainStep, train_batch
