@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    float b1, float b2, float eps, float dim_model, float warmup) {
     // torch.optim.Adam (no amsgrad, no weight decay): step_size = lr_t / (1 - b1^t); denom = sqrt(v)/sqrt(1 - b2^t) + eps
     const float t = state[0];
-    const float lr_t = noam_rate(state[1], lr, dim_model, warmup);
+    // state[3] > 0: a learning rate imposed for this one update (a resumed optimizer applies the rate stored in its
+    // checkpoint before its schedule takes over again, as torch's load_state_dict leaves it in the reference)
+    const float lr_t = state[3] > 0.f ? state[3] : noam_rate(state[1], lr, dim_model, warmup);
     const double bc1 = 1.0 - pow((double)b1, (double)t);
     const double bc2 = 1.0 - pow((double)b2, (double)t);
     const float step_size = (float)((double)lr_t / bc1);
@@ -182,6 +184,7 @@ __global__ void adam_advance_kernel(float *state, float lr, float dim_model, flo
         state[0] += 1.0f;
         state[1] += 1.0f;
         state[2] = noam_rate(state[1], lr, dim_model, warmup);
+        state[3] = 0.f;
     }
 }
 

@@ -1,10 +1,14 @@
 """Hyper-parameter containers read by `models.setup_model` (field names and defaults of the reference's
-glow_tts_train/config.py:11-81).  Host-side only; JSON overlay / dataclasses_json plumbing is out of this path's scope,
-so these are plain dataclasses with a dict round-trip."""
+glow_tts_train/config.py:11-124), with the reference's JSON surface — `to_dict / from_dict / to_json / from_json`,
+`save`, `load`, `load_and_merge`, `recursive_update` — on plain dataclasses (`dataclasses_json`, which the reference
+mixes in, is not a dependency here).  Host-side only."""
 from __future__ import annotations
 
+import collections.abc
+import json
 import typing
 from dataclasses import asdict, dataclass, field, fields, is_dataclass
+from pathlib import Path
 
 
 class _DictMixin:
@@ -19,8 +23,19 @@ class _DictMixin:
                 continue
             v = d[f.name]
             sub = _NESTED.get((cls.__name__, f.name))
-            kw[f.name] = sub.from_dict(v) if (sub is not None and isinstance(v, typing.Mapping)) else v
+            if sub is not None and isinstance(v, collections.abc.Mapping):
+                v = sub.from_dict(v)
+            elif isinstance(v, list) and isinstance(getattr(cls, f.name, None), tuple):
+                v = tuple(v)                       # JSON has no tuples (betas)
+            kw[f.name] = v
         return cls(**kw)
+
+    def to_json(self, **kw) -> str:
+        return json.dumps(self.to_dict(), **kw)
+
+    @classmethod
+    def from_json(cls, text: str):
+        return cls.from_dict(json.loads(text))
 
 
 @dataclass
@@ -92,6 +107,38 @@ class TrainingConfig(_DictMixin):
     model: ModelConfig = field(default_factory=ModelConfig)
     version: int = 1
     git_commit: str = ""
+
+    def save(self, config_file: typing.TextIO):
+        """Write the configuration as JSON (reference config.py:83-85)."""
+        json.dump(self.to_dict(), config_file, indent=4)
+
+    @staticmethod
+    def load(config_file: typing.TextIO) -> "TrainingConfig":
+        """Read a configuration written by `save` (reference config.py:87-90)."""
+        return TrainingConfig.from_json(config_file.read())
+
+    @staticmethod
+    def load_and_merge(config: "TrainingConfig",
+                       config_files: typing.Iterable[typing.Union[str, Path, typing.TextIO]]) -> "TrainingConfig":
+        """Overlay JSON files, in order, on `config` (reference config.py:92-112): later files win, nested objects
+        (`audio`, `model`) are merged key by key, and keys no dataclass field carries are ignored."""
+        merged = config.to_dict()
+        for source in config_files:
+            handle = open(source, "r") if isinstance(source, (str, Path)) else source
+            with handle:
+                TrainingConfig.recursive_update(merged, json.load(handle))
+        return TrainingConfig.from_dict(merged)
+
+    @staticmethod
+    def recursive_update(base_dict: typing.Dict[typing.Any, typing.Any],
+                         new_dict: typing.Mapping[typing.Any, typing.Any]) -> None:
+        """In-place deep overwrite of `base_dict` by `new_dict` (reference config.py:114-124): a mapping is descended
+        into when the base already holds something non-None under that key, anything else replaces the base value."""
+        for key, value in new_dict.items():
+            if isinstance(value, collections.abc.Mapping) and base_dict.get(key) is not None:
+                TrainingConfig.recursive_update(base_dict[key], value)
+            else:
+                base_dict[key] = value
 
 
 _NESTED = {("TrainingConfig", "audio"): AudioConfig, ("TrainingConfig", "model"): ModelConfig}

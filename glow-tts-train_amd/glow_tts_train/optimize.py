@@ -24,7 +24,10 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1.0, betas=(0.9, 0.98), eps=1e-9, dim_model: float = 0.0, warmup_steps: float = 0.0,
                  base_lr: typing.Optional[float] = None):
         params = [p for p in params]
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the group carries every key torch.optim.Adam's does (amsgrad, weight_decay, foreach, ... at their defaults), so
+        # state_dict() has torch's layout for this torch version and the reference loads it unchanged
+        template = torch.optim.Adam([torch.zeros(1)], lr=lr, betas=betas, eps=eps).param_groups[0]
+        super().__init__(params, {k: v for k, v in template.items() if k != "params"})
         self.base_lr = float(lr if base_lr is None else base_lr)
         self.dim_model, self.warmup = float(dim_model), float(warmup_steps)
         self._build_flat()
@@ -47,7 +50,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_g = torch.zeros(total, device=dev, dtype=dt)
         self.flat_m = torch.zeros(total, device=dev, dtype=dt)
         self.flat_v = torch.zeros(total, device=dev, dtype=dt)
-        # device state: [adam step t (1-based for the NEXT update), noam step_num, lr of the next update, spare]
+        # device state: [adam step t (1-based for the NEXT update), noam step_num, lr of the next update,
+        #                lr imposed on the next update only (0 = follow the schedule)]
         self.dev_state = torch.tensor([1.0, 1.0, 0.0, 0.0], device=dev, dtype=dt)
         with torch.no_grad():
             for p, o in zip(ps, offs):
@@ -150,6 +154,15 @@ class FlatAdam(torch.optim.Optimizer):
             for k in ("lr", "betas", "eps"):
                 if k in g_new:
                     g[k] = g_new[k]
+        # torch.optim.Adam.load_state_dict leaves the stored group lr in force until the schedule next writes it, i.e.
+        # for exactly one update under "noam" (reference optimize.py:43-48, :60-61) and for good otherwise
+        groups = d.get("param_groups", [])
+        if groups and "lr" in groups[0]:
+            lr = float(groups[0]["lr"])
+            if self.warmup > 0.0:
+                self.dev_state[3] = lr
+            else:
+                self.base_lr = lr
 
 
 class Adam:

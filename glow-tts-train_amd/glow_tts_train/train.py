@@ -3,17 +3,53 @@
 The reference pays >= 521 device->host syncs per step (two `loss.item()` plus one `.item()` per parameter tensor in
 `clip_grad_value_`); here the loss stays on device, clipping and Adam/Noam are one kernel each over flat buffers,
 the alignment search never leaves the GPU, and (with `reducer`) gradient all-reduce overlaps the backward.
-Checkpoint cadence, logging and dataset plumbing stay with the caller.
+`train()` is the reference's epoch loop around it (checkpoint cadence included); batches reach HBM one step ahead
+through `dataset.DeviceBatches`.
 """
 from __future__ import annotations
 
+import logging
+import time
 import typing
+from pathlib import Path
 
 import torch
 
 from ._hip import join_side_streams, zero_scope
 from .convops import flush_groups
-from .utils import clip_grad_value_, duration_loss, mle_loss, to_gpu
+from .utils import clip_grad_value_, duration_loss, mle_loss
+
+_LOGGER = logging.getLogger("glow_tts_train")
+
+
+def train(train_loader, config, model_dir: Path, model=None, optimizer=None, global_step: int = 1,
+          checkpoint_epochs: int = 1, rank: int = 0, reducer=None):
+    """Epoch loop of the reference (train.py:19-88): seed, build or adopt model and optimizer, run `config.epochs`
+    passes over `train_loader`, and on rank 0 write `checkpoint_<step>.pth` + `config_<step>.json` into `model_dir`
+    every `checkpoint_epochs` epochs.  Returns the final global step."""
+    from .checkpoint import Checkpoint, save_checkpoint
+    from .models import setup_model
+
+    torch.manual_seed(config.seed)
+    model, optimizer = setup_model(config, model=model, optimizer=optimizer)
+    assert model is not None and optimizer is not None
+    model_dir = Path(model_dir)
+    for epoch in range(1, config.epochs + 1):
+        started = time.perf_counter()
+        global_step = train_step(global_step=global_step, epoch=epoch, model=model, optimizer=optimizer, config=config,
+                                 train_loader=train_loader, fp16_run=config.fp16_run, reducer=reducer,
+                                 on_loss=lambda e, loss, step: _LOGGER.info(
+                                     "Avg. Loss for epoch %s: %s (global step=%s)", e, loss, step))
+        if epoch % checkpoint_epochs == 0 and rank == 0:
+            path = model_dir / f"checkpoint_{global_step}.pth"
+            save_checkpoint(Checkpoint(model=model, optimizer=optimizer, learning_rate=optimizer.cur_lr,
+                                       global_step=global_step, version=config.version), path)
+            with open(model_dir / f"config_{global_step}.json", "w") as config_file:
+                config.save(config_file)
+            _LOGGER.info("Saved checkpoint to %s", path)
+        _LOGGER.debug("Epoch %s complete in %s second(s) (global step=%s)", epoch, time.perf_counter() - started,
+                      global_step)
+    return global_step
 
 
 def train_batch(model, optimizer, batch, grad_clip: float, reducer=None) -> torch.Tensor:
@@ -76,12 +112,12 @@ def train_step(global_step: int, epoch: int, model, optimizer, config, train_loa
     fp16 branch bypasses the Noam schedule)."""
     if fp16_run:
         raise NotImplementedError("glow_tts_train (MI355X build): fp16_run is not implemented; the path is fp32")
+    from .dataset import DeviceBatches
+
     model.train()
     losses = []
-    for batch in train_loader:
-        x, x_lengths, y, y_lengths, speaker_ids = batch
-        batch = (to_gpu(x), to_gpu(x_lengths), to_gpu(y), to_gpu(y_lengths),
-                 None if speaker_ids is None else to_gpu(speaker_ids))
+    device = next(model.parameters()).device
+    for batch in DeviceBatches(train_loader, device):      # batch k+1 is copied to HBM while step k runs
         losses.append(train_batch(model, optimizer, batch, config.grad_clip, reducer))
         global_step += 1
     if losses and on_loss is not None:

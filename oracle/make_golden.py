@@ -13,6 +13,7 @@ How the reference is made importable here:
     oracle/Makefile builds from the reference's own core.pyx where it lies.
 
 Usage:  make -C oracle ref && python oracle/make_golden.py          (writes tests/golden/*.npz)
+        python oracle/make_golden.py host                            (only the collate / table / config / checkpoint fixtures)
 
 This script must be run in its own process: it imports the reference under the package name `glow_tts_train`,
 which is also the name of this repo's drop-in package.
@@ -433,10 +434,131 @@ def gen_losses(R):
          logw=npy(logw), logw_=npy(logw_), lengths=npy(lens), dur_loss=npy(dl), dlogw=npy(logw.grad))
 
 
+def numpy_scalar_globals():
+    import numpy._core.multiarray as ncm
+    return [ncm.scalar, np.dtype, type(np.dtype(np.float64)), type(np.dtype(np.int64)), type(np.dtype(np.float32))]
+
+
+def gen_host(R):
+    """Fixtures for the data formats either side of the path: the reference's collate on ragged
+    utterance lists, its text / mel table readers, the field defaults of its config classes, and a checkpoint FILE
+    written by its own save_checkpoint() after two optimisation steps of a tiny model."""
+    import dataclasses
+    import io
+    import json
+    from pathlib import Path
+
+    from glow_tts_train import checkpoint as ref_ckpt
+    from glow_tts_train import config as ref_cfg
+    from glow_tts_train import dataset as ref_data
+
+    # -- collate --------------------------------------------------------------------------------------------
+    arrs = {}
+    cases = [("a", 1, False, [5, 9, 3, 7], [21, 40, 13, 30]),
+             ("b", 2, True, [6, 6, 2, 11, 6], [25, 27, 9, 45, 26]),          # ties in text length, odd mel maximum
+             ("c", 4, True, [1], [7])]
+    for tag, nfps, multi, tls, mls in cases:
+        gen = torch.Generator().manual_seed(len(tls) * 100 + nfps)
+        batch = []
+        for i, (tl, ml) in enumerate(zip(tls, mls)):
+            text = torch.randint(1, 148, (tl,), generator=gen, dtype=torch.int32)
+            mel = torch.randn(8, ml, generator=gen)
+            batch.append((text, mel, tl, (i * 7) % 4) if multi else (text, mel, tl))
+        out = ref_data.PhonemeMelCollate(n_frames_per_step=nfps, multispeaker=multi)(batch)
+        arrs[f"{tag}.n_frames_per_step"] = np.int64(nfps)
+        arrs[f"{tag}.multispeaker"] = np.int64(multi)
+        arrs[f"{tag}.text_lengths"] = np.asarray(tls, np.int64)
+        arrs[f"{tag}.mel_lengths"] = np.asarray(mls, np.int64)
+        arrs[f"{tag}.texts"] = np.concatenate([npy(b[0]) for b in batch])
+        arrs[f"{tag}.mels"] = np.concatenate([npy(b[1]) for b in batch], axis=1)
+        arrs[f"{tag}.speakers"] = np.asarray([b[3] for b in batch] if multi else [], np.int64)
+        for name, t in zip(("text_padded", "input_lengths", "mel_padded", "output_lengths", "speaker_ids"), out):
+            arrs[f"{tag}.out.{name}"] = npy(t)
+            if t is not None:
+                arrs[f"{tag}.out.{name}.dtype"] = np.asarray(str(t.dtype))
+    # -- table readers --------------------------------------------------------------------------------------
+    csv_text = "utt1|1 2 3 4\nutt2|5 6\nutt3|7 8 9 10 11 12 13\nutt4| 14 15 16 \n"
+    jsonl_text = '{"id": "utt1", "mel": [[0.5, 1.5, 2.5], [3.0, 4.0, 5.0]]}\n\n{"id": "utt4", "mel": [[-1.0], [2.0]]}\n'
+    cfg = ref_cfg.TrainingConfig(min_seq_length=3, max_seq_length=6)
+    ph = ref_data.load_phonemes(io.StringIO(csv_text), cfg)
+    mels = ref_data.load_mels(io.StringIO(jsonl_text))
+    arrs["tables.csv"] = np.asarray(csv_text)
+    arrs["tables.jsonl"] = np.asarray(jsonl_text)
+    arrs["tables.phoneme_ids"] = np.asarray(sorted(ph))
+    for k, v in ph.items():
+        arrs[f"tables.phonemes.{k}"] = npy(v)
+        arrs[f"tables.phonemes.{k}.dtype"] = np.asarray(str(v.dtype))
+    arrs["tables.mel_ids"] = np.asarray(sorted(mels))
+    for k, v in mels.items():
+        arrs[f"tables.mels.{k}"] = npy(v)
+    save("host_dataset", **arrs)
+
+    # -- config defaults ------------------------------------------------------------------------------------
+    with open(os.path.join(OUT, "host_config_defaults.json"), "w") as f:
+        json.dump(dataclasses.asdict(ref_cfg.TrainingConfig()), f, indent=1, sort_keys=True)
+
+    # -- checkpoint written by the reference ---------------------------------------------------------------
+    U = R.utils
+    mc = ref_cfg.ModelConfig(num_symbols=20, hidden_channels=16, filter_channels=32, filter_channels_dp=16,
+                             n_blocks_dec=2, n_layers_enc=1, n_block_layers=2, hidden_channels_enc=16,
+                             hidden_channels_dec=16, p_dropout=0.0, p_dropout_dec=0.0, window_size=4, prenet=False)
+    cfg = ref_cfg.TrainingConfig(model=mc, audio=ref_cfg.AudioConfig(mel_channels=8), warmup_steps=10)
+    torch.manual_seed(1234)
+    model, opt = R.models.setup_model(cfg, use_cuda=False)
+    with torch.no_grad():
+        for fl in model.decoder.flows:
+            if hasattr(fl, "end"):
+                fl.end.weight.copy_(0.05 * torch.randn_like(fl.end.weight))
+                fl.end.bias.copy_(0.05 * torch.randn_like(fl.end.bias))
+    model.train()
+    gen = torch.Generator().manual_seed(5)
+    xl = torch.tensor([7, 5, 4])
+    yl = torch.tensor([30, 22, 18])
+    x = torch.randint(1, 20, (3, 7), generator=gen) * (torch.arange(7)[None] < xl[:, None])
+    y = torch.randn(3, 8, 30, generator=gen) * (torch.arange(30)[None, None] < yl[:, None, None])
+
+    def one_step():
+        opt.zero_grad()
+        (z, z_m, z_logs, logdet, z_mask), _, (_a, logw, logw_) = model(x, xl, y, yl, g=None)
+        loss = U.mle_loss(z, z_m, z_logs, logdet, z_mask) + U.duration_loss(logw, logw_, xl)
+        loss.backward()
+        U.clip_grad_value_(model.parameters(), cfg.grad_clip)
+        opt.step()
+        return float(loss)
+
+    losses = [one_step(), one_step()]
+    path = Path(OUT) / "host_ref_checkpoint.pth"
+    ref_ckpt.save_checkpoint(ref_ckpt.Checkpoint(model=model, optimizer=opt, learning_rate=opt.cur_lr, global_step=3,
+                                                 version=cfg.version), path)
+    # what the reference does with that file: load it into fresh objects, then take one more step
+    # (the file holds numpy scalars — cur_lr comes out of np.power, optimize.py:35-42 — which torch >= 2.6 refuses
+    # under its default weights_only=True; the reference's torch.load call predates that default, so allow them here)
+    torch.manual_seed(99)
+    with torch.serialization.safe_globals(numpy_scalar_globals()):
+        ck = ref_ckpt.load_checkpoint(path, cfg, use_cuda=False)
+    model, opt = ck.model, ck.optimizer
+    # the reference's Adam wrapper restarts its Noam counter at 1 on load (optimize.py:28, :60-61) and only torch's
+    # own per-parameter step survives; record what the third step then does
+    model.train()
+    lr_before = opt.cur_lr
+    loss3 = one_step()
+    save("host_ref_checkpoint_expect", x=npy(x), x_lengths=npy(xl), y=npy(y), y_lengths=npy(yl),
+         losses=np.asarray(losses + [loss3], np.float64), learning_rate=np.float64(ck.learning_rate),
+         global_step=np.int64(ck.global_step), version=np.int64(ck.version), lr_before_step3=np.float64(lr_before),
+         lr_after_step3=np.float64(opt.cur_lr), step_num_after=np.int64(opt.step_num),
+         model_config=np.asarray(json.dumps(dataclasses.asdict(mc))),
+         **{"sd_after3." + k: npy(v) for k, v in model.state_dict().items()})
+    print("host_ref_checkpoint.pth:", os.path.getsize(path), "bytes")
+
+
 def main():
     R = import_reference()
     torch.set_num_threads(1)
     torch.use_deterministic_algorithms(False)
+    if sys.argv[1:] == ["host"]:            # only the §8f-row-4 fixtures; the others stay as committed
+        gen_host(R)
+        return
+    gen_host(R)
     gen_mas(R)
     gen_flows(R)
     gen_wn_gate_squeeze(R)
