@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--t-mel", type=int, default=800)
     ap.add_argument("--t-text", type=int, default=0, help="default T_mel / 5 (SURVEY.md §8)")
     ap.add_argument("--blocks", type=int, default=12)
+    ap.add_argument("--speakers", type=int, default=0, help="speaker-conditioned couplings (BASELINE config 5: 4)")
+    ap.add_argument("--gin", type=int, default=64, help="speaker embedding width when --speakers > 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -142,6 +144,8 @@ def build_workload(args, dev, rank):
     cfg = config.TrainingConfig()
     cfg.model.num_symbols = 148
     cfg.model.n_blocks_dec = args.blocks
+    if args.speakers > 0:
+        cfg.model.n_speakers, cfg.model.gin_channels = args.speakers, args.gin
     torch.manual_seed(cfg.seed)
     model, opt = models.setup_model(cfg, use_cuda=True)
     # non-degenerate couplings for the benchmark: the zero-initialised end convs would make logs == 0 everywhere
@@ -157,14 +161,15 @@ def build_workload(args, dev, rank):
     x_lengths = torch.full((B,), T_text, dtype=torch.long, device=dev)
     y = torch.randn(B, cfg.audio.mel_channels, T_mel, generator=gen).to(dev)
     y_lengths = torch.full((B,), T_mel, dtype=torch.long, device=dev)
-    batch = (x, x_lengths, y, y_lengths, None)
+    speaker_ids = (torch.arange(B) % args.speakers).to(dev) if args.speakers > 0 else None
+    batch = (x, x_lengths, y, y_lengths, speaker_ids)
 
     # data-dependent ActNorm initialisation on the first batch (ddi.py:20-39), untimed; rank 0's result wins (Q10)
     for f in model.decoder.flows:
         if getattr(f, "set_ddi", False):
             f.set_ddi(True)
     with torch.no_grad():
-        model(x, x_lengths, y, y_lengths)
+        model(x, x_lengths, y, y_lengths, g=speaker_ids)
     torch.cuda.synchronize()
     log("data-dependent init forward done")
     return model, opt, batch, cfg
@@ -241,13 +246,17 @@ def main():
     frames = world * B * T_mel * args.steps
     ms_per_step = 1e3 * dt / args.steps
 
+    sizes = (B, T_mel, args.blocks, args.speakers)
+    which = {(32, 800, 12, 0): "BASELINE configs[1]", (48, 1200, 20, 4): "BASELINE configs[4]"}.get(
+        sizes, "custom sizes (not a BASELINE configuration)")
     out = {
         "metric": "mel_frames_per_sec", "value": frames / dt, "unit": "mel-frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: full training step, per-GPU B={B}, T_text={T_text}, T_mel={T_mel}, "
+        "config": {"workload": f"{which}: full training step, per-GPU B={B}, T_text={T_text}, T_mel={T_mel}, "
                                f"80 mels, {args.blocks} flow blocks, n_split=4, n_sqz=2, H=192, fp32, dropout 0.1/0.05, "
-                               "random-init weights, synthetic resident batch",
+                               + (f"{args.speakers} speakers (gin {args.gin}), " if args.speakers > 0 else "")
+                               + "random-init weights, synthetic resident batch",
                    "global_batch": world * B, "parallelism": f"dp{world}", "launch": mode, "final_loss": loss_val},
     }
 

@@ -431,22 +431,26 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
 }
 
 // embedding gradients: dE[r][d] += sum_i M[i][i + r - w] * A[d][i]   (M, A) = (Pd, dO) -> dE_v ; (dS, Q) -> dE_k
-// workgroup = one (utterance, head): the 2w+1 diagonals of Pd / dS and the dO / Q rows of the head are staged in LDS
-// once (coalesced, 8 loads in flight per thread); then thread = one (r, d) output walks the queries out of LDS.
+// workgroup = one (utterance, head, slab of DC channels): the 2w+1 diagonals of Pd / dS and the slab's dO / Q rows are
+// staged in LDS once (coalesced, 8 loads in flight per thread); then thread = one (r, d) output walks the queries out
+// of LDS.  DC is chosen by the host so that (2w+1) * DC <= 256 outputs — one per thread — and the slab fits LDS at
+// T = 256 whatever the head width.
 __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restrict__ p, const float *__restrict__ ds,
                                                            const unsigned char *__restrict__ drop, float drop_scale,
                                                            const float *__restrict__ dout, const float *__restrict__ q,
                                                            float *__restrict__ dek, float *__restrict__ dev, int H, int T,
-                                                           int dk, int w, int e_hs) {
+                                                           int dk, int w, int e_hs, int DC) {
     extern __shared__ __align__(16) float smem[];
     const int nr = 2 * w + 1;
     const int TP = T + 1;               // odd pitch: threads of one wave read different rows at the same column
     float *dp_ = smem;                  // [nr][T]   Pd[i][i+r-w]
     float *dd_ = dp_ + nr * T;          // [nr][T]   dS[i][i+r-w]
-    float *os_ = dd_ + nr * T;          // [dk][TP]  dO rows
-    float *qs_ = os_ + dk * TP;         // [dk][TP]  Q rows
+    float *os_ = dd_ + nr * T;          // [DC][TP]  dO rows of this slab
+    float *qs_ = os_ + DC * TP;         // [DC][TP]  Q rows of this slab
     const int h = blockIdx.x % H, b = blockIdx.x / H;
-    const long cbase = ((long)b * H + h) * dk;
+    const int d0 = blockIdx.y * DC;
+    const int nd = min(DC, dk - d0);
+    const long cbase = ((long)b * H + h) * dk + d0;
     const long pbase = ((long)b * H + h) * T * T;
     for (int idx = threadIdx.x; idx < nr * T; idx += 256) {
         const int r = idx / T, i = idx - r * T;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
         dp_[idx] = pv;
         dd_[idx] = dv;
     }
-    const int total = dk * T;
+    const int total = nd * T;
     for (int base = 0; base < total; base += 256 * 8) {
         float vo[8], vq[8];
 #pragma unroll
@@ -481,16 +485,16 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
         }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nr * dk; idx += 256) {
-        const int r = idx / dk, d = idx - r * dk;
+    for (int idx = threadIdx.x; idx < nr * nd; idx += 256) {
+        const int r = idx / nd, d = idx - r * nd;
         float sv = 0.f, sk = 0.f;
 #pragma unroll 4
         for (int i = 0; i < T; ++i) {
             sv += dp_[r * T + i] * os_[d * TP + i];
             sk += dd_[r * T + i] * qs_[d * TP + i];
         }
-        atomicAdd(dev + (long)h * e_hs + idx, sv);
-        atomicAdd(dek + (long)h * e_hs + idx, sk);
+        atomicAdd(dev + (long)h * e_hs + r * dk + d0 + d, sv);
+        atomicAdd(dek + (long)h * e_hs + r * dk + d0 + d, sk);
     }
 }
 
@@ -573,7 +577,10 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     }
     hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
     if (emb_k) {
-        const size_t lds_r = ((size_t)2 * (2 * window + 1) * T + (size_t)2 * dk * (T + 1)) * sizeof(float);
+        const int nr = 2 * window + 1;
+        int DC = (256 / nr) & ~7;                      // one (r, d) output per thread, slab rows a multiple of 8
+        if (DC > dk) DC = dk;
+        const size_t lds_r = ((size_t)2 * nr * T + (size_t)2 * DC * (T + 1)) * sizeof(float);
         static size_t attr_max_r = 0;
         if (lds_r > attr_max_r) {
             hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_relgrad_kernel),
@@ -581,8 +588,8 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
             if (er != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(er)); return (int)er; }
             attr_max_r = lds_r;
         }
-        hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H), dim3(256), lds_r, s, p_attn, ds, drop, drop_scale, dout, q, demb_k,
-                           demb_v, H, T, dk, window, p.e_hs);
+        hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H, (dk + DC - 1) / DC), dim3(256), lds_r, s, p_attn, ds, drop,
+                           drop_scale, dout, q, demb_k, demb_v, H, T, dk, window, p.e_hs, DC);
     }
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn_bwd");
 }

@@ -567,6 +567,59 @@ def test_full_size_decoder_roundtrip_and_mas_properties(G):
     assert (G.ops.mas_path(p * 10.0, tx, ty) == p).all()
 
 
+@pytest.mark.parametrize("name,b,t_text,t_mel,blocks,spk", [
+    ("config3-shapes", 64, 200, 1000, 12, False),       # BASELINE configs[2] sizes (arithmetic here is fp32)
+    ("config5", 48, 240, 1200, 20, True),               # BASELINE configs[4]: speaker-conditioned, 20 blocks, long
+])
+def test_full_size_other_configs_step_and_roundtrip(G, name, b, t_text, t_mel, blocks, spk):
+    """The larger BASELINE configurations at full size, ragged lengths: size-independent checks — decoder -> inverse
+    gives the mel back, the alignment is a monotonic path per utterance, the log-det of an utterance does not depend
+    on what else is in the batch, one full optimisation step leaves finite parameters and moves them."""
+    from oracle import glow_oracle as O
+    from glow_tts_train.train import train_batch
+
+    hp = O.HParams(n_blocks_dec=blocks, n_speakers=4 if spk else 0, gin_channels=64 if spk else 0)
+    sd, model = _oracle_pair(G, hp, seed=3, end_std=0.005)
+    gen = torch.Generator().manual_seed(6)
+    yl = torch.linspace(t_mel, t_mel // 2, b).long()
+    xl = (yl // 5).clamp(min=1)
+    x = (torch.randint(1, 148, (b, t_text), generator=gen) * (torch.arange(t_text)[None] < xl[:, None])).cuda()
+    y = (torch.randn(b, 80, t_mel, generator=gen) * (torch.arange(t_mel)[None, None] < yl[:, None, None])).cuda()
+    ids = (torch.arange(b) % 4).cuda() if spk else None
+    xl, yl = xl.cuda(), yl.cuda()
+
+    with torch.no_grad():
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, logw, logw_) = model(x, xl, y, yl, g=ids)
+        assert all(torch.isfinite(t).all() for t in (z, z_m, z_logs, logdet, logw, logw_))
+        # alignment: one text position per valid frame, non-decreasing, ending on the last text position
+        path = attn[:, 0]                                              # (B, T_text, T_mel)
+        frames = z_mask[:, 0].sum(1).long()
+        assert (path.sum(1) == z_mask[:, 0]).all()
+        idx = path.argmax(1)
+        for i in (0, b // 2, b - 1):
+            n = int(frames[i])
+            d = idx[i, 1:n] - idx[i, :n - 1]
+            assert ((d == 0) | (d == 1)).all() and idx[i, 0] == 0 and idx[i, n - 1] == int(xl[i]) - 1
+        # batch independence: the shortest utterance alone gives the same latent and log-det
+        g1 = None if ids is None else model.emb_g(ids[-1:]).unsqueeze(-1)
+        g_all = None if ids is None else model.emb_g(ids).unsqueeze(-1)
+        if g1 is not None:
+            g1, g_all = torch.nn.functional.normalize(g1, dim=1), torch.nn.functional.normalize(g_all, dim=1)
+        n = int(frames[-1])
+        z1, ld1 = model.decoder(y[-1:, :, :n].contiguous(), z_mask[-1:, :, :n].contiguous(), g=g1)
+        assert rel_err(z1, z[-1:, :, :n]) < REL and rel_err(ld1, logdet[-1:]) < REL
+        # invertibility at full size
+        model.decoder.store_inverse()
+        yr, _ = model.decoder(z, z_mask, g=g_all, reverse=True)
+        assert rel_err(yr, y[:, :, :z.shape[2]] * z_mask) < REL
+
+    opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=192, warmup_steps=4000, lr=1.0)
+    before = opt._optim.flat_p.clone()
+    loss = train_batch(model, opt, (x, xl, y, yl, ids), 5.0)
+    assert torch.isfinite(loss) and torch.isfinite(opt._optim.flat_p).all() and torch.isfinite(opt._optim.flat_g).all()
+    assert (opt._optim.flat_p != before).float().mean() > 0.5
+
+
 # =============================================================================================== MFMA conv kernels
 @pytest.mark.parametrize("b,cin,cout,t,k,dil,mask_out,slice_in", [
     (3, 80, 192, 50, 1, 1, True, True),       # coupling start conv: channel slice consumed in place, masked output
@@ -712,7 +765,8 @@ def test_attention_dropout_matches_manual_mask(G):
         assert_close(a, e, what="grad", rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("t,ch,win,blk", [(160, 192, 4, None), (256, 64, 7, None), (200, 32, 4, 20), (33, 256, 2, None)])
+@pytest.mark.parametrize("t,ch,win,blk", [(160, 192, 4, None), (256, 64, 7, None), (200, 32, 4, 20), (33, 256, 2, None),
+                                          (240, 192, 4, None), (256, 192, 7, None)])      # config 5 / the T limit at H=192
 def test_attention_kernel_vs_general_path(G, t, ch, win, blk):
     torch.manual_seed(t)
     b = 2
