@@ -1,0 +1,677 @@
+// convgemm_split.hip — the forward-type implicit-GEMM convolution of convgemm.hip with each fp32 operand split into
+// NS bf16 planes and the products formed on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Why: the native fp32 MFMA (16x16x4, 32 cycles for 2 048 FLOP) caps the WN convolutions at 157 TFLOP/s and the
+// kernels of convgemm.hip sit at 66-73 % of that.  The bf16 instruction does 16 384 FLOP in 16 cycles.  An fp32 value
+// is the exact sum of three bf16 values (8 + 8 + 8 mantissa bits: h = top bits, m = top bits of v - h, l = v - h - m),
+// so   x * w = (xh + xm + xl) * (wh + wm + wl)   and the six products  hh, hm, mh, hl, lh, mm  carry everything down
+// to 2^-24 |x w| — the size of ONE fp32 rounding; every product of two bf16 is exact in fp32 and the sums are fp32, as
+// in the native kernel.  Six bf16 MFMAs per 32-deep step cost 96 cycles where the fp32 path needs 256.
+//   NS = 3 ("bf16x6"): fp32-equivalent (measured: same error against an fp64 reference as the native kernel);
+//   NS = 2 ("bf16x3"): hh + hl + lh, products good to 2^-16;      NS = 1: plain bf16 operands (config 3's arithmetic).
+// Opt-in (glowtts_conv_math); the native fp32 kernels stay the default and the reference for parity.
+//
+// Data flow (differences from convgemm_wd_kernel, whose tiling, staging map, ring and epilogues are kept):
+//   weights   : the packed fp32 buffer [tap][g][M][16] is split ONCE per step by split_weights_kernel into bf16 planes
+//               with the same element order (glowtts_conv_split_weights, keyed by the packed buffer's address); a lane
+//               takes 4 channels of group g and 4 of group g+1 (two 8-byte buffer loads per plane) = one bf16x8 A
+//               operand: k is relabelled so that lane slot lk consumes channels 4 lk..4 lk+3 of both groups.
+//   activations: split while they are stored to LDS; plane image [g/2][frame][40 bf16]: a row holds the 32 channels of
+//               a group pair in the A operand's order (pitch 80 B, the conflict-free pitch of the fp32 image), so one
+//               ds_read_b128 per plane is a B operand.
+#include <map>
+#include <mutex>
+
+#undef GLOWTTS_TRACE
+#include "convgemm_common.hpp"
+
+namespace glowtts {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// planes 0 .. NS-2 truncate (so the remainder is exact), the last plane rounds to nearest-even (exact when NS == 3)
+template <int NS>
+__device__ __forceinline__ void split_planes(float v, unsigned (&o)[NS]) {
+    float r = v;
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl) {
+        const unsigned b = __float_as_uint(r);
+        if (pl == NS - 1) {
+            o[pl] = (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+        } else {
+            const unsigned hb = b & 0xffff0000u;
+            o[pl] = hb >> 16;
+            r = r - __uint_as_float(hb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, unsigned short *__restrict__ planes,
+                                                            long n, long plane_stride, int ns) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = w[i];
+        if (ns == 3) {
+            unsigned o[3];
+            split_planes<3>(v, o);
+            planes[i] = (unsigned short)o[0]; planes[plane_stride + i] = (unsigned short)o[1];
+            planes[2 * plane_stride + i] = (unsigned short)o[2];
+        } else if (ns == 2) {
+            unsigned o[2];
+            split_planes<2>(v, o);
+            planes[i] = (unsigned short)o[0]; planes[plane_stride + i] = (unsigned short)o[1];
+        } else {
+            unsigned o[1];
+            split_planes<1>(v, o);
+            planes[i] = (unsigned short)o[0];
+        }
+    }
+}
+
+// (a plane, b plane) pairs of the products kept, small magnitudes first
+__host__ __device__ constexpr int n_products(int ns) { return ns == 3 ? 6 : (ns == 2 ? 3 : 1); }
+__host__ __device__ constexpr int product_a(int ns, int k) {
+    return ns == 3 ? (k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 1 : k == 3 ? 0 : k == 4 ? 1 : 0) : (ns == 2 ? (k == 1 ? 1 : 0) : 0);
+}
+__host__ __device__ constexpr int product_b(int ns, int k) {
+    return ns == 3 ? (k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 1 : k == 4 ? 0 : 0) : (ns == 2 ? (k == 0 ? 1 : 0) : 0);
+}
+
+template <int NS, int RTW, int NCT, int EPI, int TAPS>
+__global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p, const unsigned short *__restrict__ wpl,
+                                                                long plane_stride) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT, XC = NT + 16, KG = 6, G2C = KG / 2;
+    constexpr int RP = 40;                           // bf16 per LDS row (32 used + 8 pad): 80 B = 20 dwords
+    constexpr int PLANE16 = G2C * XC * RP;           // bf16 elements per plane image
+    constexpr int X4 = KG * 16 * (XC / 4);
+    constexpr int S = G2C * TAPS;                    // 32-deep MFMA steps per chunk (a multiple of 3: static ring)
+    static_assert(S % 3 == 0, "ring of 3");
+    extern __shared__ __align__(16) float smem[];
+    unsigned short *Xh = reinterpret_cast<unsigned short *>(smem);      // [NS][G2C][XC][RP]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int ntile_t = (p.T + NT - 1) / NT;
+    const int b = blockIdx.x / ntile_t;
+    const int t0 = (blockIdx.x - b * ntile_t) * NT;
+    const int tile_m = blockIdx.y;
+    const int off = (4 - (p.pad & 3)) & 3;
+    const int ts = t0 - p.pad - off;
+    const int G = (p.Cin + 15) / 16;
+    const int nchunks = (G + KG - 1) / KG;
+
+    auto grow = [&](int lr) -> int {
+        if (EPI == EPI_GATE) return lr < 64 ? tile_m * 64 + lr : p.H + tile_m * 64 + (lr - 64);
+        return tile_m * WGR + lr;
+    };
+    auto row_ok = [&](int lr) -> bool {
+        if (EPI == EPI_GATE) return tile_m * 64 + (lr & 63) < p.H;
+        return tile_m * WGR + lr < p.M;
+    };
+    auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
+
+    f32x4 acc[RTW][NCT];
+#pragma unroll
+    for (int r = 0; r < RTW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- weights: bf16 planes, element order of the fp32 packing; range-checked buffer loads (rows beyond M and groups
+    // beyond G return zeros through an out-of-range offset)
+    const int wbytes = TAPS * G * p.M * 32;          // one plane
+    __amdgpu_buffer_rsrc_t wrs[NS];
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl)
+        wrs[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(wpl + pl * plane_stride), 0, wbytes, 0x00020000);
+    int wvo[RTW];
+#pragma unroll
+    for (int r = 0; r < RTW; ++r) {
+        const int lr = ltile(r) * 16 + lrow;
+        wvo[r] = row_ok(lr) ? (grow(lr) * 16 + lk * 4) * 2 : wbytes;
+    }
+    const int wtap = G * p.M * 32, wgrp = p.M * 32;  // bytes
+    i32x4 a[3][RTW][NS];
+    auto wload = [&](int c, int s, int slot) {       // weights of step s of chunk c (s may run past the chunk: next chunk)
+        if (s >= S) { s -= S; c += 1; }
+        const int g = c * KG + 2 * (s / TAPS), tap = s % TAPS;
+        const int so0 = g < G ? tap * wtap + g * wgrp : wbytes;
+        const int so1 = g + 1 < G ? tap * wtap + (g + 1) * wgrp : wbytes;
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) {
+                const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs[pl], wvo[r], so0, 0));
+                const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs[pl], wvo[r], so1, 0));
+                a[slot][r][pl] = i32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+    };
+
+    // ---- activations: the staging map of convgemm_wd_kernel (thread = channel kk of a group, frame quad qq, group
+    // parity gsel; pieces (group gsel + 2 gi, quad qq + 8 jq)); the group pair of piece gi is gi, its half is gsel
+    const float *xb = p.x + (long)b * p.x_bs;
+    const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
+    float *Ms = smem + NS * PLANE16 / 2;             // [XC]
+    constexpr int NQ = (XC / 4 + 7) / 8, NG = KG / 2;
+    static_assert(NQ * NG * 256 >= X4, "piece map covers the chunk");
+    const int kk = tid & 15, qq = (tid >> 4) & 7, gsel = tid >> 7;
+    const int c_first = p.x2 ? p.x_split : p.Cin;
+    const int xbytes = c_first * p.T * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, xbytes, 0x00020000);
+    const int x2bytes = p.x2 ? (p.Cin - p.x_split) * p.T * 4 : 0;
+    const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x2 ? p.x2 + (long)b * p.x2_bs : xb), 0, x2bytes, 0x00020000);
+    int xvo[NQ];
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq) {
+        const int t = ts + (qq + 8 * jq) * 4;
+        const bool ok = (qq + 8 * jq < XC / 4) && t >= 0 && t < p.T;
+        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * 4 : 0x7fffffff;
+    }
+    const int dbase = (qq * 4) * RP + (kk >> 2) * 8 + gsel * 4 + (kk & 3);     // bf16 index inside a plane image
+    f32x4 xreg[NG][NQ];
+    if (p.mask_in && tid < XC) {
+        const int t = ts + tid;
+        Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
+    }
+    auto xload = [&](int c) {
+        const bool second = p.x2 != nullptr && c * KG * 16 >= p.x_split;
+        const int cbase = c * KG * 16 - (second ? p.x_split : 0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+                xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * 4, 0));
+    };
+    auto xstore = [&]() {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+                if (qq + 8 * jq < XC / 4) {
+                    f32x4 v = xreg[gi][jq];
+                    if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
+                    unsigned short *d = Xh + dbase + (gi * XC + 32 * jq) * RP;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        unsigned o[NS];
+                        split_planes<NS>(v[f], o);
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
+                    }
+                }
+    };
+    const float *xd = smem + (off + lrow) * (RP / 2) + lk * 4;      // dword view of a plane image
+    i32x4 bv[2][NS];
+    auto bfetch = [&](int q, int slot) {             // q = step * NCT + column tile
+        const int s = q / NCT, cc = q - s * NCT;
+        const int g2 = s / TAPS, tap = s % TAPS;
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+            bv[slot][pl] = *reinterpret_cast<const i32x4 *>(xd + pl * (PLANE16 / 2) + (g2 * XC + cc * 16 + tap * p.dil) * (RP / 2));
+    };
+
+    wload(0, 0, 0);
+    wload(0, 1, 1);
+    wload(0, 2, 2);
+    xload(0);
+    if (p.mask_in) __syncthreads();
+    xstore();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        bfetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                const int q = s * NCT + cc;
+                if (q + 1 < S * NCT) bfetch(q + 1, (q + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);  // the next tile's LDS reads stay ahead of this tile's MFMAs
+#pragma unroll
+                for (int r = 0; r < RTW; ++r)
+#pragma unroll
+                    for (int k = 0; k < n_products(NS); ++k)
+                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, a[s % 3][r][product_a(NS, k)]),
+                            __builtin_bit_cast(bf16x8, bv[q & 1][product_b(NS, k)]), acc[r][cc], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wload(c, s + 3, s % 3);                 // refill the slot just consumed: three steps of lead
+            if (s == 0 && more) xload(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (more) {
+            xstore();
+            __syncthreads();
+        }
+    }
+    if (p.vec_epilogue) {
+        conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);
+    } else {
+        conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient on bf16 planes (the frame-packed kernel of convgemm.hip: contraction over frames, dilation 1, 'same'
+// padding).  Both operands are activations, split while they are stored to LDS (4 frames -> one ds_write_b64 per plane).
+// A 32-frame MFMA step: lane slot lk takes frames 8 lk .. 8 lk + 7 of the step, for x rows (A) and d rows (B) alike.
+// The tap shift of an x row is a shift by whole bf16 elements inside a lane's window of 16 frames (two aligned
+// ds_read_b128): even shifts are a choice of registers, odd shifts one v_alignbit per register.
+// Chunks stay 80 frames (T' = 400 = 5 chunks): the third step of a chunk is half zeros (d rows are zero past frame 80).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS, int TAPS, int NGRP, int MT>
+__global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) {
+    constexpr int MR = 16 * MT;
+    constexpr int CT = 16 * NGRP, NSTEP = (CT + 31) / 32, CTP = NSTEP * 32;
+    constexpr int PAD = (TAPS - 1) / 2, OFF = (4 - (PAD & 3)) & 3;
+    constexpr int XWL = CT + 8;                       // frames loaded per x row: window [tc - PAD - OFF, + XWL)
+    constexpr int XP16 = 104, DP16 = 104;             // bf16 pitches (== 8 mod 16: conflict-free ds_read_b128), >= CTP + 8
+    static_assert(CTP + 8 <= XP16 && XWL % 4 == 0 && TAPS - 1 + OFF < 8, "window fits");
+    constexpr int XPLANE = 64 * XP16, DPLANE = MR * DP16;
+    constexpr int X4 = 64 * (XWL / 4), D4 = MR * (CT / 4);
+    constexpr int NX = (X4 + 255) / 256, ND = (D4 + 255) / 256;
+    extern __shared__ __align__(16) float smem[];
+    unsigned short *Xh = reinterpret_cast<unsigned short *>(smem);          // [NS][64][XP16]
+    unsigned short *Dh = Xh + NS * XPLANE;                                  // [NS][MR][DP16]
+    float *Mx = smem + (NS * (XPLANE + DPLANE)) / 2;                        // [XWL]
+    float *Md = Mx + XWL;                                                   // [CT]
+    float *rowacc = Md + CT;                                                // [64]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lrow = lane & 15, lk = lane >> 4;
+    const int nkt = (p.Cin + 63) / 64;
+    const int ntiles = gridDim.x, nwg = gridDim.x * gridDim.z;
+    const int id = blockIdx.x + blockIdx.z * gridDim.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    const int tile = item % ntiles, split = item / ntiles;
+    const int kt = tile % nkt, mt = tile / nkt;
+    const int k0 = kt * 64, m0 = mt * MR;
+    const int nct = (p.T + CT - 1) / CT;
+    const int c0 = split * p.nb;
+    const int nchunks = min(p.B * nct, c0 + p.nb) - c0;
+
+    f32x4 acc[TAPS][MT];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xreg[NX], dreg[ND], mreg;
+    float bsum[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
+    const bool do_bias = (p.dbias != nullptr) && (kt == 0);
+    const bool masked = (p.mask != nullptr) || (p.mask_x != nullptr);
+
+    const int xbytes = (int)(((long)(p.B - 1) * p.x_bs + (long)p.Cin * p.T) * 4);
+    const bool d_second = p.d2 != nullptr && m0 >= p.d_split;
+    const int m_rows = d_second ? p.M - p.d_split : (p.d2 ? p.d_split : p.M);
+    const int m_base = d_second ? m0 - p.d_split : m0;
+    const long d_bs = d_second ? p.d2_bs : p.d_bs;
+    const int dbytes = (int)(((long)(p.B - 1) * d_bs + (long)m_rows * p.T) * 4);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(d_second ? p.d2 : p.d), 0, dbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mdrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask), 0, p.mask ? p.B * p.T * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.mask_x), 0, p.mask_x ? p.B * p.T * 4 : 0, 0x00020000);
+    constexpr int kOOB = 0x7fffffff;
+    auto ld16 = [&](const __amdgpu_buffer_rsrc_t &rs, int byte_off) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+    };
+    int xrow[NX], xq[NX], drow[ND], dq[ND];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (XWL / 4), r = idx / (XWL / 4);
+        xq[i] = q * 4;
+        xrow[i] = (idx < X4 && k0 + r < p.Cin) ? (k0 + r) * p.T : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int idx = tid + i * 256;
+        const int q = idx % (CT / 4), r = idx / (CT / 4);
+        dq[i] = q * 4;
+        drow[i] = (idx < D4 && m_base + r < m_rows) ? (m_base + r) * p.T : -1;
+    }
+    const bool mx_thread = tid < XWL / 4, md_thread = tid >= 64 && tid < 64 + CT / 4;
+
+    // the images' pad columns (x beyond the loaded window, d beyond the chunk) stay zero for the whole kernel
+    for (int i = tid; i < NS * (XPLANE + DPLANE) / 2; i += 256) smem[i] = 0.f;
+    __syncthreads();
+
+    auto load_chunk = [&](int c) {
+        const int b = (c0 + c) / nct;
+        const int tc = ((c0 + c) % nct) * CT;
+        const int ts = tc - PAD - OFF;
+        const int xb = b * (int)p.x_bs, db = b * (int)d_bs;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int t = ts + xq[i];
+            const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
+            xreg[i] = ld16(xrs, ok ? (xb + xrow[i] + t) * 4 : kOOB);
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int t = tc + dq[i];
+            const bool ok = drow[i] >= 0 && t < p.T;
+            dreg[i] = ld16(drs, ok ? (db + drow[i] + t) * 4 : kOOB);
+        }
+        if (masked) {
+            const int tx = ts + tid * 4, td = tc + (tid - 64) * 4;
+            if (mx_thread) mreg = ld16(mxrs, (tx >= 0 && tx < p.T) ? (b * p.T + tx) * 4 : kOOB);
+            if (md_thread) mreg = ld16(mdrs, (td < p.T) ? (b * p.T + td) * 4 : kOOB);
+        }
+    };
+    auto store_chunk = [&]() {
+        if (masked) {
+            if (mx_thread) *reinterpret_cast<f32x4 *>(Mx + tid * 4) = mreg;
+            if (md_thread) *reinterpret_cast<f32x4 *>(Md + (tid - 64) * 4) = mreg;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (XWL / 4), r = idx / (XWL / 4);
+            if (idx < X4) {
+                f32x4 v = xreg[i];
+                if (p.mask_x) v *= *reinterpret_cast<const f32x4 *>(Mx + q * 4);
+                unsigned o[4][NS];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) split_planes<NS>(v[f], o[f]);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) {
+                    i32x2 w;
+                    w[0] = (int)(o[0][pl] | (o[1][pl] << 16));
+                    w[1] = (int)(o[2][pl] | (o[3][pl] << 16));
+                    *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            const int q = idx % (CT / 4), r = idx / (CT / 4);
+            if (idx < D4) {
+                f32x4 v = dreg[i];
+                if (p.mask) v *= *reinterpret_cast<const f32x4 *>(Md + q * 4);
+                if (do_bias) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                unsigned o[4][NS];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) split_planes<NS>(v[f], o[f]);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) {
+                    i32x2 w;
+                    w[0] = (int)(o[0][pl] | (o[1][pl] << 16));
+                    w[1] = (int)(o[2][pl] | (o[3][pl] << 16));
+                    *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = w;
+                }
+            }
+        }
+    };
+    const unsigned short *xa = Xh + (wave * 16 + lrow) * XP16 + lk * 8;
+    const unsigned short *db_ = Dh + lrow * DP16 + lk * 8;
+    auto compute = [&]() {
+        int aw[2][NS][8];
+        i32x4 bv[2][MT][NS];
+        auto fetch = [&](int g, int sl) {
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) {
+                const i32x4 lo = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32);
+                const i32x4 hi = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32 + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { aw[sl][pl][e] = lo[e]; aw[sl][pl][4 + e] = hi[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    bv[sl][i][pl] = *reinterpret_cast<const i32x4 *>(db_ + pl * DPLANE + i * 16 * DP16 + g * 32);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NSTEP; ++g) {
+            if (g + 1 < NSTEP) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int sl = g & 1;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                const int sh = tp + OFF;                 // shift in bf16 elements inside the 16-frame window
+                i32x4 av[NS];
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        av[pl][e] = (sh & 1) ? (int)__builtin_amdgcn_alignbit((unsigned)aw[sl][pl][(sh >> 1) + e + 1],
+                                                                             (unsigned)aw[sl][pl][(sh >> 1) + e], 16)
+                                             : aw[sl][pl][(sh >> 1) + e];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int k = 0; k < n_products(NS); ++k)
+                        acc[tp][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, av[product_a(NS, k)]),
+                            __builtin_bit_cast(bf16x8, bv[sl][i][product_b(NS, k)]), acc[tp][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk();
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) load_chunk(c + 1);
+        compute();
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
+        float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    atomicAdd(base + ((long)tp * p.Cin + reg) * p.M + i * 16, acc[tp][i][reg]);
+    } else {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int k = k0 + wave * 16 + lk * 4 + reg;
+                    const int m = m0 + i * 16 + lrow;
+                    if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+                }
+    }
+    if (do_bias) {
+        __syncthreads();
+        if (tid < 64) rowacc[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < D4) atomicAdd(rowacc + idx / (CT / 4), bsum[i]);
+        }
+        __syncthreads();
+        if (tid < MR && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side: arithmetic mode, plane registry, launch
+// ---------------------------------------------------------------------------------------------------------------
+struct PlaneSet {
+    unsigned short *planes;
+    long n;              // fp32 elements covered
+    int ns;              // planes currently valid
+};
+static std::mutex g_split_mu;
+static std::map<const float *, PlaneSet> g_split_sets;    // keyed by the packed fp32 buffer's base address
+static int g_conv_math = 0;       // planes for the forward-type kernels (0 = native fp32)
+static int g_conv_math_wrw = 0;   // planes for the weight-gradient kernel
+
+static bool find_planes(const float *wp, int ns, const unsigned short **out, long *stride) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_sets.upper_bound(wp);
+    if (it == g_split_sets.begin()) return false;
+    --it;
+    const long off = wp - it->first;
+    if (off < 0 || off >= it->second.n || it->second.ns != ns) return false;
+    *out = it->second.planes + off;
+    *stride = it->second.n;
+    return true;
+}
+
+template <int NS, int RTW, int NCT, int EPI, int TAPS>
+static int launch_split(ConvGemmParams &p, const unsigned short *planes, long stride, hipStream_t s) {
+    constexpr int WGR = 64 * RTW, NT = 16 * NCT;
+    constexpr size_t lds_pipe = (size_t)NS * 3 * (NT + 16) * 80 + (size_t)(NT + 16) * sizeof(float);
+    constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
+    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
+                     aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
+    static size_t attr_max_e = 0;
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("glowtts_conv (split): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
+    const int ntile_t = (p.T + NT - 1) / NT;
+    const int rows = (EPI == EPI_GATE) ? p.H : p.M;
+    const int per = (EPI == EPI_GATE) ? 64 : WGR;
+    dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
+    hipLaunchKernelGGL((convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>), grid, dim3(256), lds, s, p, planes, stride);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv (split)");
+}
+
+template <int NS>
+static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, bool n5, const unsigned short *pl, long st, hipStream_t s) {
+#define GLOWTTS_SPLIT_CASE(E, R, TP)                                                   \
+    if (epi == E && (R == 2) == big && p.taps == TP)                                   \
+        return n5 ? launch_split<NS, R, 5, E, TP>(p, pl, st, s) : launch_split<NS, R, 4, E, TP>(p, pl, st, s);
+    GLOWTTS_SPLIT_CASE(EPI_GATE, 2, 5)
+    GLOWTTS_SPLIT_CASE(EPI_RESSKIP, 2, 1)
+    GLOWTTS_SPLIT_CASE(EPI_RESSKIP_LAST, 1, 1)
+    GLOWTTS_SPLIT_CASE(EPI_GATEBWD, 1, 1)
+    GLOWTTS_SPLIT_CASE(EPI_ADD, 1, 5)
+    GLOWTTS_SPLIT_CASE(EPI_PLAIN, 1, 5)
+#undef GLOWTTS_SPLIT_CASE
+    return -1;
+}
+
+template <int NS, int TAPS, int NGRP, int MT>
+static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
+    constexpr int CT = 16 * NGRP, MR = 16 * MT;
+    constexpr size_t lds = (size_t)NS * (64 + MR) * 104 * 2 + (size_t)(CT + 8 + CT + 64) * sizeof(float);
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    static size_t attr_max_e = 0;
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("glowtts_conv_wrw (split): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
+    const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
+    const int total = p.B * ((p.T + CT - 1) / CT);
+    int splits = 512 / tiles;                       // all workgroups resident at once (2 per CU)
+    if (splits > total) splits = total;
+    if (splits < 1) splits = 1;
+    p.nb = (total + splits - 1) / splits;
+    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
+    hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");
+}
+
+template <int NS>
+static int dispatch_wrw_split_ns(ConvWrwParams &p, hipStream_t s) {
+    const bool n5 = (p.T % 80 == 0) || ((p.T + 79) / 80) * 80 <= ((p.T + 63) / 64) * 64;
+    if (p.taps == 5 && p.M % 32 == 0 && (!p.d2 || p.d_split % 32 == 0))
+        return n5 ? launch_wrw_split<NS, 5, 5, 2>(p, s) : launch_wrw_split<NS, 5, 4, 2>(p, s);
+    if (p.taps == 1) return n5 ? launch_wrw_split<NS, 1, 5, 4>(p, s) : launch_wrw_split<NS, 1, 4, 4>(p, s);
+    return -1;
+}
+
+// called by the frame-packed weight-gradient entries (dilation 1, 'same' padding, 16-byte rows already checked)
+int conv_wrw_split_dispatch(ConvWrwParams &p, hipStream_t s) {
+    const int ns = g_conv_math_wrw;
+    if (ns == 3) return dispatch_wrw_split_ns<3>(p, s);
+    if (ns == 2) return dispatch_wrw_split_ns<2>(p, s);
+    if (ns == 1) return dispatch_wrw_split_ns<1>(p, s);
+    return -1;
+}
+
+// called first by dispatch_convgemm: -1 = not handled here (mode off, weights not registered, shape not instantiated)
+int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s) {
+    const int ns = g_conv_math;
+    if (ns == 0 || !pipe_ok) return -1;
+    const unsigned short *pl = nullptr;
+    long st = 0;
+    if (!find_planes(p.wp, ns, &pl, &st)) return -1;
+    if (ns == 3) return dispatch_split_ns<3>(p, epi, big, n5, pl, st, s);
+    if (ns == 2) return dispatch_split_ns<2>(p, epi, big, n5, pl, st, s);
+    return dispatch_split_ns<1>(p, epi, big, n5, pl, st, s);
+}
+
+}  // namespace glowtts
+
+using namespace glowtts;
+
+extern "C" int glowtts_conv_math(int nsplit) {
+    if (nsplit < 0) return g_conv_math | (g_conv_math_wrw << 2);
+    GLOWTTS_CHECK_ARG(nsplit <= 15, "glowtts_conv_math: mode %d (0 = native fp32, 1 = bf16, 2 = bf16x3, 3 = bf16x6; "
+                      "+ 4 x the same code for the weight-gradient kernel)", nsplit);
+    g_conv_math = nsplit & 3;
+    g_conv_math_wrw = (nsplit >> 2) & 3;
+    return 0;
+}
+
+extern "C" int glowtts_conv_split_weights(const float *wp, long n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(wp && n > 0, "glowtts_conv_split_weights: bad arguments");
+    const int ns = g_conv_math;
+    if (ns == 0) return 0;
+    unsigned short *planes = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_split_mu);
+        auto it = g_split_sets.find(wp);
+        if (it != g_split_sets.end() && it->second.n != n) {
+            (void)hipFree(it->second.planes);
+            g_split_sets.erase(it);
+            it = g_split_sets.end();
+        }
+        if (it == g_split_sets.end()) {
+            void *mem = nullptr;
+            hipError_t e = hipMalloc(&mem, (size_t)3 * n * sizeof(unsigned short));
+            if (e != hipSuccess) { set_error("glowtts_conv_split_weights: %s", hipGetErrorString(e)); return (int)e; }
+            it = g_split_sets.emplace(wp, PlaneSet{static_cast<unsigned short *>(mem), n, ns}).first;
+        }
+        it->second.ns = ns;
+        planes = it->second.planes;
+    }
+    long grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wp, planes, n, n, ns);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv_split_weights");
+}
+
+extern "C" int glowtts_conv_split_release(const float *wp) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    auto it = g_split_sets.find(wp);
+    if (it != g_split_sets.end()) {
+        (void)hipFree(it->second.planes);
+        g_split_sets.erase(it);
+    }
+    return 0;
+}

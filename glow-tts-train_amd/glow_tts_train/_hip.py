@@ -49,6 +49,7 @@ _SIGNATURES = {
     "glowtts_chan_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_conv_split_weights": [_P, _L],
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
     "glowtts_pack_weight_multi": [_P, _P, _I, _I],
@@ -75,7 +76,8 @@ class WnLayer(ctypes.Structure):
                                                  "db_in", "db_rs")]
 
 
-EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version"])
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
+                           "glowtts_conv_split_release"])
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -103,12 +105,40 @@ def load() -> ctypes.CDLL:
     lib.glowtts_last_error.argtypes = []
     lib.glowtts_abi_version.restype = _I
     lib.glowtts_abi_version.argtypes = []
+    lib.glowtts_conv_math.restype = _I
+    lib.glowtts_conv_math.argtypes = [_I]
+    lib.glowtts_conv_split_release.restype = _I
+    lib.glowtts_conv_split_release.argtypes = [_P]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
         fn.argtypes = list(args) + [_P]
     _lib = lib
     return lib
+
+
+CONV_MATH_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+
+
+def conv_math(mode=None) -> int:
+    """Arithmetic of the WN convolutions (include/glowtts_hip.h: glowtts_conv_math): "fp32" (native MFMA, default),
+    "bf16", "bf16x3", "bf16x6" or the numeric code; None only queries.  Returns the mode in force BEFORE the call."""
+    lib = load()
+    before = lib.glowtts_conv_math(-1)
+    if mode is not None:
+        if isinstance(mode, str):            # "bf16x6" or "bf16x6+wrw" (the weight-gradient kernel as well)
+            base, _, wrw = mode.partition("+")
+            code = CONV_MATH_MODES[base] * (5 if wrw == "wrw" else 1)
+        else:
+            code = int(mode)
+        if lib.glowtts_conv_math(code) != 0:
+            raise RuntimeError(lib.glowtts_last_error().decode())
+    return before
+
+
+def conv_split_release(t: Optional[torch.Tensor]):
+    if t is not None and _lib is not None:
+        _lib.glowtts_conv_split_release(t.data_ptr())
 
 
 def ptr(t: Optional[torch.Tensor]):

@@ -8,6 +8,7 @@ already exists (the flat-buffer optimizer keeps it allocated), which removes one
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -15,7 +16,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _hip
-from ._hip import call, f32, ptr, scratch_zeros
+from ._hip import call, conv_math, conv_split_release, f32, ptr, scratch_zeros
 
 # parameters whose .grad was written directly by a backward (no AccumulateGrad node runs for them); a data-parallel
 # reducer subscribes here to learn that a gradient is complete (parallel.FlowBlockReducer)
@@ -283,6 +284,22 @@ class ChanLayerNormFn(Function):
         return dx, (dx if res is not None else None), dg, db, None
 
 
+# Arithmetic of the WN convolutions (see _hip.conv_math / include/glowtts_hip.h).  GLOWTTS_CONV_MATH = fp32 (default:
+# native fp32 MFMA) | bf16x6 | bf16x3 | bf16, optionally "+wrw" for the weight-gradient kernel too.
+_SPLIT_MATH = [False]
+
+
+def set_conv_math(mode: str) -> str:
+    """Select the arithmetic of the WN-stack convolutions; returns the previous setting's numeric code."""
+    before = conv_math(mode)
+    _SPLIT_MATH[0] = (conv_math(None) & 3) != 0
+    return before
+
+
+if os.environ.get("GLOWTTS_CONV_MATH", "fp32") != "fp32":
+    set_conv_math(os.environ["GLOWTTS_CONV_MATH"])
+
+
 class WNPackPlan:
     """Persistent packed-weight / packed-gradient buffers and device descriptor tables of one WN stack, so that weight
     norm + packing of all 2*n_layers convolutions is ONE launch per forward and their un-packing ONE launch per backward
@@ -301,12 +318,20 @@ class WNPackPlan:
         dev = params[0].device
         self.convs = []          # (v, g, wp_f, wp_b, inv, cout, cin, taps, dwp_offset)
         rows, off = [0], 0
+        # all packed weights of the stack live in ONE buffer (zero-filled once: k positions beyond a channel count stay
+        # zero), so the optional split into bf16 planes (glowtts_conv_math) is one launch over it
+        shapes = [tuple(params[3 * i].shape) for i in range(n_convs)]
+        sizes = [(t * ((ci + 15) // 16) * co * 16, t * ((co + 15) // 16) * ci * 16) for co, ci, t in shapes]
+        conv_split_release(getattr(self, "wp_arena", None))
+        self.wp_arena = torch.zeros(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
+        cursor = 0
         for i in range(n_convs):
             v, g = params[3 * i], params[3 * i + 1]
             cout, cin, taps = v.shape
             gi, go = (cin + 15) // 16, (cout + 15) // 16
-            wp_f = (torch.empty if cin % 16 == 0 else torch.zeros)(taps, gi, cout, 16, device=dev)
-            wp_b = (torch.empty if cout % 16 == 0 else torch.zeros)(taps, go, cin, 16, device=dev)
+            wp_f = self.wp_arena[cursor: cursor + sizes[i][0]].view(taps, gi, cout, 16)
+            wp_b = self.wp_arena[cursor + sizes[i][0]: cursor + sizes[i][0] + sizes[i][1]].view(taps, go, cin, 16)
+            cursor += sizes[i][0] + sizes[i][1]
             inv = torch.empty(cout, device=dev) if g is not None else None
             self.convs.append((v, g, wp_f, wp_b, inv, cout, cin, taps, off))
             off += taps * cin * cout
@@ -322,6 +347,14 @@ class WNPackPlan:
 
     def pack(self):
         call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
+        if _SPLIT_MATH[0]:                     # bf16-plane arithmetic is on: refresh the planes of the new weights
+            call("glowtts_conv_split_weights", ptr(self.wp_arena), self.wp_arena.numel())
+
+    def __del__(self):
+        try:
+            conv_split_release(getattr(self, "wp_arena", None))
+        except Exception:
+            pass
 
     def dwp_view(self, i):
         cout, cin, taps, off = self.convs[i][5:9]
