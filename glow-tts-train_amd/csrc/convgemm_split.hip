@@ -13,15 +13,13 @@
 //
 // Data flow (differences from convgemm_wd_kernel, whose tiling, staging map, ring and epilogues are kept):
 //   weights   : the packed fp32 buffer [tap][g][M][16] is split ONCE per step by split_weights_kernel into bf16 planes
-//               with the same element order (glowtts_conv_split_weights, keyed by the packed buffer's address); a lane
+//               with the same element order (glowtts_conv_split_weights into a caller-owned buffer, bound to the
+//               calling thread by glowtts_conv_bind_planes around the launches that use it); a lane
 //               takes 4 channels of group g and 4 of group g+1 (two 8-byte buffer loads per plane) = one bf16x8 A
 //               operand: k is relabelled so that lane slot lk consumes channels 4 lk..4 lk+3 of both groups.
 //   activations: split while they are stored to LDS; plane image [g/2][frame][40 bf16]: a row holds the 32 channels of
 //               a group pair in the A operand's order (pitch 80 B, the conflict-free pitch of the fp32 image), so one
 //               ds_read_b128 per plane is a B operand.
-#include <map>
-#include <mutex>
-
 #undef GLOWTTS_TRACE
 #include "convgemm_common.hpp"
 
@@ -511,25 +509,24 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
 // ---------------------------------------------------------------------------------------------------------------
 // host side: arithmetic mode, plane registry, launch
 // ---------------------------------------------------------------------------------------------------------------
-struct PlaneSet {
-    unsigned short *planes;
-    long n;              // fp32 elements covered
-    int ns;              // planes currently valid
+// The planes of a packed-weight buffer belong to the caller (a device buffer of 3 x n bf16 next to its n fp32 values).
+// A thread binds ONE such pair for the launches it is about to make (the host side binds a WN stack's buffer around its
+// forward / backward and unbinds after): no hidden storage here, nothing that can go stale.
+struct PlaneBinding {
+    const float *wp = nullptr;
+    long n = 0;
+    const unsigned short *planes = nullptr;
+    int ns = 0;
 };
-static std::mutex g_split_mu;
-static std::map<const float *, PlaneSet> g_split_sets;    // keyed by the packed fp32 buffer's base address
+static thread_local PlaneBinding t_bound;
 static int g_conv_math = 0;       // planes for the forward-type kernels (0 = native fp32)
 static int g_conv_math_wrw = 0;   // planes for the weight-gradient kernel
 
 static bool find_planes(const float *wp, int ns, const unsigned short **out, long *stride) {
-    std::lock_guard<std::mutex> lk(g_split_mu);
-    auto it = g_split_sets.upper_bound(wp);
-    if (it == g_split_sets.begin()) return false;
-    --it;
-    const long off = wp - it->first;
-    if (off < 0 || off >= it->second.n || it->second.ns != ns) return false;
-    *out = it->second.planes + off;
-    *stride = it->second.n;
+    const PlaneBinding &b = t_bound;
+    if (b.wp == nullptr || b.ns != ns || wp < b.wp || wp >= b.wp + b.n) return false;
+    *out = b.planes + (wp - b.wp);
+    *stride = b.n;
     return true;
 }
 
@@ -638,40 +635,21 @@ extern "C" int glowtts_conv_math(int nsplit) {
     return 0;
 }
 
-extern "C" int glowtts_conv_split_weights(const float *wp, long n, glowtts_stream_t stream) {
-    GLOWTTS_CHECK_ARG(wp && n > 0, "glowtts_conv_split_weights: bad arguments");
+extern "C" int glowtts_conv_split_weights(const float *wp, long n, unsigned short *planes, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(wp && planes && n > 0, "glowtts_conv_split_weights: bad arguments");
     const int ns = g_conv_math;
     if (ns == 0) return 0;
-    unsigned short *planes = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_split_mu);
-        auto it = g_split_sets.find(wp);
-        if (it != g_split_sets.end() && it->second.n != n) {
-            (void)hipFree(it->second.planes);
-            g_split_sets.erase(it);
-            it = g_split_sets.end();
-        }
-        if (it == g_split_sets.end()) {
-            void *mem = nullptr;
-            hipError_t e = hipMalloc(&mem, (size_t)3 * n * sizeof(unsigned short));
-            if (e != hipSuccess) { set_error("glowtts_conv_split_weights: %s", hipGetErrorString(e)); return (int)e; }
-            it = g_split_sets.emplace(wp, PlaneSet{static_cast<unsigned short *>(mem), n, ns}).first;
-        }
-        it->second.ns = ns;
-        planes = it->second.planes;
-    }
     long grid = (n + 255) / 256;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wp, planes, n, n, ns);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_split_weights");
 }
 
-extern "C" int glowtts_conv_split_release(const float *wp) {
-    std::lock_guard<std::mutex> lk(g_split_mu);
-    auto it = g_split_sets.find(wp);
-    if (it != g_split_sets.end()) {
-        (void)hipFree(it->second.planes);
-        g_split_sets.erase(it);
-    }
+extern "C" int glowtts_conv_bind_planes(const float *wp, long n, const unsigned short *planes) {
+    GLOWTTS_CHECK_ARG(wp == nullptr || (planes && n > 0), "glowtts_conv_bind_planes: bad arguments");
+    t_bound.wp = wp;
+    t_bound.n = wp ? n : 0;
+    t_bound.planes = wp ? planes : nullptr;
+    t_bound.ns = wp ? g_conv_math : 0;           // the planes were written for the mode in force now
     return 0;
 }

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "glowtts_chan_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
-    "glowtts_conv_split_weights": [_P, _L],
+    "glowtts_conv_split_weights": [_P, _L, _P],
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
     "glowtts_pack_weight_multi": [_P, _P, _I, _I],
@@ -77,7 +77,7 @@ class WnLayer(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
-                           "glowtts_conv_split_release"])
+                           "glowtts_conv_bind_planes"])
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -107,8 +107,8 @@ def load() -> ctypes.CDLL:
     lib.glowtts_abi_version.argtypes = []
     lib.glowtts_conv_math.restype = _I
     lib.glowtts_conv_math.argtypes = [_I]
-    lib.glowtts_conv_split_release.restype = _I
-    lib.glowtts_conv_split_release.argtypes = [_P]
+    lib.glowtts_conv_bind_planes.restype = _I
+    lib.glowtts_conv_bind_planes.argtypes = [_P, _L, _P]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -136,9 +136,13 @@ def conv_math(mode=None) -> int:
     return before
 
 
-def conv_split_release(t: Optional[torch.Tensor]):
-    if t is not None and _lib is not None:
-        _lib.glowtts_conv_split_release(t.data_ptr())
+def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] = None):
+    """Bind (or, with None, unbind) a packed-weight buffer's bf16 planes for this thread's next convolution launches."""
+    lib = load()
+    if wp is None:
+        lib.glowtts_conv_bind_planes(None, 0, None)
+    elif lib.glowtts_conv_bind_planes(wp.data_ptr(), wp.numel(), planes.data_ptr()) != 0:
+        raise RuntimeError(lib.glowtts_last_error().decode())
 
 
 def ptr(t: Optional[torch.Tensor]):

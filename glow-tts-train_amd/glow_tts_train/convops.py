@@ -16,7 +16,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _hip
-from ._hip import call, conv_math, conv_split_release, f32, ptr, scratch_zeros
+from ._hip import call, conv_bind_planes, conv_math, f32, ptr, scratch_zeros
 
 # parameters whose .grad was written directly by a backward (no AccumulateGrad node runs for them); a data-parallel
 # reducer subscribes here to learn that a gradient is complete (parallel.FlowBlockReducer)
@@ -322,8 +322,8 @@ class WNPackPlan:
         # zero), so the optional split into bf16 planes (glowtts_conv_math) is one launch over it
         shapes = [tuple(params[3 * i].shape) for i in range(n_convs)]
         sizes = [(t * ((ci + 15) // 16) * co * 16, t * ((co + 15) // 16) * ci * 16) for co, ci, t in shapes]
-        conv_split_release(getattr(self, "wp_arena", None))
         self.wp_arena = torch.zeros(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
+        self.wp_planes = None                # bf16 planes of wp_arena (3 x n uint16), made on first use of a split mode
         cursor = 0
         for i in range(n_convs):
             v, g = params[3 * i], params[3 * i + 1]
@@ -348,13 +348,21 @@ class WNPackPlan:
     def pack(self):
         call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
         if _SPLIT_MATH[0]:                     # bf16-plane arithmetic is on: refresh the planes of the new weights
-            call("glowtts_conv_split_weights", ptr(self.wp_arena), self.wp_arena.numel())
+            if self.wp_planes is None:
+                self.wp_planes = torch.empty(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
+            call("glowtts_conv_split_weights", ptr(self.wp_arena), self.wp_arena.numel(), ptr(self.wp_planes))
 
-    def __del__(self):
-        try:
-            conv_split_release(getattr(self, "wp_arena", None))
-        except Exception:
-            pass
+    def bind(self) -> bool:
+        """Hand this stack's planes to the calling thread's next convolution launches (no-op in native fp32 mode)."""
+        if _SPLIT_MATH[0] and self.wp_planes is not None:
+            conv_bind_planes(self.wp_arena, self.wp_planes)
+            return True
+        return False
+
+    @staticmethod
+    def unbind(bound: bool):
+        if bound:
+            conv_bind_planes(None)
 
     def dwp_view(self, i):
         cout, cin, taps, off = self.convs[i][5:9]
@@ -511,14 +519,22 @@ class WNFn(Function):
     @staticmethod
     def forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, drop_pre, *params):
         # params: per layer (in_v, in_g, in_b, rs_v, rs_g, rs_b); plan: the module's WNPackPlan
+        plan.ensure(params, n_layers)
+        plan.pack()
+        bound = plan.bind()
+        try:
+            return WNFn._forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, drop_pre, *params)
+        finally:
+            plan.unbind(bound)
+
+    @staticmethod
+    def _forward(ctx, x, m2, cond, p_drop, dil_rate, n_layers, plan, drop_pre, *params):
         x = f32(x.contiguous())
         B, H, T = x.shape
         dev = x.device
         saved = []
         skip = None
         cur = x
-        plan.ensure(params, n_layers)
-        plan.pack()
         drop_all = None
         if p_drop > 0.0:
             if drop_pre is not None and tuple(drop_pre.shape) == (n_layers, B, 2 * H, T) and drop_pre.is_contiguous():
@@ -577,11 +593,15 @@ class WNFn(Function):
         n_layers, dil_rate, p_drop, has_cond, B, H, T = ctx.cfg
         sv = ctx.saved_tensors
         m2 = sv[0]
-        if ctx.native:
-            return WNFn._backward_native(ctx, dout)
-        saved = sv[1: 1 + 3 * n_layers]
-        drops = list(sv[1 + 3 * n_layers]) if p_drop > 0 else [None] * n_layers
-        return WNFn._backward_layers(ctx, dout, m2, saved, drops)
+        bound = ctx.plan.bind()              # (the backward runs on autograd's thread: the binding is per thread)
+        try:
+            if ctx.native:
+                return WNFn._backward_native(ctx, dout)
+            saved = sv[1: 1 + 3 * n_layers]
+            drops = list(sv[1 + 3 * n_layers]) if p_drop > 0 else [None] * n_layers
+            return WNFn._backward_layers(ctx, dout, m2, saved, drops)
+        finally:
+            ctx.plan.unbind(bound)
 
     @staticmethod
     def _backward_layers(ctx, dout, m2, saved, drops):

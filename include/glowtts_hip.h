@@ -176,12 +176,15 @@ int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b
 /* Opt-in arithmetic for the WN convolutions (convgemm_split.hip): fp32 operands split into bf16 planes, products on the
  * bf16 matrix pipe, fp32 accumulation.  mode 0 = native fp32 MFMA (default, the parity reference), 1 = bf16 operands,
  * 2 = bf16x3 (products good to 2^-16), 3 = bf16x6 (fp32-equivalent: dropped terms <= 2^-24 |x w|); the weight-gradient
- * kernel has its own code in bits 2-3 (mode = forward_code + 4 * wrw_code).  A negative mode only returns the current one.  A convolution runs in the selected mode when its packed weights lie inside a buffer
- * last handed to glowtts_conv_split_weights (call it after every re-packing: the planes are a snapshot); others, and
- * shapes without a split instantiation, run native.  The library owns the plane storage (released per buffer). */
+ * kernel has its own code in bits 2-3 (mode = forward_code + 4 * wrw_code).  A negative mode only returns the current one.
+ *   glowtts_conv_split_weights: planes[pl * n + i] = plane pl of wp[i] (caller-owned, 3 * n uint16; call after every
+ *     re-packing — the planes are a snapshot of the weights);
+ *   glowtts_conv_bind_planes: the CALLING THREAD's forward-type convolutions whose packed weights lie in [wp, wp + n) use
+ *     these planes until the next bind (wp = NULL unbinds); everything else, and shapes without a split instantiation,
+ *     runs native.  The weight-gradient kernel needs no planes (both its operands are activations). */
 int glowtts_conv_math(int mode);
-int glowtts_conv_split_weights(const float *wp, long n_floats, glowtts_stream_t stream);
-int glowtts_conv_split_release(const float *wp);
+int glowtts_conv_split_weights(const float *wp, long n_floats, uint16_t *planes, glowtts_stream_t stream);
+int glowtts_conv_bind_planes(const float *wp, long n_floats, const uint16_t *planes);
 int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g, const float *inv_norm, float *dv,
                                float *dg, int Cout, int Cin, int taps, glowtts_stream_t stream);
 int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,

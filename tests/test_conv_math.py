@@ -1,0 +1,246 @@
+"""The opt-in bf16-plane arithmetic of the WN convolutions (csrc/convgemm_split.hip, glowtts_conv_math).
+
+An fp32 value is the exact sum of three bf16 values; "bf16x6" forms the six products above 2^-24 on the bf16 matrix pipe
+with fp32 accumulation, so its results must be as close to an fp64 reference as the native fp32 MFMA kernels are.
+"bf16x3" (2^-16 products) and "bf16" are looser modes with their own bounds.  Native fp32 stays the default and the
+parity reference; these tests pin what each mode promises.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def M():
+    """Package handles + a guard that restores native fp32 after every test."""
+    from glow_tts_train import _hip, convops, layers
+
+    _hip.load()
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.hip, ns.convops, ns.layers = _hip, convops, layers
+    before = _hip.conv_math(None)
+    yield ns
+    _hip.conv_bind_planes(None)
+    _PLANES.clear()
+    _hip.conv_math(before)
+    convops._SPLIT_MATH[0] = (before & 3) != 0
+
+
+_PLANES = {}
+
+
+def _split(M, *weights):
+    """Split a packed buffer into caller-owned planes and bind them to this thread (the tests use one buffer at a time)."""
+    for w in weights:
+        planes = _PLANES.setdefault(w.data_ptr(), torch.empty(3 * w.numel(), device=w.device, dtype=torch.int16))
+        M.hip.call("glowtts_conv_split_weights", M.hip.ptr(w), w.numel(), M.hip.ptr(planes))
+        M.hip.conv_bind_planes(w, planes)
+
+
+def _errors(fn, ref, M, weights, modes):
+    out = {}
+    scale = float(ref.abs().max())
+    for mode in modes:
+        M.convops.set_conv_math(mode)
+        _split(M, *weights)
+        got = fn().double()
+        out[mode] = float((got - ref).abs().max()) / scale
+    M.convops.set_conv_math("fp32")
+    return out
+
+
+MODES = ("fp32", "bf16x6+wrw", "bf16x3+wrw", "bf16+wrw")
+
+
+def _check(err, what, must_split=True):
+    native, x6, x3, b16 = (err[m] for m in MODES)
+    assert native < 2e-5, (what, err)
+    assert x6 <= 1.5 * native + 1e-7, (what, err)              # fp32-equivalent: no worse than the native fp32 MFMA path
+    assert x6 <= x3 < 2e-4, (what, err)                        # products good to 2^-16
+    assert x3 <= b16 < 3e-2, (what, err)
+    if must_split:                                             # the split kernels really ran (production width)
+        assert b16 > 20 * native, (what, err)
+
+
+@pytest.mark.parametrize("b,h,t", [(4, 192, 400), (3, 192, 160), (2, 96, 96)])
+def test_every_mode_against_fp64(M, b, h, t):
+    """Gated in-conv (k = 5), res/skip 1x1, backward-data (k = 5) and both weight gradients at WN shapes."""
+    call, ptr = M.hip.call, M.hip.ptr
+    dev = "cuda"
+    torch.manual_seed(b * 1000 + h + t)
+    x = torch.randn(b, h, t, device=dev)
+    lens = torch.randint(t // 2, t + 1, (b,))
+    lens[0] = t
+    m2 = (torch.arange(t)[None] < lens[:, None]).float().to(dev)
+    v_in = torch.randn(2 * h, h, 5, device=dev) * 0.03
+    b_in = torch.randn(2 * h, device=dev) * 0.1
+    v_rs = torch.randn(2 * h, h, 1, device=dev) * 0.07
+    wf_in, wb_in, _ = M.convops.pack_weight(v_in, None)
+    wf_rs, _, _ = M.convops.pack_weight(v_rs, None)
+    acts_in = torch.randn(b, h, t, device=dev) * 0.5
+    skip_in = torch.randn(b, h, t, device=dev)
+    d2 = torch.randn(b, 2 * h, t, device=dev)
+
+    def gate():
+        acts = torch.empty(b, h, t, device=dev)
+        ts = torch.empty(b, 2 * h, t, device=dev)
+        call("glowtts_conv_gate_fwd", ptr(x), ptr(wf_in), ptr(b_in), None, None, 1.0, ptr(acts), ptr(ts), b, h, t, 5, 1, 2)
+        return torch.cat([acts, ts], 1)
+
+    pre = F.conv1d(x.double(), v_in.double(), b_in.double(), padding=2)
+    th, sg = torch.tanh(pre[:, :h]), torch.sigmoid(pre[:, h:])
+    _check(_errors(gate, torch.cat([th * sg, th, sg], 1), M, (wf_in,), MODES), "gate", h == 192)
+
+    def resskip():
+        xo = torch.empty(b, h, t, device=dev)
+        sk = torch.empty(b, h, t, device=dev)
+        call("glowtts_conv_res_skip_fwd", ptr(acts_in), ptr(wf_rs), ptr(b_in), ptr(m2), ptr(x), ptr(skip_in), ptr(xo), ptr(sk),
+             b, h, t, 0)
+        return torch.cat([xo, sk], 1)
+
+    rs = F.conv1d(acts_in.double(), v_rs.double(), b_in.double())
+    ref = torch.cat([(x.double() + rs[:, :h]) * m2[:, None].double(), skip_in.double() + rs[:, h:]], 1)
+    _check(_errors(resskip, ref, M, (wf_rs,), MODES), "res/skip", h == 192)
+
+    def bwd_data():
+        dx = torch.empty(b, h, t, device=dev)
+        M.convops.conv_fwd(d2, wb_in, None, None, dx, 2 * h, h, 5, 1, 2, addend=skip_in)
+        return dx
+
+    ref = F.conv_transpose1d(d2.double(), v_in.double(), padding=2) + skip_in.double()
+    _check(_errors(bwd_data, ref, M, (wb_in,), MODES), "backward-data", h == 192)
+
+    def wrw5():
+        dwp = torch.zeros(5, h, 2 * h, device=dev)
+        db = torch.zeros(2 * h, device=dev)
+        call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d2), d2.stride(0), ptr(m2), None, ptr(dwp), ptr(db), b, h, 2 * h, t,
+             5, 1, 2)
+        return torch.cat([dwp.reshape(-1), db])
+
+    dm = d2.double() * m2[:, None].double()
+    dw = torch.nn.grad.conv1d_weight(x.double(), (2 * h, h, 5), dm, padding=2)
+    _check(_errors(wrw5, torch.cat([dw.permute(2, 1, 0).reshape(-1), dm.sum((0, 2))]), M, (), MODES), "weight grad k=5")
+
+    def wrw1():
+        dwp = torch.zeros(1, h, 2 * h, device=dev)
+        call("glowtts_conv_wrw", ptr(acts_in), acts_in.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp), None, b, h, 2 * h,
+             t, 1, 1, 0)
+        return dwp.reshape(-1)
+
+    _check(_errors(wrw1, torch.einsum("bot,bct->co", d2.double(), acts_in.double()).reshape(-1), M, (), MODES), "weight grad 1x1")
+
+
+def test_planes_are_a_snapshot_and_only_bound_weights_switch(M):
+    """The planes are a snapshot of the packed buffer they were made from (WNPackPlan re-splits after every pack), and only
+    the buffer bound to the calling thread runs in the selected mode: everything else stays native, bit for bit."""
+    call, ptr = M.hip.call, M.hip.ptr
+    b, h, t = 2, 192, 160
+    torch.manual_seed(5)
+    x = torch.randn(b, h, t, device="cuda")
+    v5 = torch.randn(2 * h, h, 5, device="cuda") * 0.03
+    wf, _, _ = M.convops.pack_weight(v5, None)
+    other, _, _ = M.convops.pack_weight(v5 * 1.5, None)
+    acts = torch.empty(b, h, t, device="cuda")
+
+    def gate(w):
+        call("glowtts_conv_gate_fwd", ptr(x), ptr(w), None, None, None, 1.0, ptr(acts), None, b, h, t, 5, 1, 2)
+        return acts.clone()
+
+    native, native_other = gate(wf), gate(other)
+    M.convops.set_conv_math("bf16")
+    assert torch.equal(gate(wf), native)                       # mode on, nothing bound: native kernel
+    _split(M, wf)
+    coarse = gate(wf)
+    assert not torch.equal(coarse, native) and rel_err(coarse, native) < 3e-2
+    assert torch.equal(gate(other), native_other)              # a buffer that is not the bound one: native
+    wf.mul_(2.0)                                               # weights change, planes do not: the old result persists
+    assert torch.equal(gate(wf), coarse)
+    _split(M, wf)
+    assert rel_err(gate(wf), coarse) > 0.1
+    M.hip.conv_bind_planes(None)
+    M.convops.set_conv_math("fp32")
+    doubled = gate(wf)
+    M.convops.set_conv_math("bf16")
+    assert torch.equal(gate(wf), doubled)                      # unbound: native again
+    # a binding made under one mode is not used under another (the planes were written for the mode in force then)
+    _split(M, wf)
+    M.convops.set_conv_math("bf16x6")
+    assert torch.equal(gate(wf), doubled)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 1.0), ("bf16x6+wrw", 1.0), ("bf16x3+wrw", 20.0)])
+def test_wn_stack_in_split_mode_matches_oracle(M, mode, tol):
+    """The whole WN stack (native forward executor, layer-by-layer backward) in split arithmetic against the CPU oracle:
+    bf16x6 within the tolerances of the native path (tests/test_hip_parity.py::test_wn_stack_shapes_vs_oracle)."""
+    from oracle import glow_oracle as O
+
+    b, h, t, k, nl = 2, 192, 160, 5, 4
+    torch.manual_seed(77)
+    wn = M.layers.WN(2 * h, h, kernel_size=k, dilation_rate=1, n_layers=nl, p_dropout=0.0).cuda().train()
+    x0 = torch.randn(b, h, t)
+    lens = torch.tensor([t, t - 37])
+    mask = (torch.arange(t)[None] < lens[:, None]).float()[:, None]
+    r = torch.randn(b, h, t)
+    sd = {"wn." + k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in wn.state_dict().items()}
+    xo = (x0 * mask).clone().requires_grad_(True)
+    yo = O.wn(sd, "wn", xo, mask, None, h, nl, 1)
+    (yo * r).sum().backward()
+
+    M.convops.set_conv_math(mode)
+    for p in wn.parameters():
+        p.grad = torch.zeros_like(p)
+    x = (x0 * mask).cuda().requires_grad_(True)
+    y = wn(x, mask.cuda())
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(y, yo, what="y", rtol=2e-4 * tol, atol=2e-5 * tol * max(1.0, float(yo.abs().max())))
+    assert_close(x.grad, xo.grad, what="dx", rtol=5e-4 * tol, atol=5e-5 * tol * max(1.0, float(xo.grad.abs().max())))
+    for name, p in wn.named_parameters():
+        want = sd["wn." + name].grad
+        assert_close(p.grad, want, what=f"grad {name}", rtol=1e-3 * tol, atol=1e-4 * tol * max(1.0, float(want.abs().max())))
+
+
+def test_training_step_bf16x6_tracks_native(M):
+    """Three optimisation steps of a production-width model, native fp32 against bf16x6, from the same start: losses agree
+    to fp32 noise and the parameters stay together (Adam's sign-like update only diverges where gradients are noise)."""
+    from glow_tts_train import models, optimize
+    from glow_tts_train.train import train_batch
+
+    def run(mode):
+        M.convops.set_conv_math(mode)
+        torch.manual_seed(1234)
+        model = models.FlowGenerator(n_vocab=148, hidden_channels=192, filter_channels=768, filter_channels_dp=256,
+                                     out_channels=80, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.0, n_blocks_dec=3,
+                                     kernel_size_dec=5, dilation_rate=1, n_block_layers=4, p_dropout_dec=0.0, n_split=4,
+                                     n_sqz=2, window_size=4, mean_only=True, prenet=True).cuda().train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        with torch.no_grad():
+            for f in model.decoder.flows:
+                if hasattr(f, "end"):
+                    f.end.weight.normal_(0, 0.01)
+        opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=192, warmup_steps=4000, lr=1.0)
+        gen = torch.Generator().manual_seed(9)
+        bsz, tx, ty = 4, 40, 200
+        xl = torch.tensor([40, 33, 30, 21]).cuda()
+        yl = torch.tensor([200, 170, 150, 110]).cuda()
+        x = (torch.randint(1, 148, (bsz, tx), generator=gen) * (torch.arange(tx)[None] < xl.cpu()[:, None])).cuda()
+        y = (torch.randn(bsz, 80, ty, generator=gen) * (torch.arange(ty)[None, None] < yl.cpu()[:, None, None])).cuda()
+        losses = [float(train_batch(model, opt, (x, xl, y, yl, None), 5.0)) for _ in range(3)]
+        return losses, opt._optim.flat_p.clone()
+
+    l0, p0 = run("fp32")
+    l1, p1 = run("bf16x6+wrw")
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    close = ((p1 - p0).abs() <= 1e-5 + 1e-3 * p0.abs()).float().mean().item()
+    assert close > 0.99, close

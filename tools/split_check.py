@@ -110,11 +110,14 @@ for name, fn, ref_fn, weights in CASES:
     scale = ref.abs().max()
     for mode in ("fp32", "bf16x6", "bf16x3", "bf16"):
         _hip.conv_math(mode + "+wrw")
-        for w in weights:
-            call("glowtts_conv_split_weights", ptr(w), w.numel())
+        for w in weights:            # one buffer per case: split it and bind its planes to this thread
+            planes = torch.empty(3 * w.numel(), device=dev, dtype=torch.int16)
+            call("glowtts_conv_split_weights", ptr(w), w.numel(), ptr(planes))
+            _hip.conv_bind_planes(w, planes)
         out = fn().double()
         err = (out - ref).abs()
         us = timed(fn)
         print(f"{name:20s} {mode:7s} {us:8.1f} us   max|err|/max|ref| {float(err.max() / scale):.3e}   "
               f"rms err/rms ref {float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.3e}", flush=True)
+    _hip.conv_bind_planes(None)
     _hip.conv_math("fp32")
