@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--gin", type=int, default=64, help="speaker embedding width when --speakers > 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-split-math", action="store_true",
+                    help="skip the extra leg that times the same step with the WN convolutions in bf16x6 split arithmetic")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (GraphedTrainStep); default is eager launches — the step is "
@@ -259,6 +261,33 @@ def main():
                                + "random-init weights, synthetic resident batch",
                    "global_batch": world * B, "parallelism": f"dp{world}", "launch": mode, "final_loss": loss_val},
     }
+
+    # ---- extra leg (not `value`): the same step with the WN convolutions' fp32 operands split into bf16 planes and the
+    # six products above 2^-24 formed on the bf16 matrix pipe ("bf16x6", csrc/convgemm_split.hip): fp32-equivalent results
+    # (tests/test_conv_math.py: error against fp64 no larger than the native fp32 MFMA kernels'), opt-in at run time
+    # (GLOWTTS_CONV_MATH=bf16x6).  `value` above is always the native fp32 MFMA path.
+    if not args.no_split_math and mode == "eager":
+        from glow_tts_train import convops
+
+        previous = convops.set_conv_math("bf16x6")
+        for _ in range(3):
+            step_fn()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step_fn()
+        fence()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt)
+        convops.set_conv_math(previous)
+        out["split_math"] = {"mode": "bf16x6", "value": frames / dts, "unit": "mel-frames/s",
+                             "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
+                             "arithmetic": "WN convolutions (forward, backward-data): fp32 operands as 3 bf16 planes, 6 products "
+                                           "per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; everything else as in `value`"}
+        log(f"split-math leg: {out['split_math']['ms_per_step']:.2f} ms/step")
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if rank == 0 and not args.no_roofline:
