@@ -270,24 +270,30 @@ def main():
         from glow_tts_train import convops
 
         previous = convops.set_conv_math("bf16x6")
-        for _ in range(3):
-            step_fn()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step_fn()
-        fence()
-        dts = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dts], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dts = float(tt)
-        convops.set_conv_math(previous)
-        out["split_math"] = {"mode": "bf16x6", "value": frames / dts, "unit": "mel-frames/s",
-                             "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
-                             "arithmetic": "WN convolutions (forward, backward-data): fp32 operands as 3 bf16 planes, 6 products "
-                                           "per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; everything else as in `value`"}
-        log(f"split-math leg: {out['split_math']['ms_per_step']:.2f} ms/step")
+        try:
+            for _ in range(3):
+                step_fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step_fn()
+            fence()
+            dts = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([dts], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dts = float(tt)
+            out["split_math"] = {"mode": "bf16x6", "value": frames / dts, "unit": "mel-frames/s",
+                                 "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
+                                 "arithmetic": "WN convolutions (forward, backward-data): fp32 operands as 3 bf16 planes, 6 "
+                                               "products per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; everything "
+                                               "else as in `value`"}
+            log(f"split-math leg: {out['split_math']['ms_per_step']:.2f} ms/step")
+        except Exception as exc:                    # the extra leg must never cost the run its native result
+            log(f"split-math leg failed ({type(exc).__name__}: {exc}); reported as null")
+            out["split_math"] = None
+        finally:
+            convops.set_conv_math(previous)         # the roofline pass below measures the native kernels
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if rank == 0 and not args.no_roofline:
