@@ -20,7 +20,6 @@
 //   activations: split while they are stored to LDS; plane image [g/2][frame][40 bf16]: a row holds the 32 channels of
 //               a group pair in the A operand's order (pitch 80 B, the conflict-free pitch of the fp32 image), so one
 //               ds_read_b128 per plane is a B operand.
-#undef GLOWTTS_TRACE
 #include "convgemm_common.hpp"
 
 namespace glowtts {
@@ -210,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
             bv[slot][pl] = *reinterpret_cast<const i32x4 *>(xd + pl * (PLANE16 / 2) + (g2 * XC + cc * 16 + tap * p.dil) * (RP / 2));
     };
 
+    GLOWTTS_TRACE_POINT(0);
     wload(0, 0, 0);
     wload(0, 1, 1);
     wload(0, 2, 2);
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
     if (p.mask_in) __syncthreads();
     xstore();
     __syncthreads();
+    GLOWTTS_TRACE_POINT(1);
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         bfetch(0, 0);
@@ -240,17 +241,20 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
             if (s == 0 && more) xload(c + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        GLOWTTS_TRACE_POINT(2 + 2 * (c & 3));
         __syncthreads();
         if (more) {
             xstore();
             __syncthreads();
         }
+        GLOWTTS_TRACE_POINT(3 + 2 * (c & 3));
     }
     if (p.vec_epilogue) {
         conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);
     } else {
         conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
     }
+    GLOWTTS_TRACE_POINT(10);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -456,21 +460,28 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         }
     };
 
+    GLOWTTS_TRACE_POINT_Z(0);
     if (nchunks > 0) {
         load_chunk(0);
         store_chunk();
     }
     __syncthreads();
+    GLOWTTS_TRACE_POINT_Z(1);
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
         if (more) load_chunk(c + 1);
         compute();
+        if (c == 0) GLOWTTS_TRACE_POINT_Z(2);
         __syncthreads();
+        if (c == 0) GLOWTTS_TRACE_POINT_Z(5);
         if (more) {
             store_chunk();
+            if (c == 0) GLOWTTS_TRACE_POINT_Z(6);
             __syncthreads();
         }
+        if (c == 0) GLOWTTS_TRACE_POINT_Z(3);
     }
+    GLOWTTS_TRACE_POINT_Z(4);
     if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
         float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
 #pragma unroll
@@ -492,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                     if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
                 }
     }
+    GLOWTTS_TRACE_POINT_Z(10);
     if (do_bias) {
         __syncthreads();
         if (tid < 64) rowacc[tid] = 0.f;
@@ -653,3 +665,15 @@ extern "C" int glowtts_conv_bind_planes(const float *wp, long n, const unsigned 
     t_bound.ns = wp ? g_conv_math : 0;           // the planes were written for the mode in force now
     return 0;
 }
+
+#ifdef GLOWTTS_TRACE
+extern "C" int glowtts_debug_trace_read_split(unsigned long long *host, int n_words, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(glowtts::g_trace), (size_t)n_words * 8);
+    if (e != hipSuccess) return (int)e;
+    if (clear) {
+        static unsigned long long zeros[8192 * 16];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(glowtts::g_trace), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
+#endif

@@ -46,7 +46,17 @@ dwp5 = torch.zeros(5, H, 2 * H, device=dev)
 dwp1 = torch.zeros(1, H, 2 * H, device=dev)
 fn = fns[which]
 lib = _hip.load()
-rd = lib.glowtts_debug_trace_read
+split = os.environ.get("TRACE_CONV_MATH")          # e.g. "bf16x6+wrw": trace the bf16-plane kernels (convgemm_split.hip)
+if split:
+    _hip.conv_math(split)
+    _planes = {}
+    for w in (wf_in, wb_in, wf_rs, wb_rs):          # bind the one buffer the chosen kernel uses
+        _planes[w.data_ptr()] = torch.empty(3 * w.numel(), device=dev, dtype=torch.int16)
+    _use = {"gate": wf_in, "resskip": wf_rs, "bwd_data5": wb_in, "bwd_data1": wb_rs, "gate_bwd": wb_rs}.get(which)
+    if _use is not None:
+        call("glowtts_conv_split_weights", ptr(_use), _use.numel(), ptr(_planes[_use.data_ptr()]))
+        _hip.conv_bind_planes(_use, _planes[_use.data_ptr()])
+rd = lib.glowtts_debug_trace_read_split if split else lib.glowtts_debug_trace_read
 rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 NW = 8192 * 16
 buf = np.zeros(NW, dtype=np.uint64)
