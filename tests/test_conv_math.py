@@ -244,3 +244,37 @@ def test_training_step_bf16x6_tracks_native(M):
     np.testing.assert_allclose(l1, l0, rtol=2e-5)
     close = ((p1 - p0).abs() <= 1e-5 + 1e-3 * p0.abs()).float().mean().item()
     assert close > 0.99, close
+
+
+@pytest.mark.parametrize("b,t_mel,blocks", [(64, 1000, 12), (8, 400, 6)])
+def test_bf16_mode_logdet_tolerance(M, b, t_mel, blocks):
+    """BASELINE configs[2] ("bf16 ... log-det tolerance check") at its full size, and config 1's: the flow decoder with the
+    WN convolutions on plain bf16 operands against the native fp32 path.  The invertible kernels (ActNorm, InvConvNear,
+    affine apply) stay fp32 in every mode, so the log-det only moves through the couplings' predicted log-scales."""
+    from glow_tts_train import models
+
+    torch.manual_seed(3)
+    dec = models.FlowSpecDecoder(80, 192, 5, 1, blocks, 4, p_dropout=0.0, n_split=4, n_sqz=2, sigmoid_scale=False,
+                                 gin_channels=0).cuda().train()
+    with torch.no_grad():
+        for f in dec.flows:
+            if hasattr(f, "end"):
+                f.end.weight.normal_(0, 0.01)
+            if hasattr(f, "logs") and hasattr(f, "bias"):
+                f.logs.normal_(0, 0.1)
+                f.bias.normal_(0, 0.1)
+    yl = torch.linspace(t_mel, t_mel // 2, b).long()
+    y = (torch.randn(b, 80, t_mel) * (torch.arange(t_mel)[None, None] < yl[:, None, None])).cuda()
+    mask = (torch.arange(t_mel)[None, None] < ((yl // 2) * 2)[:, None, None]).float().cuda()
+
+    def run(mode):
+        M.convops.set_conv_math(mode)
+        with torch.no_grad():
+            return dec(y, mask)
+
+    z0, ld0 = run("fp32")
+    z6, ld6 = run("bf16x6")
+    z1, ld1 = run("bf16")
+    assert rel_err(z6, z0) < 1e-5 and rel_err(ld6, ld0) < 1e-6
+    assert 1e-5 < rel_err(z1, z0) < 5e-2                            # really a different arithmetic, and a usable one
+    assert rel_err(ld1, ld0) < 2e-3                                 # the log-det tolerance of the bf16 configuration
