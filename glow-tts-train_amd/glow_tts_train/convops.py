@@ -305,9 +305,10 @@ class WNPackPlan:
     norm + packing of all 2*n_layers convolutions is ONE launch per forward and their un-packing ONE launch per backward
     (the tables hold raw device pointers, valid as long as the parameter storage does not move: checked by key)."""
 
-    def __init__(self):
+    def __init__(self, want_planes: bool = False):
         self.key = None
         self.gkey = None
+        self.want_planes = want_planes       # only a WN stack's convolutions have bf16-plane kernels (convgemm_split.hip)
 
     def ensure(self, params, n_layers=None, n_convs=None):
         """params: (v, g, bias) per convolution; a WN stack passes n_layers (2 convolutions per layer)."""
@@ -347,7 +348,7 @@ class WNPackPlan:
 
     def pack(self):
         call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
-        if _SPLIT_MATH[0]:                     # bf16-plane arithmetic is on: refresh the planes of the new weights
+        if _SPLIT_MATH[0] and self.want_planes:   # bf16-plane arithmetic is on: refresh the planes of the new weights
             if self.wp_planes is None:
                 self.wp_planes = torch.empty(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
             call("glowtts_conv_split_weights", ptr(self.wp_arena), self.wp_arena.numel(), ptr(self.wp_planes))

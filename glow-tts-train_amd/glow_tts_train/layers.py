@@ -114,7 +114,7 @@ class WN(nn.Module):
             flat.extend(self._conv_params(rs_layer))
         p_drop = float(self.p_dropout) if self.training else 0.0
         if not hasattr(self, "_pack_plan"):
-            self._pack_plan = convops.WNPackPlan()
+            self._pack_plan = convops.WNPackPlan(want_planes=True)
         drop_pre, self._drop_pre = getattr(self, "_drop_pre", None), None     # keep-masks drawn ahead by FlowSpecDecoder
         return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, drop_pre, *flat)
 
