@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 // ds_read_b128): even shifts are a choice of registers, odd shifts one v_alignbit per register.
 // Chunks stay 80 frames (T' = 400 = 5 chunks): the third step of a chunk is half zeros (d rows are zero past frame 80).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NS, int TAPS, int NGRP, int MT>
+// PRE: x and d arrive as bf16 planes already (p.xpl / p.dpl, written by glowtts_split_planes or a producer's epilogue):
+// staging is then 8-byte loads straight into 8-byte LDS stores, with no vector work at all.
+template <int NS, int TAPS, int NGRP, int MT, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) {
     constexpr int MR = 16 * MT;
     constexpr int CT = 16 * NGRP, NSTEP = (CT + 31) / 32, CTP = NSTEP * 32;
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xreg[NX], dreg[ND], mreg;
+    f32x4 xreg[PRE ? 1 : NX], dreg[PRE ? 1 : ND], mreg;
+    i32x2 xpr[PRE ? NX : 1][NS], dpr[PRE ? ND : 1][NS];
     float bsum[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) bsum[i] = 0.f;
@@ -322,6 +325,14 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     auto ld16 = [&](const __amdgpu_buffer_rsrc_t &rs, int byte_off) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
     };
+    __amdgpu_buffer_rsrc_t xprs[NS], dprs[NS];
+    if (PRE) {
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+            xprs[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.xpl + pl * p.xpl_stride), 0, xbytes / 2, 0x00020000);
+            dprs[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(p.dpl + pl * p.dpl_stride), 0, dbytes / 2, 0x00020000);
+        }
+    }
     int xrow[NX], xq[NX], drow[ND], dq[ND];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -348,6 +359,25 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         const int tc = ((c0 + c) % nct) * CT;
         const int ts = tc - PAD - OFF;
         const int xb = b * (int)p.x_bs, db = b * (int)d_bs;
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int t = ts + xq[i];
+                const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    xpr[i][pl] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(xprs[pl], ok ? (xb + xrow[i] + t) * 2 : kOOB, 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int t = tc + dq[i];
+                const bool ok = drow[i] >= 0 && t < p.T;
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    dpr[i][pl] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(dprs[pl], ok ? (db + drow[i] + t) * 2 : kOOB, 0, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int t = ts + xq[i];
@@ -367,6 +397,36 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         }
     };
     auto store_chunk = [&]() {
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int idx = tid + i * 256;
+                const int q = idx % (XWL / 4), r = idx / (XWL / 4);
+                if (idx < X4)
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = xpr[i][pl];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int idx = tid + i * 256;
+                const int q = idx % (CT / 4), r = idx / (CT / 4);
+                if (idx < D4) {
+                    if (do_bias) {                           // the planes sum back to the fp32 value exactly
+                        float sum = 0.f;
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) {
+                            const unsigned a = (unsigned)dpr[i][pl][0], b2 = (unsigned)dpr[i][pl][1];
+                            sum += (__uint_as_float(a << 16) + __uint_as_float(a & 0xffff0000u)) +
+                                   (__uint_as_float(b2 << 16) + __uint_as_float(b2 & 0xffff0000u));
+                        }
+                        bsum[i] += sum;
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = dpr[i][pl];
+                }
+            }
+            return;
+        }
         if (masked) {
             if (mx_thread) *reinterpret_cast<f32x4 *>(Mx + tid * 4) = mreg;
             if (md_thread) *reinterpret_cast<f32x4 *>(Md + (tid - 64) * 4) = mreg;
@@ -604,6 +664,35 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");
 }
 
+template <int NS, int TAPS, int NGRP, int MT>
+static int launch_wrw_planes(ConvWrwParams &p, hipStream_t s) {
+    constexpr int CT = 16 * NGRP, MR = 16 * MT;
+    constexpr size_t lds = (size_t)NS * (64 + MR) * 104 * 2 + (size_t)(CT + 8 + CT + 64) * sizeof(float);
+    static size_t attr_max_e = 0;
+    if ((size_t)lds > attr_max_e) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("glowtts_conv_wrw_planes: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+        attr_max_e = (size_t)lds;
+    }
+    const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
+    const int total = p.B * ((p.T + CT - 1) / CT);
+    int splits = 512 / tiles;
+    if (splits > total) splits = total;
+    if (splits < 1) splits = 1;
+    p.nb = (total + splits - 1) / splits;
+    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
+    hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT, true>), grid, dim3(256), lds, s, p);
+    GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw_planes");
+}
+
+int conv_wrw_planes_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
+    const bool n5 = (p.T % 80 == 0) || ((p.T + 79) / 80) * 80 <= ((p.T + 63) / 64) * 64;
+    if (ns == 3 && p.taps == 5 && p.M % 32 == 0) return n5 ? launch_wrw_planes<3, 5, 5, 2>(p, s) : launch_wrw_planes<3, 5, 4, 2>(p, s);
+    if (ns == 3 && p.taps == 1) return n5 ? launch_wrw_planes<3, 1, 5, 4>(p, s) : launch_wrw_planes<3, 1, 4, 4>(p, s);
+    return -1;
+}
+
 template <int NS>
 static int dispatch_wrw_split_ns(ConvWrwParams &p, hipStream_t s) {
     const bool n5 = (p.T % 80 == 0) || ((p.T + 79) / 80) * 80 <= ((p.T + 63) / 64) * 64;
@@ -664,6 +753,34 @@ extern "C" int glowtts_conv_bind_planes(const float *wp, long n, const unsigned 
     t_bound.planes = wp ? planes : nullptr;
     t_bound.ns = wp ? g_conv_math : 0;           // the planes were written for the mode in force now
     return 0;
+}
+
+extern "C" int glowtts_split_planes(const float *x, long n, unsigned short *planes, int n_planes, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && planes && n > 0 && n_planes >= 1 && n_planes <= 3, "glowtts_split_planes: bad arguments");
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, planes, n, n, n_planes);
+    GLOWTTS_LAUNCH_CHECK("glowtts_split_planes");
+}
+
+extern "C" int glowtts_conv_wrw_planes(const unsigned short *x_planes, long x_plane_stride, long x_bs,
+                                       const unsigned short *d_planes, long d_plane_stride, long d_bs, float *dwp, float *dbias,
+                                       int B, int Cin, int M, int T, int taps, int n_planes, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x_planes && d_planes && dwp, "glowtts_conv_wrw_planes: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && Cin > 0 && M > 0 && T >= 0 && T % 4 == 0 && x_bs % 4 == 0 && d_bs % 4 == 0,
+                      "glowtts_conv_wrw_planes: bad shape (T and the batch strides must be multiples of 4)");
+    GLOWTTS_CHECK_ARG((reinterpret_cast<uintptr_t>(x_planes) & 7u) == 0 && (reinterpret_cast<uintptr_t>(d_planes) & 7u) == 0 &&
+                          x_plane_stride % 4 == 0 && d_plane_stride % 4 == 0,
+                      "glowtts_conv_wrw_planes: planes must be 8-byte aligned");
+    if ((long)B * T == 0) return 0;
+    ConvWrwParams p{};
+    p.xpl = x_planes; p.dpl = d_planes; p.xpl_stride = x_plane_stride; p.dpl_stride = d_plane_stride;
+    p.dwp = dwp; p.dbias = dbias; p.x_bs = x_bs; p.d_bs = d_bs;
+    p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = 1; p.pad = (taps - 1) / 2;
+    const int rc = conv_wrw_planes_dispatch(p, n_planes, (hipStream_t)stream);
+    GLOWTTS_CHECK_ARG(rc >= 0, "glowtts_conv_wrw_planes: no kernel for taps=%d, M=%d, planes=%d (3 planes; 5 taps with M %% 32 == 0, or 1 tap)",
+                      taps, M, n_planes);
+    return rc;
 }
 
 #ifdef GLOWTTS_TRACE

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_conv_split_weights": [_P, _L, _P],
+    "glowtts_split_planes": [_P, _L, _P, _I],
+    "glowtts_conv_wrw_planes": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _I],
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
     "glowtts_pack_weight_multi": [_P, _P, _I, _I],

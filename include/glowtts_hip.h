@@ -185,6 +185,17 @@ int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b
 int glowtts_conv_math(int mode);
 int glowtts_conv_split_weights(const float *wp, long n_floats, uint16_t *planes, glowtts_stream_t stream);
 int glowtts_conv_bind_planes(const float *wp, long n_floats, const uint16_t *planes);
+
+/* The weight gradient from operands that are bf16 planes already (3 planes: the bf16x6 arithmetic above).  Splitting costs
+ * ~15 vector instructions per value and the weight-gradient tile reuses a staged value in few MFMAs, so the split is done
+ * ONCE per tensor (glowtts_split_planes: planes[pl * n + i] = plane pl of x[i]; later by the producing kernel's epilogue)
+ * instead of once per workgroup.  x_planes / d_planes index like the fp32 tensors (B, Cin, T) / (B, M, T) with batch strides
+ * x_bs / d_bs in elements; dilation 1, 'same' padding, taps 5 (M % 32 == 0) or 1; dwp [taps][Cin][M] and dbias [M] are
+ * accumulated (atomics) as in glowtts_conv_wrw (reference: autograd of layers.py:143,153 F.conv1d). */
+int glowtts_split_planes(const float *x, long n, uint16_t *planes, int n_planes, glowtts_stream_t stream);
+int glowtts_conv_wrw_planes(const uint16_t *x_planes, long x_plane_stride, long x_bs, const uint16_t *d_planes,
+                            long d_plane_stride, long d_bs, float *dwp, float *dbias, int B, int Cin, int M, int T, int taps,
+                            int n_planes, glowtts_stream_t stream);
 int glowtts_unpack_weight_grad(const float *dwp, const float *v, const float *g, const float *inv_norm, float *dv,
                                float *dg, int Cout, int Cin, int taps, glowtts_stream_t stream);
 int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,

@@ -278,3 +278,37 @@ def test_bf16_mode_logdet_tolerance(M, b, t_mel, blocks):
     assert rel_err(z6, z0) < 1e-5 and rel_err(ld6, ld0) < 1e-6
     assert 1e-5 < rel_err(z1, z0) < 5e-2                            # really a different arithmetic, and a usable one
     assert rel_err(ld1, ld0) < 2e-3                                 # the log-det tolerance of the bf16 configuration
+
+
+@pytest.mark.parametrize("b,h,t", [(4, 192, 400), (3, 192, 160), (2, 96, 96)])
+def test_weight_gradient_from_presplit_planes(M, b, h, t):
+    """glowtts_split_planes + glowtts_conv_wrw_planes: the weight gradient from operands split ONCE into three bf16 planes
+    (groundwork for letting the producing kernels write the planes; not yet on the training path) is fp32-equivalent."""
+    call, ptr = M.hip.call, M.hip.ptr
+    dev = "cuda"
+    torch.manual_seed(b + h + t)
+    x = torch.randn(b, h, t, device=dev)
+    d = torch.randn(b, 2 * h, t, device=dev)
+    xp = torch.empty(3 * x.numel(), device=dev, dtype=torch.int16)
+    dp = torch.empty(3 * d.numel(), device=dev, dtype=torch.int16)
+    call("glowtts_split_planes", ptr(x), x.numel(), ptr(xp), 3)
+    call("glowtts_split_planes", ptr(d), d.numel(), ptr(dp), 3)
+    # the three planes sum back to the value exactly
+    planes = xp.view(3, -1).to(torch.int32).bitwise_and(0xFFFF).bitwise_left_shift(16).view(torch.float32)
+    assert torch.equal(planes[0] + planes[1] + planes[2], x.reshape(-1))
+    for taps in (5, 1):
+        dwp = torch.zeros(taps, h, 2 * h, device=dev)
+        db = torch.zeros(2 * h, device=dev)
+        call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), h * t, ptr(dp), d.numel(), 2 * h * t, ptr(dwp), ptr(db), b, h, 2 * h, t,
+             taps, 3)
+        native = torch.zeros(taps, h, 2 * h, device=dev)
+        call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d), d.stride(0), None, None, ptr(native), None, b, h, 2 * h, t, taps, 1,
+             (taps - 1) // 2)
+        dw = torch.nn.grad.conv1d_weight(x.double(), (2 * h, h, taps), d.double(), padding=(taps - 1) // 2).permute(2, 1, 0)
+        scale = float(dw.abs().max())
+        e_planes = float((dwp.double() - dw).abs().max()) / scale
+        e_native = float((native.double() - dw).abs().max()) / scale
+        assert e_planes <= 1.5 * e_native + 1e-7, (taps, e_planes, e_native)
+        assert rel_err(db, d.double().sum((0, 2))) < 1e-6
+    with pytest.raises(RuntimeError, match="no kernel"):
+        call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), h * t, ptr(dp), d.numel(), 2 * h * t, ptr(dwp), None, b, h, 2 * h, t, 3, 3)

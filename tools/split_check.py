@@ -121,3 +121,37 @@ for name, fn, ref_fn, weights in CASES:
               f"rms err/rms ref {float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.3e}", flush=True)
     _hip.conv_bind_planes(None)
     _hip.conv_math("fp32")
+
+# ---- weight gradient from operands split ONCE (glowtts_split_planes + glowtts_conv_wrw_planes), 3 planes
+xp = torch.empty(3 * x.numel(), device=dev, dtype=torch.int16)
+dp = torch.empty(3 * d2.numel(), device=dev, dtype=torch.int16)
+ap = torch.empty(3 * acts_in.numel(), device=dev, dtype=torch.int16)
+dwp5 = torch.zeros(5, H, 2 * H, device=dev)
+db5 = torch.zeros(2 * H, device=dev)
+dwp1 = torch.zeros(1, H, 2 * H, device=dev)
+
+
+def split_xd():
+    call("glowtts_split_planes", ptr(x), x.numel(), ptr(xp), 3)
+    call("glowtts_split_planes", ptr(d2), d2.numel(), ptr(dp), 3)
+
+
+def wrw5_planes():
+    call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), H * T, ptr(dp), d2.numel(), 2 * H * T, ptr(dwp5), ptr(db5), B, H, 2 * H, T, 5, 3)
+
+
+def wrw1_planes():
+    call("glowtts_conv_wrw_planes", ptr(ap), acts_in.numel(), H * T, ptr(dp), d2.numel(), 2 * H * T, ptr(dwp1), None, B, H, 2 * H, T, 1, 3)
+
+
+split_xd()
+call("glowtts_split_planes", ptr(acts_in), acts_in.numel(), ptr(ap), 3)
+dwp5.zero_(); db5.zero_(); dwp1.zero_()
+wrw5_planes(); wrw1_planes()
+for name, got, ref in (("weight grad k=5 from planes", torch.cat([dwp5.reshape(-1), db5]).double(), wrw5_ref()),
+                       ("weight grad 1x1 from planes", dwp1.reshape(-1).double(), wrw1_ref())):
+    err = (got - ref).abs()
+    print(f"{name:28s} max|err|/max|ref| {float(err.max() / ref.abs().max()):.3e}   rms err/rms ref "
+          f"{float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.3e}")
+print(f"split x (9.8 MB) + d (19.7 MB) into planes: {timed(split_xd):.1f} us;  k=5 from planes: {timed(wrw5_planes):.1f} us;  "
+      f"1x1 from planes: {timed(wrw1_planes):.1f} us")

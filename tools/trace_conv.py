@@ -44,6 +44,14 @@ fns = {
 }
 dwp5 = torch.zeros(5, H, 2 * H, device=dev)
 dwp1 = torch.zeros(1, H, 2 * H, device=dev)
+if which == "wrw5p":                                   # weight gradient from operands split once (3 bf16 planes)
+    xp = torch.empty(3 * x.numel(), device=dev, dtype=torch.int16)
+    dp = torch.empty(3 * d2.numel(), device=dev, dtype=torch.int16)
+    call("glowtts_split_planes", ptr(x), x.numel(), ptr(xp), 3)
+    call("glowtts_split_planes", ptr(d2), d2.numel(), ptr(dp), 3)
+    fns["wrw5p"] = lambda: call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), H * T, ptr(dp), d2.numel(), 2 * H * T, ptr(dwp5),
+                                None, B, H, 2 * H, T, 5, 3)
+    os.environ.setdefault("TRACE_CONV_MATH", "fp32")
 fn = fns[which]
 lib = _hip.load()
 split = os.environ.get("TRACE_CONV_MATH")          # e.g. "bf16x6+wrw": trace the bf16-plane kernels (convgemm_split.hip)
@@ -56,7 +64,7 @@ if split:
     if _use is not None:
         call("glowtts_conv_split_weights", ptr(_use), _use.numel(), ptr(_planes[_use.data_ptr()]))
         _hip.conv_bind_planes(_use, _planes[_use.data_ptr()])
-rd = lib.glowtts_debug_trace_read_split if split else lib.glowtts_debug_trace_read
+rd = lib.glowtts_debug_trace_read_split if (split or which == "wrw5p") else lib.glowtts_debug_trace_read
 rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 NW = 8192 * 16
 buf = np.zeros(NW, dtype=np.uint64)
