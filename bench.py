@@ -265,11 +265,11 @@ def main():
     # ---- extra leg (not `value`): the same step with the WN convolutions' fp32 operands split into bf16 planes and the
     # six products above 2^-24 formed on the bf16 matrix pipe ("bf16x6", csrc/convgemm_split.hip): fp32-equivalent results
     # (tests/test_conv_math.py: error against fp64 no larger than the native fp32 MFMA kernels'), opt-in at run time
-    # (GLOWTTS_CONV_MATH=bf16x6).  `value` above is always the native fp32 MFMA path.
+    # (GLOWTTS_CONV_MATH=bf16x6+wrw).  `value` above is always the native fp32 MFMA path.
     if not args.no_split_math and mode == "eager":
         from glow_tts_train import convops
 
-        previous = convops.set_conv_math("bf16x6")
+        previous = convops.set_conv_math("bf16x6+wrw")
         try:
             for _ in range(3):
                 step_fn()
@@ -283,11 +283,11 @@ def main():
                 tt = torch.tensor([dts], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dts = float(tt)
-            out["split_math"] = {"mode": "bf16x6", "value": frames / dts, "unit": "mel-frames/s",
+            out["split_math"] = {"mode": "bf16x6+wrw", "value": frames / dts, "unit": "mel-frames/s",
                                  "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
-                                 "arithmetic": "WN convolutions (forward, backward-data): fp32 operands as 3 bf16 planes, 6 "
-                                               "products per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; everything "
-                                               "else as in `value`"}
+                                 "arithmetic": "WN convolutions (forward, backward-data, weight gradient): fp32 operands as 3 "
+                                               "bf16 planes, 6 products per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; "
+                                               "everything else as in `value`"}
             log(f"split-math leg: {out['split_math']['ms_per_step']:.2f} ms/step")
         except Exception as exc:                    # the extra leg must never cost the run its native result
             log(f"split-math leg failed ({type(exc).__name__}: {exc}); reported as null")

@@ -28,21 +28,31 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-// planes 0 .. NS-2 truncate (so the remainder is exact), the last plane rounds to nearest-even (exact when NS == 3)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Two values at a time: plane pl of (a, b) as one packed word (a in the low half) — v_cvt_pk_bf16_f32 (round to nearest
+// even) for the plane, then the remainder v - plane, which is exact: each plane takes the top 8 significand bits of what
+// is left, so three planes hold all 24 and h + m + l == v (checked bit for bit in tests/test_conv_math.py).
 template <int NS>
-__device__ __forceinline__ void split_planes(float v, unsigned (&o)[NS]) {
-    float r = v;
+__device__ __forceinline__ void split_planes2(float a, float b, unsigned (&o)[NS]) {
 #pragma unroll
     for (int pl = 0; pl < NS; ++pl) {
-        const unsigned b = __float_as_uint(r);
-        if (pl == NS - 1) {
-            o[pl] = (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
-        } else {
-            const unsigned hb = b & 0xffff0000u;
-            o[pl] = hb >> 16;
-            r = r - __uint_as_float(hb);
+        const f32x2 v = {a, b};
+        const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        o[pl] = w;
+        if (pl + 1 < NS) {
+            a = a - __uint_as_float(w << 16);
+            b = b - __uint_as_float(w & 0xffff0000u);
         }
     }
+}
+
+template <int NS>
+__device__ __forceinline__ void split_planes(float v, unsigned (&o)[NS]) {      // one value: bf16 pattern in the low half
+    split_planes2<NS>(v, 0.f, o);
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl) o[pl] &= 0xffffu;
 }
 
 __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restrict__ w, unsigned short *__restrict__ planes,
@@ -191,11 +201,14 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
                     if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
                     unsigned short *d = Xh + dbase + (gi * XC + 32 * jq) * RP;
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
+                    for (int f = 0; f < 4; f += 2) {
                         unsigned o[NS];
-                        split_planes<NS>(v[f], o);
+                        split_planes2<NS>(v[f], v[f + 1], o);
 #pragma unroll
-                        for (int pl = 0; pl < NS; ++pl) d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
+                        for (int pl = 0; pl < NS; ++pl) {
+                            d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
+                            d[pl * PLANE16 + (f + 1) * RP] = (unsigned short)(o[pl] >> 16);
+                        }
                     }
                 }
     };
@@ -439,16 +452,12 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
             if (idx < X4) {
                 f32x4 v = xreg[i];
                 if (p.mask_x) v *= *reinterpret_cast<const f32x4 *>(Mx + q * 4);
-                unsigned o[4][NS];
+                unsigned o01[NS], o23[NS];
+                split_planes2<NS>(v[0], v[1], o01);
+                split_planes2<NS>(v[2], v[3], o23);
 #pragma unroll
-                for (int f = 0; f < 4; ++f) split_planes<NS>(v[f], o[f]);
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl) {
-                    i32x2 w;
-                    w[0] = (int)(o[0][pl] | (o[1][pl] << 16));
-                    w[1] = (int)(o[2][pl] | (o[3][pl] << 16));
-                    *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = w;
-                }
+                for (int pl = 0; pl < NS; ++pl)
+                    *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
             }
         }
 #pragma unroll
@@ -459,16 +468,12 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                 f32x4 v = dreg[i];
                 if (p.mask) v *= *reinterpret_cast<const f32x4 *>(Md + q * 4);
                 if (do_bias) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
-                unsigned o[4][NS];
+                unsigned o01[NS], o23[NS];
+                split_planes2<NS>(v[0], v[1], o01);
+                split_planes2<NS>(v[2], v[3], o23);
 #pragma unroll
-                for (int f = 0; f < 4; ++f) split_planes<NS>(v[f], o[f]);
-#pragma unroll
-                for (int pl = 0; pl < NS; ++pl) {
-                    i32x2 w;
-                    w[0] = (int)(o[0][pl] | (o[1][pl] << 16));
-                    w[1] = (int)(o[2][pl] | (o[3][pl] << 16));
-                    *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = w;
-                }
+                for (int pl = 0; pl < NS; ++pl)
+                    *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
             }
         }
     };
