@@ -130,6 +130,8 @@ def conv_math(mode=None) -> int:
     if mode is not None:
         if isinstance(mode, str):            # "bf16x6" or "bf16x6+wrw" (the weight-gradient kernel as well)
             base, _, wrw = mode.partition("+")
+            if base not in CONV_MATH_MODES or wrw not in ("", "wrw"):
+                raise ValueError(f"conv math mode {mode!r}: expected one of {sorted(CONV_MATH_MODES)}, optionally with '+wrw'")
             code = CONV_MATH_MODES[base] * (5 if wrw == "wrw" else 1)
         else:
             code = int(mode)

@@ -318,3 +318,20 @@ def test_default_bucket_keys_cut_the_encoder_per_ffn_layer():
     assert keys[:9] == ["enc.head", "enc.attn"] + [f"enc.ffn{i}" for i in range(6)] + ["enc.tail"]
     assert keys[9:] == [f"dec{i:03d}" for i in range(12)]
     assert sum(n for _, n in runs) == sum(p.numel() for p in model.parameters())
+
+
+def test_conv_math_mode_names():
+    """The arithmetic switch is host state of the library: selectable (and rejected when misspelt) without a GPU."""
+    from glow_tts_train import _hip
+
+    before = _hip.conv_math(None)
+    try:
+        assert _hip.conv_math("bf16x6+wrw") == before and _hip.conv_math(None) == 3 + 4 * 3
+        assert _hip.conv_math("bf16") == 15 and _hip.conv_math(None) == 1
+        with pytest.raises(ValueError, match="bf16x6"):
+            _hip.conv_math("bf16x9")
+        with pytest.raises(ValueError):
+            _hip.conv_math("bf16x6+all")
+        assert _hip.conv_math("fp32") == 1 and _hip.conv_math(None) == 0
+    finally:
+        _hip.conv_math(before)
