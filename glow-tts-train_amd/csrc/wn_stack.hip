@@ -69,7 +69,7 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
                               const float *acts, const float *ts, const float *mask, const unsigned char *drop,
                               float drop_scale, const float *dskip, float *d_rs, float *d_xin, float *dx,
                               const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
-                              int H, int T, int taps, int dil_rate, glowtts_stream_t wgrad_stream,
+                              int H, int T, int taps, int dil_rate, int two_source, glowtts_stream_t wgrad_stream,
                               glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(layers && x && acts && ts && mask && dskip && d_rs && d_xin && dx, "glowtts_wn_bwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_bwd: bad layer count / missing xs");
@@ -81,6 +81,45 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
     for (int i = 1; i < n_layers; ++i) dil *= dil_rate;
     const float *dsk = dskip;
     WN_TRY(order_after(ms, ws));                                    // accumulators were cleared on the main stream
+    if (two_source) {
+        // The launch sequence of convops.WNFn._backward_layers in its two-source form, layer by layer: d_rs = [dx_{i+1} mask ;
+        // dskip] is never written (gate_bwd and wrw2 read its halves from the two tensors), each weight-gradient kernel goes to
+        // the second stream as soon as its operands exist, and only d_xin / dx live per layer.  d_rs needs B*H*T floats (the
+        // last layer's masked dskip).
+        GLOWTTS_CHECK_ARG(dil_rate == 1 && H % 192 == 0 && T % 4 == 0, "glowtts_wn_bwd: two-source form needs dilation 1, H %% 192 == 0, T %% 4 == 0");
+        const int pad = (taps - 1) / 2;
+        for (int i = n_layers - 1; i >= 0; --i) {
+            const glowtts_wn_layer &L = layers[i];
+            const bool last = i == n_layers - 1;
+            const float *x_i = i == 0 ? x : xs + (long)(i - 1) * BHT;
+            const float *acts_i = acts + (long)i * BHT, *ts_i = ts + (long)i * 2 * BHT;
+            const unsigned char *drop_i = drop ? drop + (long)i * 2 * BHT : nullptr;
+            float *dxin_i = d_xin + (long)i * 2 * BHT, *dx_i = dx + (long)i * BHT;
+            const float *half = last ? nullptr : dx + (long)(i + 1) * BHT;       // left the layer above already masked
+            if (last) {
+                WN_TRY(glowtts_res_skip_bwd(nullptr, dskip, mask, nullptr, d_rs, B, H, T, 1, stream));
+                dsk = d_rs;
+                WN_TRY(order_after(ms, ws));
+                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, d_rs, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
+                                        1, 0, (glowtts_stream_t)ws));
+                WN_TRY(glowtts_conv_gate_bwd(d_rs, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, H, H, T, stream));
+            } else {
+                WN_TRY(order_after(ms, ws));
+                WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dsk, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
+                                         T, 1, 1, 0, (glowtts_stream_t)ws));
+                WN_TRY(glowtts_conv_gate_bwd(half, dsk, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, 2 * H, H, T, stream));
+            }
+            WN_TRY(order_after(ms, ws));
+            WN_TRY(glowtts_conv_wrw(x_i, (long)H * T, dxin_i, (long)2 * H * T, nullptr, nullptr, L.dwp_in, L.db_in, B, H, 2 * H, T,
+                                    taps, 1, pad, (glowtts_stream_t)ws));
+            // dx_i = (residual path) dx_{i+1} + (conv path) W_in^T (*) d_xin, masked unless it is the stack's own input gradient
+            WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, i > 0 ? mask : nullptr, half, (long)H * T, dx_i,
+                                    (long)H * T, B, 2 * H, H, T, taps, 1, (taps - 1) - pad, 0, i > 0 ? 1 : 0, 0, stream));
+        }
+        if (unpack_desc)
+            WN_TRY(glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows, (glowtts_stream_t)ws));
+        return 0;
+    }
     for (int i = n_layers - 1; i >= 0; --i, dil /= dil_rate) {
         const glowtts_wn_layer &L = layers[i];
         const bool last = i == n_layers - 1;

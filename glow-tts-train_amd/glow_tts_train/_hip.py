@@ -68,7 +68,7 @@ _SIGNATURES = {
     "glowtts_adam_advance": [_P, _F, _F, _F],
     # whole WN stack per call (csrc/wn_stack.hip); the first argument is a HOST array of WnLayer
     "glowtts_wn_fwd": [_P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I],
-    "glowtts_wn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "glowtts_wn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 
 

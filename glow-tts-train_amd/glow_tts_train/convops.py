@@ -411,8 +411,10 @@ class WNPackPlan:
         call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
 
 
-# WN stack executor: "fwd" (default) = native forward (csrc/wn_stack.hip), layer-by-layer backward; "both"; "off"
-_WN_NATIVE = __import__("os").environ.get("GLOWTTS_WN_NATIVE", "fwd")
+# WN stack executor (csrc/wn_stack.hip queues a stack's whole launch sequence from C): "both" (default) = forward and
+# backward; "fwd" = native forward, backward driven layer by layer from Python; "off".  The step's host time matters: with
+# ~1 000 launches it is within 20 % of the GPU time, and past it on a slower host or with the faster bf16-plane kernels.
+_WN_NATIVE = os.environ.get("GLOWTTS_WN_NATIVE", "both")
 
 _active_groups: List = []
 
@@ -711,27 +713,31 @@ class WNFn(Function):
         dev = dout.device
         sink = _GradSink(params)
         if not sink.direct or _WN_NATIVE != "both":
-            # Default: the backward is driven layer by layer from here.  The native backward (GLOWTTS_WN_NATIVE=both) saves
-            # 3.5 ms of host time per step but measured 0.5-1.1 ms SLOWER on the GPU at config 2: it needs per-layer
-            # workspaces for the whole stack at once (200 MB per block), which falls out of the 256 MB Infinity Cache that
-            # the layer-by-layer path's recycled buffers stay in.  Also taken when gradients do not exist yet.
+            # The backward driven layer by layer from here (GLOWTTS_WN_NATIVE=fwd, or gradients that do not exist yet).  The
+            # native backward issues the same launch sequence from C and saves ~3.5 ms of host time per step.  (Its first
+            # form deferred a block's weight gradients behind its whole dx chain and materialised d_rs: 200 MB of workspace
+            # per block fell out of the 256 MB Infinity Cache and cost 0.5-1.1 ms of GPU time; the two-source, per-layer
+            # form matches this path's GPU time.)
             ctx.native = False
             saved = _wn_layers_from_slabs(x, xs, acts, ts, n_layers)
             return WNFn._backward_layers(ctx, dout, m2, saved, [None] * n_layers if drop_all is None else list(drop_all))
         taps = params[0].shape[2]
         dskip = dout.contiguous()
-        d_rs = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.float32)
+        wgrad = _WgradStream(dev)
+        # two-source form (the launch sequence of _backward_layers): no d_rs tensor, weight gradients interleaved per layer
+        two_src = wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
+        d_rs = torch.empty((B, H, T) if two_src else (n_layers, B, 2 * H, T), device=dev, dtype=torch.float32)
         d_xin = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.float32)
         dx = torch.empty(n_layers, B, H, T, device=dev, dtype=torch.float32)
         plan.dwp.zero_()
         tab = plan.layer_table(params, n_layers)
         gdesc, prefix = plan.unpack_tables(params)
-        wgrad = _WgradStream(dev)
         call("glowtts_wn_bwd", ctypes.addressof(tab), n_layers, ptr(x), ptr(xs), ptr(acts), ptr(ts), ptr(m2), ptr(drop_all),
              1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, ptr(dskip), ptr(d_rs), ptr(d_xin), ptr(dx), ptr(gdesc), ptr(prefix),
-             len(plan.convs), plan.total_rows, B, H, T, taps, dil_rate, wgrad.side.cuda_stream if wgrad.enabled else None)
+             len(plan.convs), plan.total_rows, B, H, T, taps, dil_rate, int(two_src),
+             wgrad.side.cuda_stream if wgrad.enabled else None)
         if wgrad.enabled:
-            for t in (x, xs, acts, d_rs, d_xin):        # read by the weight-gradient stream after this call returns
+            for t in (x, xs, acts, d_rs, d_xin, dx, dskip):   # read by the weight-gradient stream after this call returns
                 if t is not None:
                     t.record_stream(wgrad.side)
             with torch.cuda.stream(wgrad.side):         # listeners (the DP reducer) must wait on the stream that un-packs

@@ -233,8 +233,8 @@ int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x,
 int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *xs, const float *acts,
                    const float *ts, const float *mask, const unsigned char *drop, float drop_scale, const float *dskip,
                    float *d_rs, float *d_xin, float *dx, const long long *unpack_desc, const int *unpack_prefix,
-                   int n_conv, int total_rows, int B, int H, int T, int taps, int dil_rate, glowtts_stream_t wgrad_stream,
-                   glowtts_stream_t stream);
+                   int n_conv, int total_rows, int B, int H, int T, int taps, int dil_rate, int two_source,
+                   glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 
 /* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
  * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)

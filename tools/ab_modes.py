@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two arithmetic modes of the WN convolutions in ONE process (boxes differ by several percent): alternating blocks
-of training steps.  Usage: python tools/ab_modes.py MODE_A MODE_B [steps_per_block] [blocks]   (modes: glowtts_conv_math)"""
+of training steps.  Usage: python tools/ab_modes.py MODE_A MODE_B [steps_per_block] [blocks]
+(modes: glowtts_conv_math names, optionally "@both" / "@off" for the native WN executor setting)"""
 import os
 import sys
 import time
@@ -24,7 +25,9 @@ for _ in range(8):
 res = {m: [] for m in modes}
 for blk in range(2 * blocks):
     mode = modes[blk % 2]
-    convops.set_conv_math(mode)
+    math, _, executor = mode.partition("@")        # "bf16x6+wrw@both": arithmetic @ WN executor (fwd = default, both, off)
+    convops.set_conv_math(math)
+    convops._WN_NATIVE = executor or "fwd"
     for _ in range(3):
         train_batch(model, opt, batch, cfg.grad_clip, None)
     torch.cuda.synchronize()
@@ -34,4 +37,4 @@ for blk in range(2 * blocks):
     torch.cuda.synchronize()
     res[mode].append(1e3 * (time.perf_counter() - t0) / n)
 for mode in modes:
-    print(f"{mode:12s}: " + "  ".join(f"{v:.2f}" for v in res[mode]) + f"   mean {sum(res[mode]) / len(res[mode]):.2f} ms/step")
+    print(f"{mode:18s}: " + "  ".join(f"{v:.2f}" for v in res[mode]) + f"   mean {sum(res[mode]) / len(res[mode]):.2f} ms/step")
