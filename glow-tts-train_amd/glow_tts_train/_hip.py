@@ -119,6 +119,13 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def direct_apply(cls):
+    """`cls.apply` without the Python wrapper of torch.autograd.Function.apply (default-argument binding for setup_context
+    and functorch unwrapping, neither used by these operators): the engine's own entry point, ~4 us less per call on a path
+    that makes ~130 such calls per step and is within 20 % of being host-bound."""
+    return super(torch.autograd.Function, cls).apply
+
+
 CONV_MATH_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
 
 

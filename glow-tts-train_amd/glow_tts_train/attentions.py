@@ -11,7 +11,11 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import convops, ops
+from ._hip import direct_apply
 from .layers import WN, LayerNorm
+
+_coupling_apply = direct_apply(ops.CouplingFn)
+_rel_attn_apply = direct_apply(ops.RelAttnFn)
 
 
 class Encoder(nn.Module):
@@ -80,7 +84,7 @@ class CouplingBlock(nn.Module):
         out = convops.conv1d(self.end, h, m2)
         if reverse:
             return ops.coupling_reverse(x, out, m2, self.sigmoid_scale), None
-        return ops.CouplingFn.apply(x, out, m2, self.sigmoid_scale, link)
+        return _coupling_apply(x, out, m2, self.sigmoid_scale, link)
 
     def store_inverse(self):
         self.wn.remove_weight_norm()
@@ -140,7 +144,7 @@ class MultiHeadAttention(nn.Module):
             p_drop = float(self.p_dropout) if self.training else 0.0
             ek = self.emb_rel_k if self.window_size is not None else None
             ev = self.emb_rel_v if self.window_size is not None else None
-            return ops.RelAttnFn.apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
+            return _rel_attn_apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
                                        self.block_length, p_drop)
         return self._attention_general(query, key, value, mask)
 

@@ -238,6 +238,9 @@ class Conv1dFn(Function):
         return dx, dv, dg, db, None, None, None, None, None, None, None
 
 
+_conv1d_apply = _hip.direct_apply(Conv1dFn)
+
+
 def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = None, mask_in: bool = False,
            mask_out: bool = False, link=None) -> torch.Tensor:
     """Run an nn.Conv1d (optionally weight-normed, 'same' padding) through the MFMA kernels."""
@@ -250,7 +253,7 @@ def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = 
         group = None
     if group is not None and torch.is_grad_enabled() and (v.requires_grad or x.requires_grad):
         group.pending += 1                               # one backward call to wait for before the group un-packs
-    return Conv1dFn.apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0], group, gidx, link)
+    return _conv1d_apply(x, v, g, conv.bias, m2, mask_in, mask_out, conv.dilation[0], group, gidx, link)
 
 
 class ChanLayerNormFn(Function):

@@ -14,6 +14,10 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import convops, ops
+from ._hip import direct_apply
+
+_chan_ln_apply = direct_apply(convops.ChanLayerNormFn)
+_wn_apply = direct_apply(convops.WNFn)
 
 
 def _ones_mask(x: torch.Tensor) -> torch.Tensor:
@@ -32,7 +36,7 @@ class LayerNorm(nn.Module):
     def forward(self, x, res=None):
         """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in)."""
         if x.dim() == 3:
-            return convops.ChanLayerNormFn.apply(x, res, self.gamma, self.beta, self.eps)
+            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps)
         # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
         v = x if res is None else x + res
         return F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
@@ -116,7 +120,7 @@ class WN(nn.Module):
         if not hasattr(self, "_pack_plan"):
             self._pack_plan = convops.WNPackPlan(want_planes=True)
         drop_pre, self._drop_pre = getattr(self, "_drop_pre", None), None     # keep-masks drawn ahead by FlowSpecDecoder
-        return convops.WNFn.apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, drop_pre, *flat)
+        return _wn_apply(x, m2, cond, p_drop, self.dilation_rate, self.n_layers, self._pack_plan, drop_pre, *flat)
 
     def remove_weight_norm(self):
         if self.gin_channels != 0:

@@ -19,6 +19,8 @@ from .layers import ActNorm, ConvReluNorm, InvConvNear, LayerNorm
 from .optimize import OptimizerType
 from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 
+_actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
+
 _LOGGER = logging.getLogger("glow_tts_train.models")
 
 
@@ -147,7 +149,7 @@ class FlowSpecDecoder(nn.Module):
                 if (isinstance(f, ActNorm) and f.initialized and isinstance(nxt, InvConvNear) and not nxt.no_jacobian
                         and nxt.n_split in (2, 4)):
                     # the two elementwise flows of a block in one pass over the tensor (ops.ActNormInvConvFn)
-                    x, logdet = ops.ActNormInvConvFn.apply(x, m2, f.logs, f.bias, nxt.weight, x_len, nxt.n_split)
+                    x, logdet = _actnorm_invconv_apply(x, m2, f.logs, f.bias, nxt.weight, x_len, nxt.n_split)
                     i += 2
                 else:
                     x, logdet = f(x, x_mask, g=g, reverse=False, x_len=x_len)
