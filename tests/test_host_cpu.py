@@ -335,3 +335,23 @@ def test_conv_math_mode_names():
         assert _hip.conv_math("fp32") == 1 and _hip.conv_math(None) == 0
     finally:
         _hip.conv_math(before)
+
+
+def test_fastcall_binding_matches_the_ctypes_table():
+    """`_glowtts_fastcall` (generated by csrc/gen_fastcall.py, built by `make`) wraps exactly the entry points of
+    `_hip._SIGNATURES`, is bound to the addresses of the library ctypes opened, validates its arguments, and `call()` uses
+    it; GLOWTTS_FASTCALL=0 or a missing module falls back to ctypes (a binding, never a compute path)."""
+    from glow_tts_train import _hip
+
+    lib = _hip.load()
+    assert _hip.FASTCALL, "run __graft_entry__.build() (make builds lib/_glowtts_fastcall*.so)"
+    assert sorted(_hip._fn_cache) == sorted(_hip._SIGNATURES)
+    fast = _hip._fn_cache["glowtts_actnorm_fwd"]
+    args = (1, 1, 1, 1, None, 1, None, 0, 4, 0, 0, None)                    # empty batch: validated, nothing launched
+    assert fast(*args) == lib.glowtts_actnorm_fwd(*args) == 0
+    assert fast(1, 1, 1, 1, None, 1, None, np.int64(0), True, 0, 0, None) == 0     # anything with __index__ is an int
+    assert _hip._fn_cache["glowtts_mas_path"](1, 1, 1, 1, 1, 600, 10, None) != 0 and b"512" in lib.glowtts_last_error()
+    with pytest.raises(TypeError):
+        fast(1, 1, 1, 1, None, 1, None, "0", 4, 0, 0, None)
+    with pytest.raises(TypeError, match="expected 12"):
+        fast(1, 2)
