@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-split-math", action="store_true",
                     help="skip the extra leg that times the same step with the WN convolutions in bf16x6 split arithmetic")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="N=1 rehearsal: open a one-rank RCCL group and run the DP reducer's real launch path (buckets "
+                         "all-reduced from the comm stream during backward); reported under `comm`, for inspection only")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (GraphedTrainStep); default is eager launches — the step is "
                          "GPU-bound, so replay buys <1 %% at this shape")
@@ -107,6 +110,55 @@ def pmc_traffic(kernel_tag):
         return table[kernel_tag]["traffic_bytes"]
     except Exception:
         return None
+
+
+def decoder_alone(model, batch, cfg, n_iter=5):
+    """SURVEY.md 8(d) secondary metric and headline (ii): FlowSpecDecoder forward + backward alone, one stream (outside a
+    training step's scope nothing is put on side streams), HIP events on that stream around each half, median of
+    `n_iter`.  frac = max(bytes_alg / 8 TB/s, flops_alg / 157.3 TFLOP/s) / t with SURVEY's per-column figures:
+    bytes fwd = (6.5 C + 28 H) e per squeezed column per block, FLOPs fwd = 2(C/2)H + L 2H 2H k + (L-1) 2H 2H + 2HH + 2HC,
+    both x3 for fwd + bwd."""
+    _, _, y, y_lengths, speaker_ids = batch
+    mc = cfg.model
+    g = None
+    if speaker_ids is not None:
+        with torch.no_grad():
+            g = torch.nn.functional.normalize(model.emb_g(speaker_ids)).unsqueeze(-1)
+    B, _, T = y.shape
+    z_mask = torch.ones(B, 1, T, device=y.device)
+    r = torch.randn_like(y)
+    cur = torch.cuda.current_stream()
+    fwd, bwd = [], []
+    for _ in range(n_iter + 1):
+        yy = y.clone().requires_grad_(True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(cur)
+        z, logdet = model.decoder(yy, z_mask, g=g, reverse=False)
+        e1.record(cur)
+        loss = (z * r).sum() + logdet.sum()
+        e1b = torch.cuda.Event(enable_timing=True)
+        e1b.record(cur)
+        loss.backward()
+        from glow_tts_train.convops import flush_groups
+        flush_groups()
+        e2.record(cur)
+        torch.cuda.synchronize()
+        fwd.append(e0.elapsed_time(e1))
+        bwd.append(e1b.elapsed_time(e2))
+    fwd, bwd = sorted(fwd[1:]), sorted(bwd[1:])
+    f_ms, b_ms = fwd[len(fwd) // 2], bwd[len(bwd) // 2]
+    C, H = cfg.audio.mel_channels * mc.n_sqz, (mc.hidden_channels_dec or mc.hidden_channels)
+    L, k, nb = mc.n_block_layers, mc.kernel_size_dec, mc.n_blocks_dec
+    N = B * (T // mc.n_sqz)
+    alg_bytes = 3 * (6.5 * C + 28 * H) * 4 * N * nb
+    alg_flops = 3 * (2 * (C // 2) * H + L * 2 * H * 2 * H * k + (L - 1) * 2 * H * 2 * H + 2 * H * H + 2 * H * C) * N * nb
+    t_roof_ms = 1e3 * max(alg_bytes / (HBM_PEAK_GBS * 1e9), alg_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12))
+    t = f_ms + b_ms
+    return {"fwd_ms": round(f_ms, 3), "bwd_ms": round(b_ms, 3), "fwd_bwd_ms": round(t, 3),
+            "alg_GB": round(alg_bytes / 1e9, 3), "alg_TFLOP": round(alg_flops / 1e12, 4),
+            "bound": "mfma (fp32)" if alg_flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) > alg_bytes / (HBM_PEAK_GBS * 1e9) else "hbm",
+            "roof_ms": round(t_roof_ms, 3), "frac": round(t_roof_ms / t, 4),
+            "mel_frames_per_s_decoder_only": round(B * T / (t * 1e-3))}
 
 
 _T0 = time.perf_counter()
@@ -196,6 +248,11 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=backend, init_method="env://")
+    elif args.rccl_self:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=backend, rank=0, world_size=1)
 
     from glow_tts_train import _hip, parallel
     from glow_tts_train.train import GraphedTrainStep, train_batch
@@ -205,7 +262,7 @@ def main():
     B, T_mel = args.batch, args.t_mel
     T_text = args.t_text or T_mel // 5
     x, x_lengths, y, y_lengths, _ = batch
-    reducer = parallel.FlowBlockReducer(model, opt) if world > 1 else None
+    reducer = parallel.FlowBlockReducer(model, opt, force=args.rccl_self, measure=True) if (world > 1 or args.rccl_self) else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
@@ -245,6 +302,19 @@ def main():
         dt = float(tt)
     loss_val = float(loss)
     log(f"timed region: {args.steps} steps in {dt:.3f} s, loss {loss_val:.4f}")
+    comm = None
+    if reducer is not None:
+        # time the compute stream spent in reducer.finish() waiting for collectives backward did not hide (HIP events on
+        # the compute stream), the timed steps only; max over ranks like the step time
+        exposed = reducer.exposed_comm_ms()[-args.steps:]
+        ex = torch.tensor([sum(exposed) / max(1, len(exposed))], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        comm = {"backend": reducer.backend + (" (RCCL)" if reducer.backend == "nccl" else ""),
+                "rccl_ranks": dist.get_world_size() if reducer.backend == "nccl" else 0,
+                "buckets": len(reducer.buckets), "buckets_launched_during_backward": reducer.launched_in_backward,
+                "grad_MB_per_step": round(4e-6 * sum(b.hi - b.lo for b in reducer.buckets), 1),
+                "exposed_comm_ms_per_step": round(float(ex), 3)}
     frames = world * B * T_mel * args.steps
     ms_per_step = 1e3 * dt / args.steps
 
@@ -261,6 +331,8 @@ def main():
                                + "random-init weights, synthetic resident batch",
                    "global_batch": world * B, "parallelism": f"dp{world}", "launch": mode, "final_loss": loss_val},
     }
+    if comm is not None:
+        out["comm"] = comm
 
     # ---- extra leg (not `value`): the same step with the WN convolutions' fp32 operands split into bf16 planes and the
     # six products above 2^-24 formed on the bf16 matrix pipe ("bf16x6", csrc/convgemm_split.hip): fp32-equivalent results
@@ -296,6 +368,8 @@ def main():
             convops.set_conv_math(previous)         # the roofline pass below measures the native kernels
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
+    if reducer is not None:
+        reducer.remove_hooks()                           # the legs below run rank-local steps without collectives
     if rank == 0 and not args.no_roofline:
         import re
 
@@ -309,6 +383,8 @@ def main():
             train_batch(model, opt, batch, cfg.grad_clip, None)
         times = _hip.disable_timing()
         log("instrumented pass done")
+        dec = decoder_alone(model, batch, cfg, n_iter=5)
+        log(f"decoder alone: fwd {dec['fwd_ms']:.2f} ms, bwd {dec['bwd_ms']:.2f} ms")
         hbm, mfma, other = {}, {}, {}
         for name, ms in times.items():
             mean_ms = sum(ms) / len(ms)
@@ -342,6 +418,7 @@ def main():
             "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
                                   "TFLOPs": round(conv_flop / conv_ms, 2) if conv_ms else None,
                                   "frac": round(conv_flop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None},
+            # leads with the bytes the fused kernels actually have to move (`frac`); SURVEY's un-fused numerator second
             "invertible_subset": {"ms_per_step": round(sub_ms, 3), "alg_GB": round(sub_bytes / 1e9, 3),
                                   "GBps": round(sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,
                                   "frac": round(sub_bytes / (sub_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sub_ms else None,
@@ -350,6 +427,7 @@ def main():
                                   "survey_alg_GB": round(survey_gb, 3),
                                   "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None},
             "step_ms": round(ms_per_step, 3),
+            "decoder": dec,
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "hbm_kernels": dict(sorted(hbm.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "other_kernels": dict(sorted(other.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
@@ -379,7 +457,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

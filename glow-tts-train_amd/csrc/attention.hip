@@ -516,13 +516,8 @@ static int attn_launch(AttnParams &p, hipStream_t s) {
     p.TP = ((p.T + 15) / 16) * 16 + 4;
     const size_t lds = attn_lds(p.dk, p.TP);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_rel_attn: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>), lds, "glowtts_rel_attn")) return rc_;
     dim3 grid((p.T + 63) / 64, p.H, p.B);
     hipLaunchKernelGGL((attn_qblock_kernel<MODE>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
@@ -568,26 +563,16 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
     d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
     const size_t lds = ((size_t)2 * dk * kBP + (size_t)2 * 64 * kAP) * sizeof(float);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_dkv_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel), lds, "glowtts_rel_attn_bwd")) return rc_;
     hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
     if (emb_k) {
         const int nr = 2 * window + 1;
         int DC = (256 / nr) & ~7;                      // one (r, d) output per thread, slab rows a multiple of 8
         if (DC > dk) DC = dk;
         const size_t lds_r = ((size_t)2 * nr * T + (size_t)2 * DC * (T + 1)) * sizeof(float);
-        static size_t attr_max_r = 0;
-        if (lds_r > attr_max_r) {
-            hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_relgrad_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-            if (er != hipSuccess) { set_error("glowtts_rel_attn_bwd: LDS attribute: %s", hipGetErrorString(er)); return (int)er; }
-            attr_max_r = lds_r;
-        }
+        static LdsLimit attr_max_r;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_r.ensure(reinterpret_cast<const void *>(&attn_relgrad_kernel), lds_r, "glowtts_rel_attn_bwd")) return rc_;
         hipLaunchKernelGGL(attn_relgrad_kernel, dim3(B * H, (dk + DC - 1) / DC), dim3(256), lds_r, s, p_attn, ds, drop,
                            drop_scale, dout, q, demb_k, demb_v, H, T, dk, window, p.e_hs, DC);
     }

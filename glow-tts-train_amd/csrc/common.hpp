@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <initializer_list>
 
 #include "glowtts_hip.h"
@@ -85,6 +86,30 @@ static inline bool can_vec4(int T, std::initializer_list<const void *> ptrs) {
         if (p && !aligned16(p)) return false;
     return true;
 }
+
+// Dynamic-LDS limit of one kernel (`static LdsLimit x;` at the launch site): hipFuncSetAttribute is per DEVICE, so the
+// high-water mark is kept per device — a process that drives a second GPU sets the attribute there too — and is monotone
+// under concurrent callers (autograd runs one backward thread per device).
+constexpr int kMaxDevices = 16;
+struct LdsLimit {
+    std::atomic<size_t> seen[kMaxDevices];
+    int ensure(const void *kernel, size_t bytes, const char *who) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const bool tracked = dev >= 0 && dev < kMaxDevices;
+        if (tracked && bytes <= seen[dev].load(std::memory_order_acquire)) return 0;
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) {
+            set_error("%s: cannot reserve %zu B of dynamic LDS: %s", who, bytes, hipGetErrorString(e));
+            return (int)e;
+        }
+        if (tracked) {
+            size_t cur = seen[dev].load(std::memory_order_relaxed);
+            while (cur < bytes && !seen[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+        }
+        return 0;
+    }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

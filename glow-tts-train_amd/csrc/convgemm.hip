@@ -832,13 +832,8 @@ static int launch_convgemm(ConvGemmParams &p, hipStream_t s) {
     p.xp_pitch = pitch16(NT + (p.taps - 1) * p.dil);
     const size_t lds = ((size_t)p.taps * 16 * (WGR + 16) + (size_t)16 * p.xp_pitch) * sizeof(float);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_conv: %d taps x dilation %d needs %zu B of LDS", p.taps, p.dil, lds);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_kernel<RTW, NCT, EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_kernel<RTW, NCT, EPI>), lds, "glowtts_conv")) return rc_;
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
@@ -856,13 +851,8 @@ static int launch_convgemm_wd(ConvGemmParams &p, hipStream_t s) {
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
-    static size_t attr_max_e = 0;
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_wd_kernel<RTW, NCT, EPI, TAPS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_wd_kernel<RTW, NCT, EPI, TAPS>), lds, "glowtts_conv")) return rc_;
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
@@ -912,13 +902,8 @@ static int launch_wrw_fp_mt(ConvWrwParams &p, hipStream_t s) {
     constexpr int CT = 16 * NGRP, MR = 16 * MT;
     constexpr size_t lds = ((size_t)64 * cpitch4(CT + 16) + (size_t)MR * cpitch4(CT) + (CT + 16) + CT) * sizeof(float);
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    static size_t attr_max_e = 0;
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_fp_kernel<TAPS, NGRP, MT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_fp_kernel<TAPS, NGRP, MT>), lds, "glowtts_conv_wrw")) return rc_;
     // all workgroups resident at once (2 per CU: 512 slots); p.nb = chunks of CT frames per workgroup
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
     const int total = p.B * ((p.T + CT - 1) / CT);
@@ -944,13 +929,8 @@ static int launch_wrw_fp(ConvWrwParams &p, hipStream_t s) {
 template <int TAPS, int CT>
 static int launch_wrw_pipe(ConvWrwParams &p, hipStream_t s) {
     constexpr size_t lds = 2 * ((size_t)64 * cpitch2(CT + 16) + (size_t)64 * cpitch2(CT)) * sizeof(float);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_pipe_kernel<TAPS, CT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv_wrw: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_pipe_kernel<TAPS, CT>), lds, "glowtts_conv_wrw")) return rc_;
     // The contraction runs over B * T frames = `total` chunks of CT; it is split so that ALL workgroups are resident at
     // once (2 per CU by LDS, 512 slots): a grid of 576 on 512 slots costs two full rounds.  p.nb = chunks per workgroup.
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + 63) / 64);

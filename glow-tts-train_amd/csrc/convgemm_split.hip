@@ -616,13 +616,8 @@ static int launch_split(ConvGemmParams &p, const unsigned short *planes, long st
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
-    static size_t attr_max_e = 0;
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv (split): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>), lds, "glowtts_conv (split)")) return rc_;
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
@@ -651,13 +646,8 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     constexpr int CT = 16 * NGRP, MR = 16 * MT;
     constexpr size_t lds = (size_t)NS * (64 + MR) * 104 * 2 + (size_t)(CT + 8 + CT + 64) * sizeof(float);
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    static size_t attr_max_e = 0;
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv_wrw (split): LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT>), lds, "glowtts_conv_wrw (split)")) return rc_;
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
     const int total = p.B * ((p.T + CT - 1) / CT);
     int splits = 512 / tiles;                       // all workgroups resident at once (2 per CU)
@@ -673,13 +663,8 @@ template <int NS, int TAPS, int NGRP, int MT>
 static int launch_wrw_planes(ConvWrwParams &p, hipStream_t s) {
     constexpr int CT = 16 * NGRP, MR = 16 * MT;
     constexpr size_t lds = (size_t)NS * (64 + MR) * 104 * 2 + (size_t)(CT + 8 + CT + 64) * sizeof(float);
-    static size_t attr_max_e = 0;
-    if ((size_t)lds > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("glowtts_conv_wrw_planes: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
-        attr_max_e = (size_t)lds;
-    }
+    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_split_kernel<NS, TAPS, NGRP, MT, true>), lds, "glowtts_conv_wrw_planes")) return rc_;
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + MR - 1) / MR);
     const int total = p.B * ((p.T + CT - 1) / CT);
     int splits = 512 / tiles;

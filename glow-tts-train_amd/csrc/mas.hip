@@ -37,13 +37,18 @@ __device__ unsigned long long g_mas_trace[1024 * 8];
 template <int R>
 __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ value, float *__restrict__ path,
                                                   const int *__restrict__ t_xs, const int *__restrict__ t_ys,
-                                                  int Tx, int Ty, int log2tc, int nblk32) {
+                                                  int Tx, int Ty, int log2tc, int nblk32, int gdirs) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROWPAD = R * 64 + 1;
     const int TC = 1 << log2tc;
     float *tile = reinterpret_cast<float *>(smem);                                // [2][TC][ROWPAD]
-    uint32_t *dirs = reinterpret_cast<uint32_t *>(tile + 2 * TC * ROWPAD);        // [R][nblk32][64]
-    int *first = reinterpret_cast<int *>(dirs + R * nblk32 * 64);                 // [Tx + 1]: first frame of every text row
+    uint32_t *dirs = reinterpret_cast<uint32_t *>(tile + 2 * TC * ROWPAD);        // [R][nblk32][64] (LDS form)
+    int *first = reinterpret_cast<int *>(dirs + (gdirs ? 0 : R * nblk32 * 64));   // [Tx + 1]: first frame of every text row
+    // Long lattices (bit image > LDS: e.g. 500 tokens x 4 000 frames): the back-pointer bits go to this utterance's own
+    // slice of the OUTPUT buffer instead — 1 bit per cell fits 32x over in the 4-byte-per-cell path, nobody reads the
+    // path before the kernel ends, and the bits are dead (spans are in `first`) before the first path element is written.
+    // Written and read back by wave 0 only; the read-back is volatile (device-scope load, never a stale L1 line).
+    uint32_t *gd = reinterpret_cast<uint32_t *>(path + (size_t)blockIdx.x * Tx * Ty);
 
     const int b = blockIdx.x;
     int tx = t_xs[b], ty = t_ys[b];
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
                 if ((y & 31) == 31 || y == ty - 1) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        dirs[(r * nblk32 + (y >> 5)) * 64 + lane] = dw[r];
+                        if (gdirs) gd[(r * nblk32 + (y >> 5)) * 64 + lane] = dw[r];
+                        else dirs[(r * nblk32 + (y >> 5)) * 64 + lane] = dw[r];
                         dw[r] = 0u;
                     }
                 }
@@ -181,7 +187,9 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     __syncthreads();
     if (threadIdx.x == 0 && tx > 0 && ty > 0) {
         auto word_of = [&](int row, int blk) -> uint32_t {
-            return row > 0 ? dirs[((row % R) * nblk32 + blk) * 64 + row / R] : 0u;
+            if (row <= 0) return 0u;
+            const int at = ((row % R) * nblk32 + blk) * 64 + row / R;
+            return gdirs ? *reinterpret_cast<volatile uint32_t *>(gd + at) : dirs[at];
         };
         int index = tx - 1, y = ty - 1, blk = y >> 5;
         uint32_t word = word_of(index, blk), below = word_of(index - 1, blk);
@@ -244,25 +252,22 @@ template <int R>
 static int launch_mas(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B, int Tx,
                       int Ty, hipStream_t stream) {
     const int nblk32 = (Ty + 31) / 32;
-    const size_t fixed = (size_t)R * nblk32 * 64 * 4 + (((size_t)(Tx + 1) * 4 + 15) & ~(size_t)15);
     const size_t budget = 150 * 1024;
+    const size_t first_b = (((size_t)(Tx + 1) * 4 + 15) & ~(size_t)15);
+    const size_t dirs_b = (size_t)R * nblk32 * 64 * 4;
+    auto tile_b = [](int l2) { return (size_t)2 * (1 << l2) * (R * 64 + 1) * 4; };
+    // back-pointer bits in LDS when they leave room for at least 16-column tiles, else in the output buffer (see kernel)
+    const int gdirs = (dirs_b + first_b + tile_b(4) > budget) ? 1 : 0;
+    const size_t fixed = first_b + (gdirs ? 0 : dirs_b);
     int log2tc = 6;
-    while (log2tc > 3 && fixed + (size_t)2 * (1 << log2tc) * (R * 64 + 1) * 4 > budget) --log2tc;
-    const size_t bytes = fixed + (size_t)2 * (1 << log2tc) * (R * 64 + 1) * 4;
+    while (log2tc > 3 && fixed + tile_b(log2tc) > budget) --log2tc;
+    const size_t bytes = fixed + tile_b(log2tc);
     GLOWTTS_CHECK_ARG(bytes <= 160 * 1024, "glowtts_mas_path: lattice %dx%d needs %zu B of LDS (> 160 KiB)", Tx, Ty,
                       bytes);
-    static size_t attr_max_e = 0;   // raise the dynamic-LDS limit only when a larger size is needed (not per launch)
-    if ((size_t)bytes > attr_max_e) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mas_kernel<R>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) {
-        set_error("glowtts_mas_path: cannot reserve %zu B LDS: %s", bytes, hipGetErrorString(e));
-        return (int)e;
-    }
-        attr_max_e = (size_t)bytes;
-    }
+    static LdsLimit limit;   // per device: raised only when a launch needs more than any earlier one
+    if (int rc_ = limit.ensure(reinterpret_cast<const void *>(&mas_kernel<R>), bytes, "glowtts_mas_path")) return rc_;
     hipLaunchKernelGGL(mas_kernel<R>, dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
-                       nblk32);
+                       nblk32, gdirs);
     GLOWTTS_LAUNCH_CHECK("glowtts_mas_path");
 }
 
@@ -274,7 +279,7 @@ extern "C" int glowtts_mas_path(const float *value, float *path, const int32_t *
     GLOWTTS_CHECK_ARG(value && path && t_x && t_y, "glowtts_mas_path: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && Tx >= 0 && Ty >= 0, "glowtts_mas_path: negative size");
     if (B == 0 || Tx == 0 || Ty == 0) return 0;
-    GLOWTTS_CHECK_ARG(Tx <= 512, "glowtts_mas_path: Tx=%d exceeds the 512-token limit of this build", Tx);
+    GLOWTTS_CHECK_ARG(Tx <= 2048, "glowtts_mas_path: Tx=%d exceeds the 2048-token limit of this build", Tx);
     GLOWTTS_CHECK_ARG((long)Tx * Ty < (1L << 31), "glowtts_mas_path: lattice too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int r = (Tx + 63) / 64;
@@ -285,8 +290,14 @@ extern "C" int glowtts_mas_path(const float *value, float *path, const int32_t *
         case 4: return launch_mas<4>(value, path, t_x, t_y, B, Tx, Ty, s);
         case 5: return launch_mas<5>(value, path, t_x, t_y, B, Tx, Ty, s);
         case 6: return launch_mas<6>(value, path, t_x, t_y, B, Tx, Ty, s);
-        default: return launch_mas<8>(value, path, t_x, t_y, B, Tx, Ty, s);
+        case 7: case 8: return launch_mas<8>(value, path, t_x, t_y, B, Tx, Ty, s);
+        default: break;
     }
+    // beyond 512 tokens (no realistic utterance; the reference's Cython loop has no limit, so neither fails here)
+    if (r <= 12) return launch_mas<12>(value, path, t_x, t_y, B, Tx, Ty, s);
+    if (r <= 16) return launch_mas<16>(value, path, t_x, t_y, B, Tx, Ty, s);
+    if (r <= 24) return launch_mas<24>(value, path, t_x, t_y, B, Tx, Ty, s);
+    return launch_mas<32>(value, path, t_x, t_y, B, Tx, Ty, s);
 }
 
 #ifdef GLOWTTS_TRACE

@@ -11,18 +11,28 @@
 
 namespace glowtts {
 
+// Ordering events: a ring per (thread, device).  An event belongs to the device that was current when it was created,
+// so a process that drives a second GPU gets a second ring; the cursor is thread-local because autograd issues the
+// backward of each device from its own thread (a shared cursor could hand two threads the same event between its
+// record and its wait).  64 events per ring: an event is re-used long after the wait that consumed it was queued.
 constexpr int kEventPool = 64;
-static hipEvent_t g_events[kEventPool];
-static bool g_events_ready = false;
-static int g_event_next = 0;
+struct EventRing {
+    hipEvent_t ev[kEventPool];
+    bool ready = false;
+    int next = 0;
+};
 
 static hipEvent_t next_event() {
-    if (!g_events_ready) {
-        for (int i = 0; i < kEventPool; ++i) hipEventCreateWithFlags(&g_events[i], hipEventDisableTiming);
-        g_events_ready = true;
+    static thread_local EventRing rings[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    EventRing &r = rings[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    if (!r.ready) {
+        for (int i = 0; i < kEventPool; ++i) hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming);
+        r.ready = true;
     }
-    hipEvent_t e = g_events[g_event_next];
-    g_event_next = (g_event_next + 1) % kEventPool;
+    hipEvent_t e = r.ev[r.next];
+    r.next = (r.next + 1) % kEventPool;
     return e;
 }
 

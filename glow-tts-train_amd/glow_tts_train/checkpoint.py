@@ -46,11 +46,24 @@ def _plain(v):
     return v
 
 
+def _numpy_multiarray():
+    """numpy's multiarray module under whichever name this numpy has (numpy >= 2: `numpy._core`, numpy 1.x: `numpy.core`)."""
+    try:
+        import numpy._core.multiarray as ncm
+    except ImportError:                                    # numpy < 2
+        import numpy.core.multiarray as ncm
+    return ncm
+
+
 def _read(path):
     """`torch.load` restricted to tensors and plain containers, plus the numpy scalar types the reference's own files
-    carry (`learning_rate` and the optimizer's `lr` are numpy float64 there: optimize.py:32-48, checkpoint.py:41)."""
-    import numpy._core.multiarray as ncm
-    allowed = [ncm.scalar, np.dtype] + [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
+    carry (`learning_rate` and the optimizer's `lr` are numpy float64 there: optimize.py:32-48, checkpoint.py:41).
+    A file pickled under numpy 1.x names the reconstructor `numpy.core.multiarray.scalar`, one pickled under numpy >= 2
+    `numpy._core.multiarray.scalar`; both spellings are allow-listed whichever numpy is installed here."""
+    ncm = _numpy_multiarray()
+    allowed = [ncm.scalar, (ncm.scalar, "numpy.core.multiarray.scalar"), (ncm.scalar, "numpy._core.multiarray.scalar"),
+               np.dtype]
+    allowed += [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64, np.int32)]
     with torch.serialization.safe_globals(allowed):
         return torch.load(path, map_location="cpu", weights_only=True)
 

@@ -12,6 +12,7 @@ import os
 from typing import List, Optional
 
 import torch
+import torch.distributed as _dist
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -23,14 +24,27 @@ from ._hip import call, conv_bind_planes, conv_math, f32, ptr, scratch_zeros
 _grad_ready_listeners: List = []
 
 # Operators add weight gradients straight into an existing `.grad` (no autograd add, no AccumulateGrad node).  A wrapper
-# that relies on AccumulateGrad hooks for EVERY parameter — torch's DistributedDataParallel — must switch this off
-# (`set_direct_grads(False)` or GLOWTTS_DIRECT_GRADS=0); `parallel.FlowBlockReducer` listens to `_notify` instead.
-_DIRECT_GRADS = __import__("os").environ.get("GLOWTTS_DIRECT_GRADS", "1") != "0"
+# that relies on AccumulateGrad hooks for EVERY parameter — torch's DistributedDataParallel, which the reference's
+# unchanged `__main__.py:268-271` puts around the model — never sees such a gradient, so the choice is made per step:
+#   * a gradient listener is attached (`parallel.FlowBlockReducer` listens to `_notify`)      -> in place;
+#   * a process group exists and nobody listens (some other wrapper owns the gradients: DDP)  -> through autograd;
+#   * no process group                                                                         -> in place.
+# `set_direct_grads(True|False)` or GLOWTTS_DIRECT_GRADS=1|0 pins the choice; `set_direct_grads(None)` returns to auto.
+_DIRECT_GRADS: Optional[bool] = {"0": False, "1": True}.get(os.environ.get("GLOWTTS_DIRECT_GRADS", ""))
 
 
-def set_direct_grads(enabled: bool) -> None:
+def set_direct_grads(enabled: Optional[bool]) -> None:
     global _DIRECT_GRADS
-    _DIRECT_GRADS = bool(enabled)
+    _DIRECT_GRADS = None if enabled is None else bool(enabled)
+
+
+def direct_grads_enabled() -> bool:
+    """May operators write parameter gradients in place this step?  (see the comment above `_DIRECT_GRADS`)"""
+    if _DIRECT_GRADS is not None:
+        return _DIRECT_GRADS
+    if _grad_ready_listeners:
+        return True
+    return not (_dist.is_available() and _dist.is_initialized())
 
 
 def _mark_direct(params, flag: bool) -> None:
@@ -134,7 +148,7 @@ class _GradSink:
 
     def __init__(self, params):
         self.params = list(params)
-        self.direct = _DIRECT_GRADS and all(
+        self.direct = direct_grads_enabled() and all(
             p is None or (p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32)
             for p in self.params)
         _mark_direct(self.params, self.direct)
@@ -456,7 +470,7 @@ class ConvGroup:
         tensors = [p for p in params if p is not None]
         self.active = all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in tensors)
         if self.active and torch.is_grad_enabled() and any(p.requires_grad for p in tensors):
-            self.active = _DIRECT_GRADS and all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
+            self.active = direct_grads_enabled() and all((not p.requires_grad) or (p.grad is not None and p.grad.is_contiguous()
                                                         and p.grad.dtype == torch.float32) for p in tensors)
         _mark_direct(tensors, self.active and torch.is_grad_enabled())
         if not self.active:

@@ -9,6 +9,7 @@ restructured for MI355X: every parameter, gradient and moment lives in ONE flat 
 from __future__ import annotations
 
 import typing
+import weakref
 
 import numpy as np
 import torch
@@ -63,7 +64,10 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = self.flat_g[o:o + n].view(p.shape)
                 p._glowtts_flat_grad = self.flat_g
                 p._glowtts_flat_numel = self.numel
+                p._glowtts_flat_owner = weakref.ref(self)
         self._params = ps
+        # zero_grad() has not run yet: the views just installed are the ones grads_in_place() compares against
+        self._views = [p.grad for p in ps]
 
     def slices(self):
         """(offset, numel) of every parameter inside the flat buffers, in construction order."""
@@ -123,12 +127,12 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         """torch.optim.Adam-compatible layout: state[i] = {step, exp_avg, exp_avg_sq} (what checkpoint.py:44 saves)."""
-        t = self.dev_state[0] - 1.0
+        t = (self.dev_state[0] - 1.0).detach().cpu()        # ONE device read for the step every entry shares
         state = {}
         for i, (p, o) in enumerate(zip(self._params, self.offsets)):
             n = p.numel()
             state[i] = {
-                "step": t.detach().clone().cpu(),
+                "step": t.clone(),
                 "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
                 "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone(),
             }
@@ -137,7 +141,17 @@ class FlatAdam(torch.optim.Optimizer):
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, d):
+        """Like torch.optim.Optimizer.load_state_dict: a state whose parameter count or moment shapes differ from this
+        optimizer's raises ValueError; an EMPTY state (a file saved before the first update) is accepted."""
         st = d.get("state", {})
+        saved_groups = d.get("param_groups", [])
+        if saved_groups and "params" in saved_groups[0]:
+            n_saved = sum(len(g["params"]) for g in saved_groups)
+            if n_saved != len(self._params):
+                raise ValueError(f"loaded state dict has {n_saved} parameters, the optimizer has {len(self._params)}")
+        missing = [i for i in range(len(self._params)) if st and i not in st and str(i) not in st]
+        if missing:
+            raise ValueError(f"optimizer state lacks entries for parameters {missing[:8]}{'...' if len(missing) > 8 else ''}")
         steps = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self._params, self.offsets)):
@@ -145,10 +159,17 @@ class FlatAdam(torch.optim.Optimizer):
                 if s is None:
                     continue
                 n = p.numel()
+                for name in ("exp_avg", "exp_avg_sq"):
+                    if tuple(s[name].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state {name}[{i}] has shape {tuple(s[name].shape)}, "
+                                         f"the parameter has {tuple(p.shape)}")
                 self.flat_m[o:o + n].copy_(s["exp_avg"].reshape(-1))
                 self.flat_v[o:o + n].copy_(s["exp_avg_sq"].reshape(-1))
                 steps.append(float(s["step"]))
             if steps:
+                if max(steps) != min(steps):
+                    import warnings
+                    warnings.warn("FlatAdam.load_state_dict: per-parameter steps differ; using the largest")
                 self.dev_state[0] = max(steps) + 1.0
         for g_new, g in zip(d.get("param_groups", []), self.param_groups):
             for k in ("lr", "betas", "eps"):

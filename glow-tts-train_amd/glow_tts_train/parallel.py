@@ -65,7 +65,12 @@ class FlowBlockReducer:
     """Bucketed, backward-overlapped gradient all-reduce over the flat gradient buffer of `optimize.FlatAdam`."""
 
     def __init__(self, model: torch.nn.Module, optimizer, process_group=None,
-                 bucket_key: typing.Callable[[str], str] = default_bucket_key):
+                 bucket_key: typing.Callable[[str], str] = default_bucket_key, force: bool = False,
+                 measure: bool = False):
+        """`force`: hook the gradients and issue every bucket's collective even in a group of ONE rank (the collective is
+        then the identity; it exercises the RCCL launch path, its streams and `finish()` on a single GPU).
+        `measure`: record HIP events around the wait in `finish()` — `exposed_comm_ms()` is the time the compute stream
+        spent waiting for collectives that backward did not hide."""
         flat = getattr(optimizer, "_optim", optimizer)
         if not hasattr(flat, "flat_g"):
             raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
@@ -73,7 +78,12 @@ class FlowBlockReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
+        self.backend = backend
         self._use_avg = backend == "nccl"
+        self._active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self._measure = bool(measure)
+        self._exposed: typing.List[typing.Tuple[typing.Any, typing.Any]] = []
+        self.launched_in_backward = 0          # buckets whose collective was issued before finish() in the last step
         named = list(model.named_parameters())
         by_id = {id(p): (o, p.numel()) for p, o in zip(flat._params, flat.offsets)}
         self.buckets: typing.List[Bucket] = []
@@ -102,7 +112,7 @@ class FlowBlockReducer:
         self._works: typing.List[typing.Any] = []
         self._hooks = []
         self._seen: typing.Set[int] = set()
-        if self.world > 1:
+        if self._active:
             for _, p in named:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_hook))
@@ -112,7 +122,7 @@ class FlowBlockReducer:
     # -- collectives ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
         """One broadcast of the whole flat parameter buffer (DDP's construction-time sync, __main__.py:269-271)."""
-        if self.world > 1:
+        if self._active:
             dist.broadcast(self.flat.flat_p, src=src, group=self.group)
 
     def _launch(self, i: int):
@@ -159,18 +169,36 @@ class FlowBlockReducer:
     def finish(self):
         """Call after backward(), before clipping: reduces buckets whose parameters got no gradient this step (their
         slice is the zeros left by zero_grad), then makes the current stream wait for every collective."""
-        if self.world > 1:
+        if self._active:
+            self.launched_in_backward = sum(self._launched)
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
+            cuda = self.flat.flat_g.is_cuda
+            if cuda and self._measure:
+                cur = torch.cuda.current_stream(self.flat.flat_g.device)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(cur)
             for w in self._works:
                 w.wait()
-            if self.flat.flat_g.is_cuda:                 # (the non-AVG path divides on the launch stream before reducing)
+            if cuda:                                     # (the non-AVG path divides on the launch stream before reducing)
                 torch.cuda.current_stream(self.flat.flat_g.device).wait_stream(_hip.side_stream(self.flat.flat_g.device, "comm"))
+                if self._measure:
+                    t1.record(cur)
+                    self._exposed.append((t0, t1))
         self._works.clear()
         self._seen.clear()
         self._pending = [b.n_params for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+
+    def exposed_comm_ms(self, reset: bool = True) -> typing.List[float]:
+        """Per step since the last call: milliseconds the compute stream waited in `finish()` for gradient collectives
+        (`measure=True`; synchronises to read the events).  What backward hid does not show up here."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._exposed]
+        if reset:
+            self._exposed.clear()
+        return out
 
     def remove_hooks(self):
         for h in self._hooks:

@@ -89,8 +89,13 @@ def clip_grad_value_(parameters, clip_value, norm_type=2):
     dev = params[0].grad.device
     sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
     flat = getattr(params[0], "_glowtts_flat_grad", None)
-    if flat is not None and all(getattr(p, "_glowtts_flat_grad", None) is flat for p in params) \
-            and sum(p.numel() for p in params) == getattr(params[0], "_glowtts_flat_numel", -1):
+    owner = getattr(params[0], "_glowtts_flat_owner", None)
+    owner = owner() if owner is not None else None
+    # one launch over the flat buffer only while EVERY .grad still is the optimizer's view of it: a hook or a wrapper that
+    # replaced a .grad leaves the flat slice stale, and clamping it would skip the live gradient (the per-tensor path below)
+    if flat is not None and owner is not None and all(getattr(p, "_glowtts_flat_grad", None) is flat for p in params) \
+            and sum(p.numel() for p in params) == getattr(params[0], "_glowtts_flat_numel", -1) \
+            and owner.flat_g is flat and owner.grads_in_place():
         call("glowtts_clip_grad_value", ptr(flat), flat.numel(), float(clip_value), ptr(sumsq))
     else:
         for p in params:

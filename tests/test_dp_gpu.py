@@ -119,3 +119,137 @@ def test_flow_block_reducer_on_real_operators_two_ranks():
     np.testing.assert_allclose(red0, red1, rtol=0, atol=1e-6 * scale, err_msg="ranks disagree after the all-reduce")
     # the reference is computed with the same kernels, so only the atomics' summation order differs
     np.testing.assert_allclose(red0, mean0, rtol=2e-3, atol=2e-5 * scale, err_msg="reduced gradients != mean of per-rank gradients")
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on one card
+def _nccl_worker(port, q):
+    """`backend="nccl"` is RCCL on ROCm.  A group of ONE rank on the test GPU runs the reducer's real launch path: slices
+    of the flat gradient buffer all-reduced (AVG) in place from the "comm" stream as their buckets complete during
+    backward, `broadcast_parameters`, and `finish()`'s stream joins (this branch had never executed)."""
+    import sys
+    import torch.distributed as dist
+
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from glow_tts_train import convops, models, optimize, parallel
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1234)
+        model, opt = _build(models, optimize)
+        dev = torch.device("cuda", 0)
+        batch = _batch(0, dev)
+        convops.set_direct_grads(True)                   # the un-reduced reference takes the same in-place route
+        plain, _ = _grads_of(model, opt, batch, None)
+        convops.set_direct_grads(None)
+        red = parallel.FlowBlockReducer(model, opt, force=True, measure=True)
+        assert red.backend == "nccl" and red._use_avg and red._active and red._hooks
+        before = opt._optim.flat_p.clone()
+        red.broadcast_parameters(0)
+        torch.cuda.synchronize()
+        same_params = bool(torch.equal(before, opt._optim.flat_p))
+        reduced, launched = _grads_of(model, opt, batch, red)
+        again, launched2 = _grads_of(model, opt, batch, red)     # second step: counters were reset by finish()
+        exposed = red.exposed_comm_ms()
+        q.put(("ok", plain, reduced, again, launched, launched2, len(red.buckets), same_params, exposed))
+    except Exception as exc:                                      # surface the failure in the parent
+        import traceback
+        q.put(("error", traceback.format_exc(), repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flow_block_reducer_runs_on_rccl_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    proc.start()
+    res = q.get(timeout=300)
+    proc.join(120)
+    assert res[0] == "ok", res[1]
+    assert proc.exitcode == 0
+    _, plain, reduced, again, launched, launched2, nb, same_params, exposed = res
+    assert same_params, "broadcast from rank 0 to a group of one must leave the parameters alone"
+    assert launched >= nb - 3 and launched2 >= nb - 3, f"only {launched}/{nb} buckets were reduced while backward ran"
+    assert len(exposed) == 2 and all(0.0 <= t < 50.0 for t in exposed)
+    scale = float(np.abs(plain).max())
+    # AVG over one rank is the identity: only the float atomics' summation order separates the runs
+    np.testing.assert_allclose(reduced, plain, rtol=2e-3, atol=2e-5 * scale)
+    np.testing.assert_allclose(again, plain, rtol=2e-3, atol=2e-5 * scale)
+
+
+# ------------------------------------------------------------------------------------------------ the reference's DDP wrap
+def _ddp_worker(rank, world, port, q):
+    """Reference `__main__.py:268-271` unchanged: `DistributedDataParallel(model, device_ids=[local_rank], ...)` around the
+    model built by `setup_model` — no environment variable, no call into convops."""
+    import sys
+    import torch.distributed as dist
+
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("GLOWTTS_DIRECT_GRADS", None)
+    from glow_tts_train import convops, models, optimize
+    from glow_tts_train.utils import clip_grad_value_
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(1234 + rank)                   # DDP's construction-time broadcast must make rank 0's weights win
+        model, opt = _build(models, optimize)
+        dev = torch.device("cuda", 0)
+        assert not convops.direct_grads_enabled()
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], output_device=0)
+        params_after_wrap = opt._optim.flat_p.detach().cpu().numpy().copy()
+        with ddp.no_sync():                              # every rank's un-reduced gradients, computed locally
+            own = [_grads_of(ddp, opt, _batch(r, dev), None)[0] for r in range(world)]
+        reduced, _ = _grads_of(ddp, opt, _batch(rank, dev), None)
+        in_place = opt._optim.grads_in_place()
+        clip_grad_value_(ddp.parameters(), 5.0)          # what train.py:145 calls on the wrapped model
+        opt.step()
+        torch.cuda.synchronize()
+        q.put((rank, reduced, np.mean(own, axis=0), params_after_wrap, in_place,
+               opt._optim.flat_p.detach().cpu().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unchanged_ddp_wrap_on_real_operators_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, red0, mean0, w0, inpl0, after0), (_, red1, mean1, w1, inpl1, after1) = res
+    np.testing.assert_array_equal(w0, w1, err_msg="DDP's parameter broadcast did not reach the flat buffer")
+    assert inpl0 and inpl1
+    scale = float(np.abs(mean0).max())
+    np.testing.assert_allclose(red0, red1, rtol=0, atol=1e-6 * scale, err_msg="ranks disagree after DDP's all-reduce")
+    np.testing.assert_allclose(red0, mean0, rtol=2e-3, atol=2e-5 * scale, err_msg="DDP gradients != mean of per-rank gradients")
+    np.testing.assert_allclose(after0, after1, rtol=0, atol=1e-6, err_msg="parameters diverge after one update")
+    assert np.isfinite(after0).all() and np.abs(after0 - w0).max() > 0
+
+
+def test_clip_clamps_a_replaced_gradient_on_device():
+    import sys
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    from glow_tts_train import models, optimize, utils
+
+    model, opt = _build(models, optimize)
+    opt.zero_grad()
+    opt._optim.flat_g.fill_(0.5)
+    victim = next(iter(model.parameters()))
+    victim.grad = torch.full_like(victim, 9.0)
+    norm = utils.clip_grad_value_(model.parameters(), 2.0)
+    torch.cuda.synchronize()
+    assert float(victim.grad.max()) == 2.0
+    n_rest = opt._optim.numel - victim.numel()
+    assert float(norm) == pytest.approx((81.0 * victim.numel() + 0.25 * n_rest) ** 0.5, rel=1e-4)
+    opt.step()                                            # folds the foreign gradient back into the flat buffer
+    assert opt._optim.grads_in_place()

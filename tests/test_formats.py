@@ -200,6 +200,31 @@ def test_reads_reference_checkpoint_and_writes_the_same_layout(tmp_path):
     assert ck2.optimizer is None and dropped in ck2.model.state_dict()
 
 
+def test_reads_checkpoint_pickled_under_numpy1(tmp_path):
+    """Real reference checkpoints were written under numpy 1.x, whose scalars pickle as `numpy.core.multiarray.scalar`
+    (this box's numpy 2 writes `numpy._core...`).  The fixture's pickle stream is rewritten to the numpy-1 spelling —
+    protocol-2 GLOBAL opcodes are newline-terminated text, so the rename is a byte substitution — and must still load."""
+    import zipfile
+
+    from glow_tts_train import checkpoint as C
+
+    cfg, e = _tiny_config()
+    old = tmp_path / "np1.pth"
+    renamed = 0
+    with zipfile.ZipFile(REF_CKPT) as zin, zipfile.ZipFile(old, "w", zipfile.ZIP_STORED) as zout:
+        for item in zin.infolist():
+            data = zin.read(item.filename)
+            if item.filename.endswith("data.pkl"):
+                renamed = data.count(b"cnumpy._core.multiarray\n")
+                data = data.replace(b"cnumpy._core.multiarray\n", b"cnumpy.core.multiarray\n")
+            zout.writestr(item, data)
+    assert renamed > 0, "fixture no longer carries numpy scalars: this test would prove nothing"
+    raw = C._read(old)
+    assert float(raw["learning_rate"]) == pytest.approx(float(e["learning_rate"]), rel=1e-12)
+    ck = C.load_checkpoint(old, cfg, use_cuda=False)
+    assert ck.global_step == 3
+
+
 def test_checkpoint_looks_through_a_wrapper(tmp_path):
     from glow_tts_train import checkpoint as C
 

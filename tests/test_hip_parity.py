@@ -89,7 +89,10 @@ def test_mas_reference_wrapper_semantics(G):
     assert (out.cpu().numpy() == want).all()
 
 
-@pytest.mark.parametrize("b,tx,ty", [(32, 160, 800), (8, 100, 400), (5, 257, 1000), (3, 500, 520), (64, 200, 1000)])
+@pytest.mark.parametrize("b,tx,ty", [(32, 160, 800), (8, 100, 400), (5, 257, 1000), (3, 500, 520), (64, 200, 1000),
+                                     # beyond the former limits: > 512 tokens; bit lattice > LDS (500 x 4000:
+                                     # back-pointers go through the output buffer); odd frame count on that path
+                                     (2, 700, 1500), (1, 1100, 1203), (2, 500, 4000), (1, 2048, 2100)])
 def test_mas_vs_oracle_full_size(G, b, tx, ty):
     from oracle import glow_oracle as O
 
@@ -887,7 +890,7 @@ def test_direct_grads_switch_routes_gradients_through_autograd(G):
             torch.cuda.synchronize()
             res[direct] = ({k: p.grad.clone() for k, p in blk.named_parameters()}, set(fired))
     finally:
-        convops.set_direct_grads(True)
+        convops.set_direct_grads(None)               # back to the automatic choice
         for h in hooks:
             h.remove()
     names = {n for n, _ in blk.named_parameters()}

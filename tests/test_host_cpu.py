@@ -282,6 +282,124 @@ def test_flow_block_reducer_gloo_world2():
     assert g0[opt._optim.slices()[-1][0]:].abs().sum() == 0            # unused embedding: zeros, still reduced
 
 
+def _ddp_worker(rank, world, port, q):
+    """The reference's own wrap (`__main__.py:268-271`): torch DistributedDataParallel around a model whose parameters and
+    gradients are views of FlatAdam's flat buffers."""
+    import sys
+
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    from glow_tts_train import convops, optimize, parallel
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    auto_before = convops.direct_grads_enabled()                # no process group yet: in place
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        auto_in_group = convops.direct_grads_enabled()          # a group and nobody listening: through autograd (DDP)
+        torch.manual_seed(100 + rank)
+        model = _Toy()
+        for p in model.emb_g.parameters():                      # DDP wants a gradient for every parameter it manages
+            p.requires_grad_(False)
+        opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+        red = parallel.FlowBlockReducer(model, opt)
+        auto_with_reducer = convops.direct_grads_enabled()      # our reducer listens: in place again
+        red.remove_hooks()
+        auto_after_remove = convops.direct_grads_enabled()
+        ddp = torch.nn.parallel.DistributedDataParallel(model)  # broadcasts rank 0's parameters INTO the flat buffer
+        torch.manual_seed(7)
+        data = torch.randn(world * 4, 6)
+        opt.zero_grad()
+        ddp(data[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
+        in_place = opt._optim.grads_in_place()                  # DDP copies the reduced bucket back into the same views
+        q.put((rank, (auto_before, auto_in_group, auto_with_reducer, auto_after_remove), in_place,
+               opt._optim.flat_p.numpy().copy(), opt._optim.flat_g.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unchanged_ddp_wrap_gloo_world2_matches_flow_block_reducer():
+    """DDP semantics on the flat buffers == FlowBlockReducer's (mean of per-rank gradients, rank 0's parameters), and the
+    operators' in-place-gradient shortcut switches itself off when a process group exists without our reducer."""
+    from glow_tts_train import optimize
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, auto0, inpl0, p0, g0), (_, auto1, inpl1, p1, g1) = res
+    assert auto0 == auto1 == (True, False, True, False)
+    assert inpl0 and inpl1, "DDP must leave .grad as the optimizer's views of the flat buffer"
+    p0, g0, p1, g1 = (torch.from_numpy(a) for a in (p0, g0, p1, g1))
+    assert torch.equal(p0, p1) and torch.equal(g0, g1)
+    torch.manual_seed(100)
+    model = _Toy()
+    opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+    torch.manual_seed(7)
+    data = torch.randn(world * 4, 6)
+    opt.zero_grad()
+    (sum(model(data[r * 4:(r + 1) * 4]).pow(2).mean() for r in range(world)) / world).backward()
+    assert_close(g0, opt._optim.flat_g, what="DDP-averaged grads", rtol=1e-5, atol=1e-7)
+
+
+def test_clip_falls_back_to_live_gradients_when_one_was_replaced(monkeypatch):
+    """`utils.clip_grad_value_` may clamp the flat buffer in one launch only while every `.grad` still is the
+    optimizer's view of it; a replaced `.grad` must be clamped itself (the kernel is stubbed: selection logic only)."""
+    from glow_tts_train import optimize, utils
+
+    model = _Toy()
+    opt = optimize.Adam(model.parameters(), scheduler="noam", dim_model=6)
+    flat = opt._optim
+    clamped = []
+
+    def fake_call(name, t, n, clip, sumsq, **kw):
+        assert name == "glowtts_clip_grad_value"
+        clamped.append(t)
+        sumsq += (t.reshape(-1)[:n] ** 2).sum()
+        t.clamp_(-clip, clip)
+
+    monkeypatch.setattr(utils, "call", fake_call)
+    monkeypatch.setattr(utils, "ptr", lambda t: t)
+    opt.zero_grad()
+    flat.flat_g.fill_(3.0)
+    norm = utils.clip_grad_value_(model.parameters(), 1.0)
+    assert len(clamped) == 1 and clamped[0] is flat.flat_g and float(flat.flat_g.max()) == 1.0
+    assert float(norm) == pytest.approx(3.0 * flat.numel_padded ** 0.5)
+    # a foreign tensor takes the place of one gradient
+    clamped.clear()
+    victim = next(iter(model.parameters()))
+    victim.grad = torch.full_like(victim, 7.0)
+    assert not flat.grads_in_place() and flat.clip_grad_value_(1.0) is None
+    utils.clip_grad_value_(model.parameters(), 2.0)
+    assert len(clamped) == len([p for p in model.parameters()]), "per-tensor path expected"
+    assert float(victim.grad.max()) == 2.0, "the live gradient was not clamped"
+
+
+def test_flat_adam_load_state_dict_rejects_mismatched_state():
+    from glow_tts_train import optimize
+
+    m = _make()
+    opt = optimize.Adam(m.parameters(), scheduler="noam", dim_model=32)
+    sd = opt.state_dict()
+    opt.load_state_dict({"state": {}, "param_groups": sd["param_groups"]})      # saved before the first update: fine
+    broken = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
+    del broken["state"][3]
+    with pytest.raises(ValueError, match="lacks entries"):
+        opt.load_state_dict(broken)
+    broken = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
+    broken["state"][0] = dict(broken["state"][0], exp_avg=torch.zeros(5))
+    with pytest.raises(ValueError, match="shape"):
+        opt.load_state_dict(broken)
+    other = optimize.Adam(list(m.parameters())[:4], scheduler="noam", dim_model=32)
+    with pytest.raises(ValueError, match="parameters"):
+        other.load_state_dict(sd)
+
+
 def test_reducer_single_process_is_a_noop():
     from glow_tts_train import optimize, parallel
 
@@ -350,7 +468,7 @@ def test_fastcall_binding_matches_the_ctypes_table():
     args = (1, 1, 1, 1, None, 1, None, 0, 4, 0, 0, None)                    # empty batch: validated, nothing launched
     assert fast(*args) == lib.glowtts_actnorm_fwd(*args) == 0
     assert fast(1, 1, 1, 1, None, 1, None, np.int64(0), True, 0, 0, None) == 0     # anything with __index__ is an int
-    assert _hip._fn_cache["glowtts_mas_path"](1, 1, 1, 1, 1, 600, 10, None) != 0 and b"512" in lib.glowtts_last_error()
+    assert _hip._fn_cache["glowtts_mas_path"](1, 1, 1, 1, 1, 2100, 10, None) != 0 and b"2048" in lib.glowtts_last_error()
     with pytest.raises(TypeError):
         fast(1, 1, 1, 1, None, 1, None, "0", 4, 0, 0, None)
     with pytest.raises(TypeError, match="expected 12"):
