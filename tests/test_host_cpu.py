@@ -44,8 +44,8 @@ def test_cabi_argument_errors_do_not_need_a_gpu():
     lib = _hip.load()
     rc = lib.glowtts_invconv_prepare(None, None, None, 4, None)
     assert rc != 0 and b"null pointer" in lib.glowtts_last_error()
-    rc = lib.glowtts_mas_path(1, 1, 1, 1, 1, 600, 10, None)           # non-null dummies; Tx over the limit
-    assert rc != 0 and b"512" in lib.glowtts_last_error()
+    rc = lib.glowtts_mas_path(1, 1, 1, 1, 1, 2100, 10, None)          # non-null dummies; Tx over the limit
+    assert rc != 0 and b"2048" in lib.glowtts_last_error()
     rc = lib.glowtts_invconv_fwd(1, 1, 1, None, None, 1, None, 1, 12, 4, 6, None)
     assert rc != 0 and b"n_split" in lib.glowtts_last_error()
     assert lib.glowtts_actnorm_fwd(1, 1, 1, 1, None, 1, None, 0, 4, 0, 0, None) == 0   # empty batch: no launch
