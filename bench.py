@@ -231,6 +231,11 @@ def build_workload(args, dev, rank):
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line: libraries that print there (RCCL's version banner at communicator creation) are sent
+    # to stderr for the duration of the run, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -456,7 +461,8 @@ def main():
                                          f"{cdt:.2f} s/step after 1 warm-up"}
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

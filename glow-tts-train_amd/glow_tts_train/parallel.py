@@ -34,22 +34,23 @@ _ENC_FFN_RE = re.compile(r"^(?:module\.)?encoder\.encoder\.ffn_layers\.(\d+)\.")
 
 
 def default_bucket_key(name: str) -> str:
-    """One bucket per flow block (7.1 MB).  The text encoder (28.8 MB) is cut where its parameters are contiguous in
-    construction order: embedding + prenet, the attention layers (3.6 MB together), one bucket per FFN layer (3.5 MB each:
-    a layer's gradients are complete, and un-packed, as soon as its backward is through — layer 5 first), and the tail
-    (projections, duration predictor).  Only the buckets of the lowest layers are still in flight when backward ends."""
+    """TWO flow blocks per bucket (14.3 MB) and four buckets for the text encoder (28.8 MB), cut where its parameters are
+    contiguous in construction order: embedding + prenet + attention stack, FFN layers 0-2, FFN layers 3-5, tail
+    (projections, duration predictor) — 6 + 4 = 10 collectives per step at the default size.  Fewer, larger messages are
+    the right shape for xGMI (a ring step is per-link bound, ~153 GB/s: a 14 MB bucket is ~0.17 ms on the wire at 8 ranks
+    while each launch costs ~50 us of host time on the backward thread); the decoder buckets complete in reverse block
+    order during the backward, and only the encoder head is still in flight when it ends."""
     m = _FLOW_RE.match(name)
     if m:
-        return f"dec{int(m.group(1)) // 3:03d}"
+        return f"dec{int(m.group(1)) // 6:03d}"
     m = _ENC_FFN_RE.match(name)
     if m:
-        return f"enc.ffn{int(m.group(1))}"
+        return f"enc.ffn{int(m.group(1)) // 3}"
     core = name[len("module."):] if name.startswith("module.") else name
     if core.startswith("encoder."):
-        if core.startswith("encoder.emb.") or core.startswith("encoder.pre."):
+        if core.startswith("encoder.emb.") or core.startswith("encoder.pre.") \
+                or core.startswith("encoder.encoder.attn_layers.") or core.startswith("encoder.encoder.norm_layers_1."):
             return "enc.head"
-        if core.startswith("encoder.encoder.attn_layers.") or core.startswith("encoder.encoder.norm_layers_1."):
-            return "enc.attn"
         return "enc.tail"
     return "misc"
 
@@ -111,13 +112,17 @@ class FlowBlockReducer:
         self._launched = [False] * len(self.buckets)
         self._works: typing.List[typing.Any] = []
         self._hooks = []
+        self._hook_of: typing.Dict[int, typing.Any] = {}
+        self._announced: typing.Set[int] = set()     # parameters whose gradient an operator announced itself this step
         self._seen: typing.Set[int] = set()
         if self._active:
             for _, p in named:
                 if p.requires_grad:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_hook))
+                    h = p.register_post_accumulate_grad_hook(self._on_hook)
+                    self._hooks.append(h)
+                    self._hook_of[id(p)] = h
             # gradients the conv operators write straight into .grad are announced by the operators themselves
-            convops.add_grad_ready_listener(self._on_grad)
+            convops.add_grad_ready_listener(self._on_announce)
 
     # -- collectives ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -157,6 +162,10 @@ class FlowBlockReducer:
             return
         self._on_grad(p)
 
+    def _on_announce(self, p: torch.Tensor):
+        self._announced.add(id(p))
+        self._on_grad(p)
+
     def _on_grad(self, p: torch.Tensor):
         if id(p) not in self._bucket_of or id(p) in self._seen:
             return
@@ -186,6 +195,14 @@ class FlowBlockReducer:
                 if self._measure:
                     t1.record(cur)
                     self._exposed.append((t0, t1))
+            # Parameters whose gradient the operators announce themselves need no autograd hook: ~440 of 519 at the default
+            # model, each a C++ -> Python call on the backward thread (~1.5 ms per step together).  A parameter that stops
+            # being announced (another gradient mode) only loses its EARLY launch: finish() reduces whatever is left.
+            for pid in self._announced:
+                h = self._hook_of.pop(pid, None)
+                if h is not None:
+                    h.remove()
+        self._announced.clear()
         self._works.clear()
         self._seen.clear()
         self._pending = [b.n_params for b in self.buckets]
@@ -204,4 +221,4 @@ class FlowBlockReducer:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
-        convops.remove_grad_ready_listener(self._on_grad)
+        convops.remove_grad_ready_listener(self._on_announce)
