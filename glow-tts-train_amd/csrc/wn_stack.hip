@@ -173,3 +173,76 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
         WN_TRY(glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows, (glowtts_stream_t)ws));
     return 0;
 }
+
+// ---- a whole flow block per call ---------------------------------------------------------------------------------------
+// [ActNorm, InvConvNear, CouplingBlock] (reference models.py:176-190, forward direction) is ONE host call each way.  The
+// Python path drove it as five autograd nodes per block (fused ActNorm+InvConv, start conv, WN, end conv, affine apply):
+// ~120 us of interpreter / autograd time per block forward and ~180 us backward on top of the launches themselves,
+// 3 ms of the ~19 ms host time of a config-2 step.  The launch sequence below is the same one, kernel for kernel.
+extern "C" int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
+                                      const unsigned char *drop, float drop_scale, float *y, float *h0, float *xs,
+                                      float *acts, float *ts, float *skip, float *out, float *z, float *logdet, int B, int C,
+                                      int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
+                                      glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && z && logdet,
+                      "glowtts_flow_block_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->w_inv && blk->logdet_w && (!blk->pack_desc || blk->pack_prefix),
+                      "glowtts_flow_block_fwd: incomplete block table");
+    GLOWTTS_CHECK_ARG(C > 0 && (C % 2) == 0 && (n_split == 2 || n_split == 4) && C % n_split == 0,
+                      "glowtts_flow_block_fwd: C=%d n_split=%d", C, n_split);
+    const long CT = (long)C * T, HT = (long)H * T;
+    // weight norm + k-packing of all 2 + 2 n_layers convolutions (pack_desc == NULL: the caller has packed them already,
+    // e.g. because it also refreshes bf16 planes of the packed weights); W^-1 and log det W of the invertible 1x1
+    if (blk->pack_desc)
+        WN_TRY(glowtts_pack_weight_multi(blk->pack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, stream));
+    WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
+    // flows 3i, 3i+1: y = W ((bias + e^logs x) mask) mask ; logdet = (sum logs + log det W * C/n) x_len
+    WN_TRY(glowtts_actnorm_invconv_fwd(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet, B, C, T, n_split,
+                                       stream));
+    // flow 3i+2: h = start(y[:, :C/2]) mask  ->  WN  ->  out = end(h)  ->  z = [y0 ; (m + e^logs y1) mask], logdet += sum logs mask
+    WN_TRY(glowtts_conv_fwd(y, CT, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1, 0, stream));
+    WN_TRY(glowtts_wn_fwd(blk->layers, blk->n_layers, h0, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
+                          stream));
+    WN_TRY(glowtts_conv_fwd(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, stream));
+    return glowtts_coupling_fwd(y, out, mask, z, logdet, B, C, T, sigmoid_scale, 0, stream);
+}
+
+extern "C" int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
+                                      const unsigned char *drop, float drop_scale, const float *y, const float *h0,
+                                      const float *xs, const float *acts, const float *ts, const float *skip,
+                                      const float *out, const float *dz, const float *dlogdet, float *dy, float *dout,
+                                      float *dskip, float *d_rs, float *d_xin, float *dx_wn, float *dx, int B, int C, int H,
+                                      int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int two_source,
+                                      glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && dz && dy && dout && dskip && d_rs &&
+                      d_xin && dx_wn && dx, "glowtts_flow_block_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->unpack_desc && blk->pack_prefix && blk->dwp_all && blk->dlogs &&
+                      blk->dbias && blk->dw, "glowtts_flow_block_bwd: incomplete block table");
+    hipStream_t ms = (hipStream_t)stream;
+    hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
+    const long CT = (long)C * T, HT = (long)H * T;
+    // every packed weight-gradient accumulator of the block in one fill (the kernels add into it with atomics)
+    hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ms);
+    if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
+    // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
+    WN_TRY(glowtts_coupling_bwd(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, stream));
+    // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(skip, HT, dout, CT, nullptr, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, (glowtts_stream_t)ws));
+    WN_TRY(glowtts_conv_fwd(dout, CT, blk->wb_end, nullptr, nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0, 0, 0, stream));
+    // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block)
+    WN_TRY(glowtts_wn_bwd(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, nullptr,
+                          nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, wgrad_stream, stream));
+    // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(y, CT, dx_wn, HT, mask, nullptr, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0,
+                            (glowtts_stream_t)ws));
+    WN_TRY(glowtts_conv_fwd(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, stream));
+    // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets
+    WN_TRY(glowtts_actnorm_invconv_bwd(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,
+                                       blk->dbias, blk->dw, B, C, T, n_split, stream));
+    // the second stream finishes the block: after this point on `ws` EVERY parameter gradient of the block is complete
+    // (the three ActNorm / InvConv gradients were produced on the chain, hence the ordering edge)
+    WN_TRY(order_after(ms, ws));
+    return glowtts_unpack_weight_grad_multi(blk->unpack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, (glowtts_stream_t)ws);
+}

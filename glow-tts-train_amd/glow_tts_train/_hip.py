@@ -69,6 +69,9 @@ _SIGNATURES = {
     # whole WN stack per call (csrc/wn_stack.hip); the first argument is a HOST array of WnLayer
     "glowtts_wn_fwd": [_P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I],
     "glowtts_wn_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    # a whole flow block per call (csrc/wn_stack.hip); the first argument is a HOST struct glowtts_flow_block
+    "glowtts_flow_block_fwd": [_P, _P, _P, _P, _P, _F] + [_P] * 9 + [_I] * 8,
+    "glowtts_flow_block_bwd": [_P, _P, _P, _P, _P, _F] + [_P] * 16 + [_I] * 9 + [_P],
 }
 
 
@@ -76,6 +79,16 @@ class WnLayer(ctypes.Structure):
     """struct glowtts_wn_layer (include/glowtts_hip.h): device pointers of one WN layer's packed weights and gradients."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("wf_in", "wb_in", "b_in", "wf_rs", "wb_rs", "b_rs", "dwp_in", "dwp_rs",
                                                  "db_in", "db_rs")]
+
+
+class FlowBlock(ctypes.Structure):
+    """struct glowtts_flow_block (include/glowtts_hip.h): one [ActNorm, InvConvNear, CouplingBlock] block's device pointers."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in (
+        "logs", "bias", "w", "w_inv", "logdet_w", "wf_start", "wb_start", "b_start", "wf_end", "wb_end", "b_end",
+        "dwp_start", "dwp_end", "db_start", "db_end", "dlogs", "dbias", "dw", "layers", "pack_desc", "unpack_desc",
+        "pack_prefix", "dwp_all")]
+                + [("dwp_floats", ctypes.c_longlong), ("n_layers", ctypes.c_int), ("n_conv", ctypes.c_int),
+                   ("total_rows", ctypes.c_int), ("reserved", ctypes.c_int)])
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",

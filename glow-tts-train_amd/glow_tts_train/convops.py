@@ -762,3 +762,172 @@ class WNFn(Function):
         else:
             results = sink.results()
         return (dx[0], None, None, None, None, None, None, None, *results)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class FlowBlockPlan:
+    """Packed weights, gradient accumulators and the host-side `glowtts_flow_block` table of one decoder block
+    ([ActNorm, InvConvNear, CouplingBlock]): its 2 + 2 n_layers convolutions share ONE pack launch per forward and ONE
+    un-pack launch per backward (the per-op path used two of each: the coupling's ConvGroup and the WN stack's plan)."""
+
+    def __init__(self):
+        self.plan = WNPackPlan(want_planes=True)
+        self._key = None
+
+    @staticmethod
+    def conv_params(params, n_layers):
+        """(v, g, bias) triples in the plan's order: start, end, then (in, res/skip) per WN layer."""
+        logs, bias, w, sv, sg, sb, ev, eb = params[:8]
+        return [sv, sg, sb, ev, None, eb] + list(params[8: 8 + 6 * n_layers])
+
+    def table(self, params, n_layers):
+        import ctypes
+        plan = self.plan
+        convp = self.conv_params(params, n_layers)
+        key = (plan.version, tuple(0 if p is None else p.data_ptr() for p in params),
+               tuple(0 if (p is None or p.grad is None) else p.grad.data_ptr() for p in params))
+        if key != self._key:
+            logs, bias, w = params[:3]
+            gdesc, prefix = plan.unpack_tables(convp)
+            layers = (_hip.WnLayer * n_layers)()
+            for i in range(n_layers):
+                ci, cr = plan.convs[2 + 2 * i], plan.convs[3 + 2 * i]
+                in_b, rs_b = convp[6 + 6 * i + 2], convp[6 + 6 * i + 5]
+                L = layers[i]
+                L.wf_in, L.wb_in, L.b_in = ci[2].data_ptr(), ci[3].data_ptr(), in_b.data_ptr()
+                L.wf_rs, L.wb_rs, L.b_rs = cr[2].data_ptr(), cr[3].data_ptr(), rs_b.data_ptr()
+                L.dwp_in, L.dwp_rs = plan.dwp_view(2 + 2 * i).data_ptr(), plan.dwp_view(3 + 2 * i).data_ptr()
+                L.db_in, L.db_rs = in_b.grad.data_ptr(), rs_b.grad.data_ptr()
+            t = _hip.FlowBlock()
+            t.logs, t.bias, t.w = logs.data_ptr(), bias.data_ptr(), w.data_ptr()
+            cs, ce = plan.convs[0], plan.convs[1]
+            t.wf_start, t.wb_start, t.b_start = cs[2].data_ptr(), cs[3].data_ptr(), convp[2].data_ptr()
+            t.wf_end, t.wb_end, t.b_end = ce[2].data_ptr(), ce[3].data_ptr(), convp[5].data_ptr()
+            t.dwp_start, t.dwp_end = plan.dwp_view(0).data_ptr(), plan.dwp_view(1).data_ptr()
+            t.db_start, t.db_end = convp[2].grad.data_ptr(), convp[5].grad.data_ptr()
+            t.dlogs, t.dbias, t.dw = logs.grad.data_ptr(), bias.grad.data_ptr(), w.grad.data_ptr()
+            t.layers = ctypes.addressof(layers)
+            t.pack_desc = None                     # packing (and the optional bf16-plane split) is launched by plan.pack()
+            t.unpack_desc, t.pack_prefix = gdesc.data_ptr(), prefix.data_ptr()
+            t.dwp_all, t.dwp_floats = plan.dwp.data_ptr(), plan.dwp.numel()
+            t.n_layers, t.n_conv, t.total_rows = n_layers, len(plan.convs), plan.total_rows
+            self._tab, self._layers, self._key = t, layers, key       # (the layer array must outlive the struct)
+        return self._tab
+
+
+def flow_block_eligible(actnorm, invconv, coupling, x, g) -> bool:
+    """Can [actnorm, invconv, coupling] run as ONE native call each way (FlowBlockFn)?  Training direction, no conditioning
+    input, fused-flow sizes, every parameter gradient already allocated (the flat-buffer optimizer) and written in place."""
+    if g is not None or not x.is_cuda or not torch.is_grad_enabled() or not _hip.timing_off() or _WN_NATIVE != "both":
+        return False
+    if not actnorm.initialized or invconv.no_jacobian or invconv.n_split not in (2, 4) or coupling.gin_channels != 0:
+        return False
+    if not direct_grads_enabled():
+        return False
+    wn = coupling.wn
+    convs = [coupling.start, coupling.end] + list(wn.in_layers) + list(wn.res_skip_layers)
+    if not hasattr(coupling.start, "weight_v") or hasattr(coupling.end, "weight_v") or any(c.bias is None for c in convs) \
+            or not all(hasattr(c, "weight_v") for c in convs[2:]):
+        return False
+    # gradients are accumulated in place: every buffer must exist already (the flat-buffer optimizer keeps them allocated)
+    return all(p.requires_grad and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32
+               for p in flow_block_params(actnorm, invconv, coupling))
+
+
+def flow_block_params(actnorm, invconv, coupling):
+    wn = coupling.wn
+    out = [actnorm.logs, actnorm.bias, invconv.weight, coupling.start.weight_v, coupling.start.weight_g, coupling.start.bias,
+           coupling.end.weight, coupling.end.bias]
+    for in_layer, rs_layer in zip(wn.in_layers, wn.res_skip_layers):
+        out += [in_layer.weight_v, in_layer.weight_g, in_layer.bias, rs_layer.weight_v, rs_layer.weight_g, rs_layer.bias]
+    return out
+
+
+class FlowBlockFn(Function):
+    """One decoder block — ActNorm, InvConvNear, CouplingBlock (reference models.py:176-190; layers.py:182-199, 238-272;
+    attentions.py:119-142) — as ONE autograd node whose forward and backward are one native call each
+    (csrc/wn_stack.hip: glowtts_flow_block_fwd / _bwd queue the block's whole launch sequence from C)."""
+
+    @staticmethod
+    def forward(ctx, x, m2, x_len, drop, cfg, bplan, *params):
+        import ctypes
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = cfg
+        x = f32(x.contiguous())
+        B, C, T = x.shape
+        dev = x.device
+        plan = bplan.plan
+        plan.ensure(FlowBlockPlan.conv_params(params, n_layers), n_convs=2 + 2 * n_layers)
+        plan.pack()
+        bound = plan.bind()
+        try:
+            new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                      # noqa: E731
+            y, out, z = new(B, C, T), new(B, C, T), new(B, C, T)
+            h0, skip = new(B, H, T), new(B, H, T)
+            acts, ts = new(n_layers, B, H, T), new(n_layers, B, 2 * H, T)
+            xs = new(n_layers - 1, B, H, T) if n_layers > 1 else None
+            logdet = new(B)
+            winv = new(n_split * n_split + 1)
+            if p_drop > 0.0 and (drop is None or tuple(drop.shape) != (n_layers, B, 2 * H, T) or not drop.is_contiguous()):
+                drop = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)
+            if p_drop <= 0.0:
+                drop = None
+            tab = bplan.table(params, n_layers)
+            tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
+            taps = params[8].shape[2]
+            scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+            call("glowtts_flow_block_fwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), scale, ptr(y), ptr(h0),
+                 ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(z), ptr(logdet), B, C, H, T, taps, dil_rate, n_split,
+                 int(sigmoid_scale))
+        finally:
+            plan.unbind(bound)
+        ctx.save_for_backward(x, m2, x_len, y, h0, acts, ts, skip, out, winv, *([] if xs is None else [xs]),
+                              *([] if drop is None else [drop]))
+        ctx.cfg, ctx.bplan, ctx.params, ctx.taps, ctx.scale = cfg, bplan, params, taps, scale
+        return z, logdet
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, dlogdet):
+        import ctypes
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = ctx.cfg
+        sv = list(ctx.saved_tensors)
+        x, m2, x_len, y, h0, acts, ts, skip, out, winv = sv[:10]
+        rest = sv[10:]
+        xs = rest.pop(0) if n_layers > 1 else None
+        drop = rest.pop(0) if p_drop > 0 else None
+        params, bplan = ctx.params, ctx.bplan
+        plan = bplan.plan
+        B, C, T = x.shape
+        dev = x.device
+        if not all(p.grad is not None and p.grad.is_contiguous() for p in params):
+            raise RuntimeError("FlowBlockFn.backward: a parameter gradient buffer disappeared between forward and backward")
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                          # noqa: E731
+        dz = dz.contiguous() if dz is not None else torch.zeros_like(x)
+        dlogdet = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
+        wgrad = _WgradStream(dev)
+        two_src = wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
+        dy, dout, dx = new(B, C, T), new(B, C, T), new(B, C, T)
+        dskip = new(B, H, T)
+        d_rs = new(B, H, T) if two_src else new(n_layers, B, 2 * H, T)
+        d_xin, dx_wn = new(n_layers, B, 2 * H, T), new(n_layers, B, H, T)
+        tab = bplan.table(params, n_layers)
+        tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
+        bound = plan.bind()
+        try:
+            call("glowtts_flow_block_bwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), ctx.scale, ptr(y),
+                 ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(dz), ptr(dlogdet), ptr(dy), ptr(dout), ptr(dskip),
+                 ptr(d_rs), ptr(d_xin), ptr(dx_wn), ptr(dx), B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale),
+                 int(two_src), wgrad.side.cuda_stream if wgrad.enabled else None)
+        finally:
+            plan.unbind(bound)
+        live = [p for p in params if p is not None]
+        _mark_direct(live, True)
+        if wgrad.enabled:
+            for t in (y, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn):     # read by the second stream after this returns
+                if t is not None:
+                    t.record_stream(wgrad.side)
+            with torch.cuda.stream(wgrad.side):          # every gradient of the block is complete at this point of THAT stream
+                _notify(live)
+        else:
+            _notify(live)
+        return (dx, None, None, None, None, None) + (None,) * len(params)

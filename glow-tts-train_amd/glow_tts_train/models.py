@@ -20,6 +20,7 @@ from .optimize import OptimizerType
 from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 
 _actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
+_flow_block_apply = _hip.direct_apply(convops.FlowBlockFn)
 
 _LOGGER = logging.getLogger("glow_tts_train.models")
 
@@ -146,7 +147,20 @@ class FlowSpecDecoder(nn.Module):
             while i < len(self.flows):
                 f = self.flows[i]
                 nxt = self.flows[i + 1] if i + 1 < len(self.flows) else None
-                if (isinstance(f, ActNorm) and f.initialized and isinstance(nxt, InvConvNear) and not nxt.no_jacobian
+                cpl = self.flows[i + 2] if i + 2 < len(self.flows) else None
+                if (isinstance(f, ActNorm) and isinstance(nxt, InvConvNear) and isinstance(cpl, CouplingBlock)
+                        and convops.flow_block_eligible(f, nxt, cpl, x, g)):
+                    # the whole block [ActNorm, InvConvNear, CouplingBlock] as one autograd node, one native call each way
+                    wn = cpl.wn
+                    if not hasattr(cpl, "_block_plan"):
+                        cpl._block_plan = convops.FlowBlockPlan()
+                    drop, wn._drop_pre = getattr(wn, "_drop_pre", None), None
+                    cfg = (nxt.n_split, bool(cpl.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0,
+                           wn.dilation_rate, wn.n_layers, wn.hidden_channels)
+                    x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan,
+                                                  *convops.flow_block_params(f, nxt, cpl))
+                    i += 3
+                elif (isinstance(f, ActNorm) and f.initialized and isinstance(nxt, InvConvNear) and not nxt.no_jacobian
                         and nxt.n_split in (2, 4)):
                     # the two elementwise flows of a block in one pass over the tensor (ops.ActNormInvConvFn)
                     x, logdet = _actnorm_invconv_apply(x, m2, f.logs, f.bias, nxt.weight, x_len, nxt.n_split)

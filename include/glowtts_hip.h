@@ -7,7 +7,9 @@
  *
  * Conventions (all functions):
  *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
- *     no allocation, no ownership transfer, no hidden global state (re-entrant from autograd's backward thread);
+ *     no allocation, no ownership transfer; re-entrant from autograd's backward threads.  The only process-wide state
+ *     is the arithmetic mode of glowtts_conv_math (an explicit setter), per-device high-water marks of kernel LDS limits
+ *     and per-thread event rings / plane bindings;
  *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)
  *     holding 0/1 (the reference's (B,1,T) float mask viewed flat); log-determinants are fp32 (B);
  *   - `stream` is a hipStream_t (pass PyTorch's current stream): launches are asynchronous and ordered on it,
@@ -40,7 +42,8 @@ int glowtts_abi_version(void);
  * path  : (B, Tx, Ty) fp32, fully written with 0/1 (no pre-zeroing needed).
  * t_x,t_y: (B) int32 valid lengths (the reference derives them from the mask, __init__.py:18-19).
  * Bit-exact with the reference for identical `value` (one fp32 add per cell, max = (prev > cur) ? prev : cur,
- * max_neg_val = -1e9).  Limits: Tx <= 512.
+ * max_neg_val = -1e9).  Limits: Tx <= 2048 (the reference has none); lattices whose 1-bit back-pointer image exceeds the
+ * LDS (e.g. 500 x 4000) keep it in `path` until the path itself is written.
  */
 int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const int32_t *t_y,
                      int B, int Tx, int Ty, glowtts_stream_t stream);
@@ -235,6 +238,45 @@ int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, const float *x,
                    float *d_rs, float *d_xin, float *dx, const long long *unpack_desc, const int *unpack_prefix,
                    int n_conv, int total_rows, int B, int H, int T, int taps, int dil_rate, int two_source,
                    glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
+
+/* ---- a whole flow block per call (csrc/wn_stack.hip): [ActNorm, InvConvNear, CouplingBlock], models.py:176-190 ---------
+ * The launch sequence of one decoder block in the forward (training) direction, without conditioning input, n_split in
+ * {2, 4}.  `blk` is a HOST struct of DEVICE pointers; `layers` inside it a host array as for glowtts_wn_fwd.
+ * fwd : x (B,C,T) -> z (B,C,T), logdet (B) WRITTEN (ActNorm + InvConv + coupling terms summed).  Packs every convolution's
+ *       weights first (pack_desc: 2 + 2 n_layers rows, start / end / WN in-conv and res-skip per layer; NULL = the caller
+ *       has packed them), factorises W
+ *       into blk->w_inv / blk->logdet_w (kept for the backward), and writes the slabs the backward reads:
+ *       y (B,C,T) after the invertible 1x1, h0 (B,H,T) start-conv output, xs / acts / ts / skip as glowtts_wn_fwd,
+ *       out (B,C,T) end-conv output (m ; logs).
+ * bwd : dz (B,C,T), dlogdet (B) -> dx (B,C,T).  Workspaces: dy, dout (B,C,T), dskip (B,H,T), d_rs / d_xin / dx_wn as
+ *       glowtts_wn_bwd.  Packed weight gradients accumulate in blk->dwp_all (cleared here), are un-packed through the weight
+ *       norm into the parameters' gradient buffers by unpack_desc, bias gradients go to db_*, ActNorm / InvConv gradients
+ *       are ACCUMULATED into dlogs, dbias (C) and dw (n*n).  Weight-gradient kernels and the un-packing run on wgrad_stream
+ *       (NULL: `stream`); once everything queued there has run, every parameter gradient of the block is complete. */
+typedef struct glowtts_flow_block {
+    const float *logs, *bias, *w;                 /* ActNorm (C each), InvConvNear weight (n x n) */
+    float *w_inv, *logdet_w;                      /* n*n + 1 floats written by the forward, read by the backward */
+    const float *wf_start, *wb_start, *b_start;   /* packed 1x1 start conv (C/2 -> H), bias */
+    const float *wf_end, *wb_end, *b_end;         /* packed 1x1 end conv (H -> C), bias */
+    float *dwp_start, *dwp_end, *db_start, *db_end;
+    float *dlogs, *dbias, *dw;
+    const glowtts_wn_layer *layers;               /* host array, n_layers entries */
+    const long long *pack_desc, *unpack_desc;     /* device tables (glowtts_pack_weight_multi / _unpack_weight_grad_multi) */
+    const int *pack_prefix;                       /* device, n_conv + 1 entries */
+    float *dwp_all;                               /* all packed weight-gradient accumulators of the block, contiguous */
+    long long dwp_floats;
+    int n_layers, n_conv, total_rows, reserved;
+} glowtts_flow_block;
+int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
+                           const unsigned char *drop, float drop_scale, float *y, float *h0, float *xs, float *acts,
+                           float *ts, float *skip, float *out, float *z, float *logdet, int B, int C, int H, int T, int taps,
+                           int dil_rate, int n_split, int sigmoid_scale, glowtts_stream_t stream);
+int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
+                           const unsigned char *drop, float drop_scale, const float *y, const float *h0, const float *xs,
+                           const float *acts, const float *ts, const float *skip, const float *out, const float *dz,
+                           const float *dlogdet, float *dy, float *dout, float *dskip, float *d_rs, float *d_xin,
+                           float *dx_wn, float *dx, int B, int C, int H, int T, int taps, int dil_rate, int n_split,
+                           int sigmoid_scale, int two_source, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 
 /* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
  * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)

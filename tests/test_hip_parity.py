@@ -936,6 +936,60 @@ def test_wn_native_executor_matches_layer_by_layer_path(G):
             assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+@pytest.mark.parametrize("b,h,t,blocks,p_drop,sig", [(3, 192, 100, 2, 0.0, False), (2, 192, 64, 2, 0.05, False),
+                                                       (2, 48, 37, 3, 0.0, True)])
+def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig):
+    """convops.FlowBlockFn (a whole [ActNorm, InvConvNear, CouplingBlock] block queued from C, one autograd node) against
+    the per-operator path (five nodes per block): same kernels in the same order, so outputs agree to rounding of the
+    atomics; with dropout both draw the same keep-masks from the same generator state."""
+    from glow_tts_train import convops
+
+    torch.manual_seed(77)
+    dec = G.models.FlowSpecDecoder(80, h, kernel_size=5, dilation_rate=1, n_blocks=blocks, n_layers=3, p_dropout=p_drop,
+                                   n_split=4, n_sqz=2, sigmoid_scale=sig).cuda().train()
+    with torch.no_grad():
+        for f in dec.flows:
+            if hasattr(f, "end"):
+                f.end.weight.normal_(0, 0.02)
+            if hasattr(f, "logs"):
+                f.logs.normal_(0, 0.1)
+                f.bias.normal_(0, 0.1)
+    y0 = torch.randn(b, 80, 2 * t, device="cuda")
+    lens = torch.tensor([2 * t, 2 * t - 10, t][:b], device="cuda")
+    mask = (torch.arange(2 * t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
+    r = torch.randn(b, 80, 2 * t, device="cuda")
+    s = torch.randn(b, device="cuda")
+    res = {}
+    used = {}
+    orig = convops.FlowBlockFn.forward
+    for mode in ("both", "fwd"):                       # "fwd": the block executor declines, per-op path runs
+        convops._WN_NATIVE = mode
+        calls = []
+        convops.FlowBlockFn.forward = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
+        try:
+            for p in dec.parameters():
+                p.grad = torch.zeros_like(p)
+            torch.manual_seed(5)
+            y = (y0 * mask).clone().requires_grad_(True)
+            z, ld = dec(y, mask)
+            ((z * r).sum() + (ld * s).sum()).backward()
+            convops.flush_groups()
+            torch.cuda.synchronize()
+        finally:
+            convops._WN_NATIVE = "both"
+            convops.FlowBlockFn.forward = orig
+        used[mode] = len(calls)
+        res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), {k: p.grad.clone() for k, p in dec.named_parameters()})
+    assert used["both"] == blocks and used["fwd"] == 0, used
+    z1, l1, dx1, g1 = res["both"]
+    z0, l0, dx0, g0 = res["fwd"]
+    assert_close(z1, z0, what="z", rtol=1e-6, atol=1e-6)
+    assert_close(l1, l0, what="logdet", rtol=1e-6, atol=1e-4)
+    assert_close(dx1, dx0, what="dx", rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
+    for k in g0:
+        assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
+
+
 @pytest.mark.parametrize("b,h,t,k,nl,dil,prealloc", [
     (2, 16, 37, 5, 3, 1, False),      # rows not 16-byte aligned (T % 4 != 0): generic kernels
     (3, 48, 52, 3, 2, 2, True),       # dilation 2 (pipe wrw fallback), grads pre-allocated (direct sinks, no two-source)
