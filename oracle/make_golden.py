@@ -13,6 +13,7 @@ How the reference is made importable here:
     oracle/Makefile builds from the reference's own core.pyx where it lies.
 
 Usage:  make -C oracle ref && python oracle/make_golden.py          (writes tests/golden/*.npz)
+        python oracle/make_golden.py attention-long                  (only mha_c192_t240_w4 / mha_c64_t256_w4)
         python oracle/make_golden.py host                            (only the collate / table / config / checkpoint fixtures)
 
 This script must be run in its own process: it imports the reference under the package name `glow_tts_train`,
@@ -219,7 +220,14 @@ def gen_wn_gate_squeeze(R):
          mask_unsqz=npy(mu))
 
 
-def gen_attention(R):
+# the attention kernel's upper envelope (T = 240: config 5's text length; T = 256: the kernel's limit), added in round 2
+ATTENTION_LONG = [
+    ("mha_c192_t240_w4", 240, (240, 151), 4, None, 192),
+    ("mha_c64_t256_w4", 256, (256, 199), 4, None, 64),
+]
+
+
+def gen_attention(R, only_long=False):
     A = R.attentions
     cases = [
         ("mha_t12_w4", 12, (12, 7), 4, None),      # length > window+1 : pad branch (attentions.py:290-294)
@@ -236,7 +244,9 @@ def gen_attention(R):
         ("mha_c32_t5_w4", 5, (5, 2), 4, None, 32),
         ("mha_c32_t40_nowin", 40, (40, 17), None, None, 32),
         ("mha_c192_t160_w4", 160, (160, 101), 4, None, 192),
-    ]
+    ] + ATTENTION_LONG
+    if only_long:
+        cases = ATTENTION_LONG
     for name, t, lengths, win, blk, ch in cases:
         torch.manual_seed(1234)
         m = A.MultiHeadAttention(ch, ch, 2, window_size=win, p_dropout=0.0, block_length=blk)
@@ -557,6 +567,9 @@ def main():
     torch.use_deterministic_algorithms(False)
     if sys.argv[1:] == ["host"]:            # only the §8f-row-4 fixtures; the others stay as committed
         gen_host(R)
+        return
+    if sys.argv[1:] == ["attention-long"]:  # only the two long-sequence attention fixtures (round 2)
+        gen_attention(R, only_long=True)
         return
     gen_host(R)
     gen_mas(R)

@@ -6,6 +6,8 @@
 Tolerances: MAS bit-exact; fp32 kernels 1e-3 relative (BASELINE.json north_star) — most checks are far tighter and
 say so.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -32,6 +34,18 @@ def G():
     ns.hip, ns.attentions, ns.layers, ns.models = _hip, attentions, layers, models
     ns.mas, ns.ops, ns.optimize, ns.utils = monotonic_align, ops, optimize, utils
     return ns
+
+
+@pytest.fixture(params=["fp32", "bf16x6+wrw"])
+def conv_mode(request):
+    """Arithmetic of the WN-stack convolutions for the tests that exercise them against the reference's vectors / the
+    oracle: native fp32 MFMA and the fp32-equivalent bf16-plane form (csrc/convgemm_split.hip), SAME tolerances — so the
+    driver's own `pytest -m gpu` run covers both."""
+    from glow_tts_train import convops
+
+    before = convops.set_conv_math(request.param)
+    yield request.param
+    convops.set_conv_math(before)
 
 
 def dev(a, **kw):
@@ -240,6 +254,7 @@ def test_invconv_prepare_matches_torch(G):
     assert torch.isnan(G.ops.invconv_prepare(w.cuda())[1]).all()
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("name,sig,gin,k,dil,nl", [
     ("coupling_c8_h16_sig0_gin0", False, 0, 5, 1, 3),
     ("coupling_c8_h16_sig0_gin8", False, 8, 5, 1, 3),
@@ -269,6 +284,7 @@ def test_coupling_golden(G, name, sig, gin, k, dil, nl):
     assert_close(xr, g["x_rev"], what="x_rev", rtol=2e-4, atol=5e-5)
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("gin", [0, 8])
 def test_wn_golden(G, gin):
     g = load_golden(f"wn_h16_gin{gin}")
@@ -314,7 +330,8 @@ def test_gate_and_squeeze_golden(G):
 
 
 MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4",     # d_k = 8: torch path
-             "mha_c32_t70_w4", "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4"]     # MFMA kernel
+             "mha_c32_t70_w4", "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4",     # MFMA kernel
+             "mha_c192_t240_w4", "mha_c64_t256_w4"]      # ... at config 5's text length and at the kernel's size limit
 
 
 @pytest.mark.parametrize("name", MHA_CASES)
@@ -367,6 +384,7 @@ def _small_generator(G, tag):
     return m
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("tag", ["base", "spk"])
 def test_e2e_train_golden(G, tag):
     g = load_golden(f"e2e_{tag}_train")
@@ -409,6 +427,7 @@ def test_e2e_train_golden(G, tag):
     assert st[0] == 4.0 and st[1] == 4.0 and abs(float(st[2]) - g["lrs"][3]) <= 1e-6 * g["lrs"][3]
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("tag", ["base", "spk"])
 def test_e2e_generate_golden(G, tag):
     gt = load_golden(f"e2e_{tag}_train")
@@ -453,6 +472,7 @@ def _oracle_pair(G, hp, seed=11, end_std=0.05):
     return sd, m.cuda().train()
 
 
+@pytest.mark.usefixtures("conv_mode")
 def test_decoder_vs_oracle_config1_shapes(G):
     """FlowSpecDecoder forward + backward at BASELINE config 1 decoder shapes (B=8, 80 x 400, 6 blocks, H=192)."""
     from oracle import glow_oracle as O
@@ -488,6 +508,44 @@ def test_decoder_vs_oracle_config1_shapes(G):
     assert rel_err(yr, y * mask) < REL
 
 
+@pytest.mark.usefixtures("conv_mode")
+def test_generator_forward_vs_oracle_full_config2(G):
+    """FlowGenerator.forward + mle_loss at BASELINE configs[1] in full — B=32, T_text=160, T_mel=800, 12 flow blocks, 6
+    encoder layers, ragged lengths, dropout 0 — against the CPU oracle: z, log-det and the loss within 1e-3 relative
+    (north star), and the alignment search bit-exact when both sides are fed the oracle's own `logp` (SURVEY.md hard part
+    4: end to end, near-ties of `logp` may legitimately flip single frames)."""
+    from oracle import glow_oracle as O
+
+    hp = O.HParams(n_vocab=148)
+    assert hp.n_blocks_dec == 12 and hp.n_layers_enc == 6 and hp.hidden_channels == 192
+    sd, model = _oracle_pair(G, hp, seed=21)
+    torch.manual_seed(3)
+    b, tx, ty = 32, 160, 800
+    yl = torch.linspace(ty, ty // 2, b).long()
+    xl = (yl // 5).clamp(min=1)
+    x = torch.randint(1, 148, (b, tx)) * (torch.arange(tx)[None] < xl[:, None])
+    y = torch.randn(b, 80, ty) * (torch.arange(ty)[None, None] < yl[:, None, None])
+    with torch.no_grad():
+        (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = model(x.cuda(), xl.cuda(), y.cuda(), yl.cuda())
+        loss = G.utils.mle_loss(z, z_m, z_logs, logdet, z_mask)
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        (zo, zo_m, zo_logs, ldo, zo_mask), (xo_m, xo_logs, _), (attn_o, logw_o, _) = O.generator_forward(sd, hp, x, xl, y, yl)
+        loss_o = O.mle_loss(zo, zo_m, zo_logs, ldo, zo_mask)
+        errs = {"z": rel_err(z, zo), "logdet": rel_err(logdet, ldo), "x_m": rel_err(x_m, xo_m), "logw": rel_err(logw, logw_o),
+                "loss": abs(float(loss) - float(loss_o)) / abs(float(loss_o))}
+        assert all(v < REL for v in errs.values()), errs
+        # the search itself: same fp32 lattice in, same path out
+        logp_o = O.align_logp(xo_m, xo_logs, zo)
+        yl2 = (yl // 2) * 2
+        got = G.mas.maximum_path_lengths(logp_o.cuda(), xl.cuda(), yl2.cuda())
+        assert torch.equal(got.cpu(), attn_o.squeeze(1)), "MAS differs from the oracle on the oracle's own logp"
+        # end to end the two alignments may differ only where logp has near-ties
+        same = float((attn.cpu() == attn_o).float().mean())
+        frames_moved = float((attn.cpu() - attn_o).abs().sum() / 2)
+        assert same > 0.9999 and frames_moved <= 0.002 * float(yl2.sum()), (same, frames_moved)
+
+
+@pytest.mark.usefixtures("conv_mode")
 def test_full_step_vs_oracle_small_config(G):
     """Whole training step (forward, both losses, backward, clamp, Adam/Noam) vs the oracle, multi-speaker variant."""
     from oracle import glow_oracle as O
@@ -936,6 +994,7 @@ def test_wn_native_executor_matches_layer_by_layer_path(G):
             assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("b,h,t,blocks,p_drop,sig", [(3, 192, 100, 2, 0.0, False), (2, 192, 64, 2, 0.05, False),
                                                        (2, 48, 37, 3, 0.0, True)])
 def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig):
@@ -990,6 +1049,7 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
         assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("b,h,t,k,nl,dil,prealloc", [
     (2, 16, 37, 5, 3, 1, False),      # rows not 16-byte aligned (T % 4 != 0): generic kernels
     (3, 48, 52, 3, 2, 2, True),       # dilation 2 (pipe wrw fallback), grads pre-allocated (direct sinks, no two-source)

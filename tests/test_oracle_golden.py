@@ -197,7 +197,8 @@ def test_gate_and_squeeze():
 
 # ------------------------------------------------------------------------------------------------ attention
 MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4", "mha_c32_t70_w4",
-             "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4"]
+             "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4",
+             "mha_c192_t240_w4", "mha_c64_t256_w4"]
 
 
 @pytest.mark.parametrize("name", MHA_CASES)

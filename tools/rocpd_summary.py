@@ -25,15 +25,19 @@ def kernels(db, out):
 
 
 def counters(db, out, substr=""):
+    """Per (kernel, grid size): one kernel name covers several shapes (a conv template runs at the decoder's and at the
+    encoder's sizes), and a mean over them describes none; the grid size separates them."""
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
     name_col = "kernel_name" if "kernel_name" in cols else "name"
+    grid = "grid_size" if "grid_size" in cols else "0"
     rows = c.execute(
-        f"select {name_col}, counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
-        f"where {name_col} like ? group by {name_col}, counter_name order by 1, 2", (f"%{substr}%",)).fetchall()
+        f"select {name_col}, {grid}, counter_name, count(*), avg(value), min(value), max(value), avg(end - start) "
+        f"from counters_collection where {name_col} like ? group by {name_col}, {grid}, counter_name order by 1, 2, 3",
+        (f"%{substr}%",)).fetchall()
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch", "Min", "Max"])
+        w.writerow(["Kernel", "GridSize", "Counter", "Dispatches", "MeanPerDispatch", "Min", "Max", "MeanDurationNs"])
         w.writerows([(r[0][:160],) + tuple(r[1:]) for r in rows])
     print(f"{out}: {len(rows)} rows")
 
