@@ -77,6 +77,43 @@ template <> struct Vec<1> {
     __device__ __forceinline__ float operator[](int) const { return d; }
 };
 
+// Typed access for tensors that are fp32 or bf16 in HBM (B16): element offset `off`, V elements; arithmetic stays fp32.
+// bf16 -> fp32 is a shift; fp32 -> bf16 rounds to nearest even (v_cvt_pk_bf16_f32).
+typedef __bf16 bf16x2_io __attribute__((ext_vector_type(2)));
+typedef float f32x2_io __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned io_pack_bf16x2(float a, float b) {
+    const f32x2_io v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_io));
+}
+template <int V, bool B16> struct VecIO;
+template <int V> struct VecIO<V, false> {
+    static __device__ __forceinline__ Vec<V> load(const void *base, long off) { return Vec<V>::load(static_cast<const float *>(base) + off); }
+    static __device__ __forceinline__ void store(void *base, long off, const Vec<V> &v) { v.store(static_cast<float *>(base) + off); }
+};
+template <> struct VecIO<4, true> {
+    static __device__ __forceinline__ Vec<4> load(const void *base, long off) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(static_cast<const unsigned short *>(base) + off);
+        Vec<4> r;
+        r.d = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                          __uint_as_float(w.y & 0xffff0000u));
+        return r;
+    }
+    static __device__ __forceinline__ void store(void *base, long off, const Vec<4> &v) {
+        *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(base) + off) =
+            make_uint2(io_pack_bf16x2(v.d.x, v.d.y), io_pack_bf16x2(v.d.z, v.d.w));
+    }
+};
+template <> struct VecIO<1, true> {
+    static __device__ __forceinline__ Vec<1> load(const void *base, long off) {
+        Vec<1> r;
+        r.d = __uint_as_float((unsigned)static_cast<const unsigned short *>(base)[off] << 16);
+        return r;
+    }
+    static __device__ __forceinline__ void store(void *base, long off, const Vec<1> &v) {
+        static_cast<unsigned short *>(base)[off] = (unsigned short)(io_pack_bf16x2(v.d, 0.f) & 0xffffu);
+    }
+};
+
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // 16-byte path is legal when every row start is 16-B aligned: T % 4 == 0 and all bases aligned.

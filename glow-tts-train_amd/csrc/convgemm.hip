@@ -879,6 +879,7 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
     const bool pipe_ok = (p.T % 4 == 0) && aligned16(p.x) && (p.x_bs % 4 == 0) &&
                          (!p.mask_in || aligned16(p.mask)) && ((p.taps - 1) * p.dil <= 12) &&
                          (EPI != EPI_GATE || p.H % 4 == 0);
+    if (p.xb) return conv_bf16_dispatch(p, EPI, big, n5, pipe_ok, s);                     // bf16 tensors in HBM
     if (int rc = conv_split_dispatch(p, EPI, big, n5, pipe_ok, s); rc >= 0) return rc;   // opt-in bf16-plane arithmetic
     // Small problems (the text encoder: T = 160) give only ~190 workgroups with 80-frame tiles — less than one per CU.
     // 32-frame tiles fill the chip (480+ workgroups): -15..20 % on the encoder's 3-tap and 1-tap convs.  At the decoder's
@@ -960,64 +961,98 @@ static int check_conv_common(const char *name, const void *x, const void *wp, in
     return 0;
 }
 
-extern "C" int glowtts_conv_fwd(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
-                                const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T,
-                                int taps, int dil, int pad, int mask_in, int mask_out, int mask_add,
-                                glowtts_stream_t stream) {
+// `_io` forms: the same operators on bf16 tensors (io_x: x / second source; io_y: every tensor the epilogue reads or writes);
+// packed weights as always plus ONE bf16 plane bound to the calling thread (glowtts_conv_bind_planes_ns).  io 0 = fp32.
+extern "C" int glowtts_conv_fwd_io(const void *x, long x_bs, const float *wp, const float *bias, const float *mask,
+                                   const void *addend, long addend_bs, void *y, long y_bs, int B, int Cin, int M, int T,
+                                   int taps, int dil, int pad, int mask_in, int mask_out, int mask_add, int io_x, int io_y,
+                                   glowtts_stream_t stream) {
     if (int rc = check_conv_common("glowtts_conv_fwd", x, wp, B, Cin, M, T, taps, dil, pad)) return rc;
     GLOWTTS_CHECK_ARG(y, "glowtts_conv_fwd: null output");
     GLOWTTS_CHECK_ARG(!(mask_in || mask_out || mask_add) || mask, "glowtts_conv_fwd: mask flag without mask");
+    GLOWTTS_CHECK_ARG(io_x || !io_y, "glowtts_conv_fwd: bf16 results need bf16 operands (io_x = 1)");
     if ((long)B * T == 0) return 0;
     ConvGemmParams p{};
-    p.x = x; p.wp = wp; p.bias = bias; p.mask = mask; p.r0 = addend; p.y0 = y;
+    p.x = static_cast<const float *>(x); p.wp = wp; p.bias = bias; p.mask = mask; p.r0 = static_cast<const float *>(addend);
+    p.y0 = static_cast<float *>(y); p.xb = io_x; p.yb = io_y;
     p.x_bs = x_bs; p.y_bs = y_bs; p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
     p.mask_in = mask_in; p.mask_out = mask_out; p.mask_add = mask_add; p.r_bs = addend_bs;
     return addend ? dispatch_convgemm<EPI_ADD>(p, (hipStream_t)stream) : dispatch_convgemm<EPI_PLAIN>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, const float *cond,
-                                     const unsigned char *drop, float drop_scale, float *acts, float *ts, int B, int H,
-                                     int T, int taps, int dil, int pad, glowtts_stream_t stream) {
+extern "C" int glowtts_conv_fwd(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
+                                const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T,
+                                int taps, int dil, int pad, int mask_in, int mask_out, int mask_add,
+                                glowtts_stream_t stream) {
+    return glowtts_conv_fwd_io(x, x_bs, wp, bias, mask, addend, addend_bs, y, y_bs, B, Cin, M, T, taps, dil, pad, mask_in,
+                               mask_out, mask_add, 0, 0, stream);
+}
+
+extern "C" int glowtts_conv_gate_fwd_io(const void *x, const float *wp, const float *bias, const float *cond,
+                                        const unsigned char *drop, float drop_scale, void *acts, void *ts, int B, int H,
+                                        int T, int taps, int dil, int pad, int io, glowtts_stream_t stream) {
     if (int rc = check_conv_common("glowtts_conv_gate_fwd", x, wp, B, H, 2 * H, T, taps, dil, pad)) return rc;
     GLOWTTS_CHECK_ARG(acts, "glowtts_conv_gate_fwd: null output");
     GLOWTTS_CHECK_ARG(H % 4 == 0, "glowtts_conv_gate_fwd: hidden width %d must be a multiple of 4", H);
     if ((long)B * T == 0) return 0;
     ConvGemmParams p{};
-    p.x = x; p.wp = wp; p.bias = bias; p.cond = cond; p.drop = drop; p.drop_scale = drop_scale; p.y0 = acts; p.y1 = ts;
+    p.x = static_cast<const float *>(x); p.wp = wp; p.bias = bias; p.cond = cond; p.drop = drop; p.drop_scale = drop_scale;
+    p.y0 = static_cast<float *>(acts); p.y1 = static_cast<float *>(ts); p.xb = io; p.yb = io;
     p.x_bs = (long)H * T; p.B = B; p.Cin = H; p.M = 2 * H; p.H = H; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
     return dispatch_convgemm<EPI_GATE>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
-                                         const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B,
-                                         int H, int T, int last, glowtts_stream_t stream) {
+extern "C" int glowtts_conv_gate_fwd(const float *x, const float *wp, const float *bias, const float *cond,
+                                     const unsigned char *drop, float drop_scale, float *acts, float *ts, int B, int H,
+                                     int T, int taps, int dil, int pad, glowtts_stream_t stream) {
+    return glowtts_conv_gate_fwd_io(x, wp, bias, cond, drop, drop_scale, acts, ts, B, H, T, taps, dil, pad, 0, stream);
+}
+
+extern "C" int glowtts_conv_res_skip_fwd_io(const void *acts, const float *wp, const float *bias, const float *mask,
+                                            const void *x_in, const void *skip_in, void *x_out, void *skip_out, int B,
+                                            int H, int T, int last, int io, glowtts_stream_t stream) {
     const int M = last ? H : 2 * H;
     if (int rc = check_conv_common("glowtts_conv_res_skip_fwd", acts, wp, B, H, M, T, 1, 1, 0)) return rc;
     GLOWTTS_CHECK_ARG(mask && skip_out && (last || (x_in && x_out)), "glowtts_conv_res_skip_fwd: null pointer");
     if ((long)B * T == 0) return 0;
     ConvGemmParams p{};
-    p.x = acts; p.wp = wp; p.bias = bias; p.mask = mask; p.r0 = x_in; p.r1 = skip_in; p.y0 = x_out; p.y1 = skip_out;
+    p.x = static_cast<const float *>(acts); p.wp = wp; p.bias = bias; p.mask = mask; p.r0 = static_cast<const float *>(x_in);
+    p.r1 = static_cast<const float *>(skip_in); p.y0 = static_cast<float *>(x_out); p.y1 = static_cast<float *>(skip_out);
+    p.xb = io; p.yb = io;
     p.x_bs = (long)H * T; p.B = B; p.Cin = H; p.M = M; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
     return last ? dispatch_convgemm<EPI_RESSKIP_LAST>(p, (hipStream_t)stream)
                 : dispatch_convgemm<EPI_RESSKIP>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *d_rs2, const float *wp_b, const float *ts,
-                                     const unsigned char *drop, float drop_scale, float *d_pre, int B, int M_rs, int H,
-                                     int T, glowtts_stream_t stream) {
+extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, const float *bias, const float *mask,
+                                         const float *x_in, const float *skip_in, float *x_out, float *skip_out, int B,
+                                         int H, int T, int last, glowtts_stream_t stream) {
+    return glowtts_conv_res_skip_fwd_io(acts, wp, bias, mask, x_in, skip_in, x_out, skip_out, B, H, T, last, 0, stream);
+}
+
+extern "C" int glowtts_conv_gate_bwd_io(const void *d_rs, const void *d_rs2, const float *wp_b, const void *ts,
+                                        const unsigned char *drop, float drop_scale, void *d_pre, int B, int M_rs, int H,
+                                        int T, int io, glowtts_stream_t stream) {
     if (int rc = check_conv_common("glowtts_conv_gate_bwd", d_rs, wp_b, B, M_rs, H, T, 1, 1, 0)) return rc;
     GLOWTTS_CHECK_ARG(ts && d_pre, "glowtts_conv_gate_bwd: null pointer");
     GLOWTTS_CHECK_ARG(H % 4 == 0, "glowtts_conv_gate_bwd: hidden width %d must be a multiple of 4", H);
     if ((long)B * T == 0) return 0;
     ConvGemmParams p{};
-    p.x = d_rs; p.wp = wp_b; p.r0 = ts; p.drop = drop; p.drop_scale = drop_scale; p.y0 = d_pre;
+    p.x = static_cast<const float *>(d_rs); p.wp = wp_b; p.r0 = static_cast<const float *>(ts); p.drop = drop;
+    p.drop_scale = drop_scale; p.y0 = static_cast<float *>(d_pre); p.xb = io; p.yb = io;
     p.x_bs = (long)M_rs * T; p.B = B; p.Cin = M_rs; p.M = H; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
     if (d_rs2) {    // d_rs = rows [0, H) as (B,H,T), d_rs2 = rows [H, 2H) as (B,H,T): never concatenated in memory
         GLOWTTS_CHECK_ARG(M_rs == 2 * H && H % 96 == 0 && T % 4 == 0 && aligned16(d_rs) && aligned16(d_rs2),
                           "glowtts_conv_gate_bwd: two-source input needs M_rs == 2H, H %% 96 == 0, T %% 4 == 0, 16-byte rows");
-        p.x_bs = (long)H * T; p.x2 = d_rs2; p.x2_bs = (long)H * T; p.x_split = H;
+        p.x_bs = (long)H * T; p.x2 = static_cast<const float *>(d_rs2); p.x2_bs = (long)H * T; p.x_split = H;
     }
     return dispatch_convgemm<EPI_GATEBWD>(p, (hipStream_t)stream);
+}
+
+extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *d_rs2, const float *wp_b, const float *ts,
+                                     const unsigned char *drop, float drop_scale, float *d_pre, int B, int M_rs, int H,
+                                     int T, glowtts_stream_t stream) {
+    return glowtts_conv_gate_bwd_io(d_rs, d_rs2, wp_b, ts, drop, drop_scale, d_pre, B, M_rs, H, T, 0, stream);
 }
 
 extern "C" int glowtts_conv_wrw2(const float *x, long x_bs, const float *d, long d_bs, const float *d2, long d2_bs,

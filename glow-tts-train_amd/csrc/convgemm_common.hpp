@@ -43,12 +43,46 @@ struct ConvGemmParams {
     int mask_add;            // ADD: multiply the addend by mask
     int vec_epilogue;        // pipelined kernel: 16-byte epilogue through LDS (all epilogue tensors 16-byte aligned)
     float drop_scale;        // 1 / (1 - p)
+    int xb;                  // 1: x / x2 are bf16 tensors (same element indexing; convgemm_split.hip NS = 1 only)
+    int yb;                  // 1: the epilogue's tensors y0, y1, r0, r1 are bf16 (bias, mask, cond stay fp32)
+};
+
+// ---- element access of the epilogues: fp32 tensors, or bf16 tensors behind the same float* fields (p.yb) ------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {      // v_cvt_pk_bf16_f32, round to nearest even
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+template <bool B16> struct EpiIO;
+template <> struct EpiIO<false> {
+    static __device__ __forceinline__ float4 ld4(const float *base, long off) { return *reinterpret_cast<const float4 *>(base + off); }
+    static __device__ __forceinline__ void st4(float *base, long off, float4 v) { *reinterpret_cast<float4 *>(base + off) = v; }
+    static __device__ __forceinline__ float ld1(const float *base, long off) { return base[off]; }
+    static __device__ __forceinline__ void st1(float *base, long off, float v) { base[off] = v; }
+};
+template <> struct EpiIO<true> {
+    static __device__ __forceinline__ float4 ld4(const float *base, long off) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(base) + off);
+        return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                           __uint_as_float(w.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st4(float *base, long off, float4 v) {
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(base) + off) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+    static __device__ __forceinline__ float ld1(const float *base, long off) {
+        return __uint_as_float((unsigned)reinterpret_cast<const unsigned short *>(base)[off] << 16);
+    }
+    static __device__ __forceinline__ void st1(float *base, long off, float v) {
+        reinterpret_cast<unsigned short *>(base)[off] = (unsigned short)(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
 };
 
 // ---- shared epilogue: lane holds rows lk*4 + reg, column lrow of every 16x16 accumulator tile -------------------
-template <int RTW, int NCT, int EPI>
+template <int RTW, int NCT, int EPI, bool YB = false>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&acc)[RTW][NCT], int b, int t0, int tile_m,
                                               int wave, int lane) {
+    using E = EpiIO<YB>;
     constexpr int WGR = 64 * RTW;
     const int lrow = lane & 15, lk = lane >> 4;
     auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
@@ -71,8 +105,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                     }
                     if (p.cond) { vt += p.cond[(long)b * 2 * p.H + ch]; vs += p.cond[(long)b * 2 * p.H + p.H + ch]; }
                     const float th = fast_tanh(vt), sg = fast_sigmoid(vs);
-                    p.y0[((long)b * p.H + ch) * p.T + t] = th * sg;
-                    if (p.y1) { p.y1[ot] = th; p.y1[os] = sg; }
+                    E::st1(p.y0, ((long)b * p.H + ch) * p.T + t, th * sg);
+                    if (p.y1) { E::st1(p.y1, ot, th); E::st1(p.y1, os, sg); }
                 }
             }
         }
@@ -92,36 +126,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                 const float m = mk ? mk[t] : 1.f;
                 if (EPI == EPI_PLAIN) {
                     if (p.mask_out) v *= m;
-                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = v;
+                    E::st1(p.y0, (long)b * p.y_bs + (long)row * p.T + t, v);
                 } else if (EPI == EPI_ADD) {
-                    const float add = p.r0[(long)b * p.r_bs + (long)row * p.T + t];
+                    const float add = E::ld1(p.r0, (long)b * p.r_bs + (long)row * p.T + t);
                     const float sum = v + (p.mask_add ? add * m : add);
-                    p.y0[(long)b * p.y_bs + (long)row * p.T + t] = p.mask_out ? sum * m : sum;
+                    E::st1(p.y0, (long)b * p.y_bs + (long)row * p.T + t, p.mask_out ? sum * m : sum);
                 } else if (EPI == EPI_RESSKIP) {
                     // rows [0,H): residual -> next layer input ; rows [H,2H): skip accumulation  (layers.py:157-159)
                     if (row < p.H) {
                         const long o = ((long)b * p.H + row) * p.T + t;
-                        p.y0[o] = (p.r0[o] + v) * m;
+                        E::st1(p.y0, o, (E::ld1(p.r0, o) + v) * m);
                     } else {
                         const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
-                        p.y1[o] = (p.r1 ? p.r1[o] : 0.f) + v;
+                        E::st1(p.y1, o, (p.r1 ? E::ld1(p.r1, o) : 0.f) + v);
                     }
                 } else if (EPI == EPI_RESSKIP_LAST) {
                     // last layer: all H rows go to the skip sum, and WN's final `output * x_mask` is folded in (:161-162)
                     const long o = ((long)b * p.H + row) * p.T + t;
-                    p.y1[o] = ((p.r1 ? p.r1[o] : 0.f) + v) * m;
+                    E::st1(p.y1, o, ((p.r1 ? E::ld1(p.r1, o) : 0.f) + v) * m);
                 } else if (EPI == EPI_GATEBWD) {
                     // v = d(acts): chain through acts = tanh * sigmoid with the STORED values, then through the
                     // forward's dropout (utils.py:31-38, layers.py:147) -> d(pre-activation) rows ch and H + ch
                     const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
-                    const float th = p.r0[ot], sg = p.r0[os];
+                    const float th = E::ld1(p.r0, ot), sg = E::ld1(p.r0, os);
                     float dt = v * sg * (1.0f - th * th), ds = v * th * sg * (1.0f - sg);
                     if (p.drop) {
                         dt = p.drop[ot] ? dt * p.drop_scale : 0.f;
                         ds = p.drop[os] ? ds * p.drop_scale : 0.f;
                     }
-                    p.y0[ot] = dt;
-                    p.y0[os] = ds;
+                    E::st1(p.y0, ot, dt);
+                    E::st1(p.y0, os, ds);
                 }
             }
         }
@@ -220,9 +254,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(ConvGemmParams p) {
 // ---- vectorised epilogue for the pipelined kernel: accumulator tiles -> LDS [row][frame] -> every lane handles 4
 // consecutive frames of one row with 16-byte global loads / stores (the direct epilogue writes 64-byte row segments).
 // Needs T % 4 == 0 (a float4 is then entirely inside or outside the utterance).
-template <int RTW, int NCT, int EPI>
+template <int RTW, int NCT, int EPI, bool YB = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4 (&acc)[RTW][NCT], float *Ls, int b, int t0,
                                                   int tile_m, int wave, int lane) {
+    using E = EpiIO<YB>;
     constexpr int WGR = 64 * RTW, NT = 16 * NCT, LP = NT + 4, Q = NT / 4;
     const int lrow = lane & 15, lk = lane >> 4;
     auto ltile = [&](int r) -> int { return (EPI == EPI_GATE) ? (r == 0 ? wave : 4 + wave) : wave * RTW + r; };
@@ -235,8 +270,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
     __syncthreads();
     const int tid = threadIdx.x;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
-    auto ld4 = [](const float *q) { return *reinterpret_cast<const float4 *>(q); };
-    auto st4 = [](float *q, float4 v) { *reinterpret_cast<float4 *>(q) = v; };
+    auto ld4 = [](const float *q) { return *reinterpret_cast<const float4 *>(q); };      // fp32 only: LDS tile, mask
     if (EPI == EPI_GATE) {
         constexpr int NG = (64 * Q) / 256;               // = NCT items per thread; keep-mask bytes are fetched up front
         unsigned int kt[NG], ks[NG];
@@ -281,10 +315,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
             float th[4], sg[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { th[j] = fast_tanh(pt[j]); sg[j] = fast_sigmoid(ps[j]); }
-            st4(p.y0 + ((long)b * p.H + ch) * p.T + t, make_float4(th[0] * sg[0], th[1] * sg[1], th[2] * sg[2], th[3] * sg[3]));
+            E::st4(p.y0, ((long)b * p.H + ch) * p.T + t, make_float4(th[0] * sg[0], th[1] * sg[1], th[2] * sg[2], th[3] * sg[3]));
             if (p.y1) {
-                st4(p.y1 + ot, make_float4(th[0], th[1], th[2], th[3]));
-                st4(p.y1 + os, make_float4(sg[0], sg[1], sg[2], sg[3]));
+                E::st4(p.y1, ot, make_float4(th[0], th[1], th[2], th[3]));
+                E::st4(p.y1, os, make_float4(sg[0], sg[1], sg[2], sg[3]));
             }
         }
         return;
@@ -307,19 +341,19 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         ra[i] = zero4; rb[i] = zero4; ka[i] = 0x01010101u; kb[i] = 0x01010101u;
         rm[i] = mk ? ld4(mk + tc) : one4;
         if (EPI == EPI_ADD) {
-            ra[i] = ld4(p.r0 + (long)b * p.r_bs + (long)rc * p.T + tc);
+            ra[i] = E::ld4(p.r0, (long)b * p.r_bs + (long)rc * p.T + tc);
         } else if (EPI == EPI_RESSKIP) {
             const bool res = rc < p.H;
             const long o = ((long)b * p.H + (res ? rc : rc - p.H)) * p.T + tc;
             const float *src = res ? p.r0 : (p.r1 ? p.r1 : p.r0);
-            ra[i] = ld4(src + o);
+            ra[i] = E::ld4(src, o);
             if (!res && !p.r1) ra[i] = zero4;
         } else if (EPI == EPI_RESSKIP_LAST) {
-            if (p.r1) ra[i] = ld4(p.r1 + ((long)b * p.H + rc) * p.T + tc);
+            if (p.r1) ra[i] = E::ld4(p.r1, ((long)b * p.H + rc) * p.T + tc);
         } else if (EPI == EPI_GATEBWD) {
             const long ot = ((long)b * 2 * p.H + rc) * p.T + tc, os = ot + (long)p.H * p.T;
-            ra[i] = ld4(p.r0 + ot);
-            rb[i] = ld4(p.r0 + os);
+            ra[i] = E::ld4(p.r0, ot);
+            rb[i] = E::ld4(p.r0, os);
             if (p.drop) {
                 ka[i] = *reinterpret_cast<const unsigned int *>(p.drop + ot);
                 kb[i] = *reinterpret_cast<const unsigned int *>(p.drop + os);
@@ -337,24 +371,24 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         const float4 m = rm[i], a = ra[i];
         if (EPI == EPI_PLAIN) {
             if (p.mask_out) { v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, v);
+            E::st4(p.y0, (long)b * p.y_bs + (long)row * p.T + t, v);
         } else if (EPI == EPI_ADD) {
             float4 ad = a;
             if (p.mask_add) { ad.x *= m.x; ad.y *= m.y; ad.z *= m.z; ad.w *= m.w; }
             float4 o = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
             if (p.mask_out) { o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-            st4(p.y0 + (long)b * p.y_bs + (long)row * p.T + t, o);
+            E::st4(p.y0, (long)b * p.y_bs + (long)row * p.T + t, o);
         } else if (EPI == EPI_RESSKIP) {
             if (row < p.H) {
                 const long o = ((long)b * p.H + row) * p.T + t;
-                st4(p.y0 + o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
+                E::st4(p.y0, o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
             } else {
                 const long o = ((long)b * p.H + (row - p.H)) * p.T + t;
-                st4(p.y1 + o, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
+                E::st4(p.y1, o, make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w));
             }
         } else if (EPI == EPI_RESSKIP_LAST) {
             const long o = ((long)b * p.H + row) * p.T + t;
-            st4(p.y1 + o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
+            E::st4(p.y1, o, make_float4((a.x + v.x) * m.x, (a.y + v.y) * m.y, (a.z + v.z) * m.z, (a.w + v.w) * m.w));
         } else if (EPI == EPI_GATEBWD) {
             // v = d(acts): chain through acts = tanh * sigmoid with the STORED values, then through the forward's dropout
             const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
@@ -369,8 +403,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
                     ds[jj] = ((kb[i] >> (8 * jj)) & 0xffu) ? ds[jj] * p.drop_scale : 0.f;
                 }
             }
-            st4(p.y0 + ot, make_float4(dt[0], dt[1], dt[2], dt[3]));
-            st4(p.y0 + os, make_float4(ds[0], ds[1], ds[2], ds[3]));
+            E::st4(p.y0, ot, make_float4(dt[0], dt[1], dt[2], dt[3]));
+            E::st4(p.y0, os, make_float4(ds[0], ds[1], ds[2], ds[3]));
         }
     }
 }
@@ -396,6 +430,11 @@ struct ConvWrwParams {
 // convgemm_split.hip: the frame-packed weight-gradient kernel on bf16 planes; -1 = not handled
 int conv_wrw_split_dispatch(ConvWrwParams &p, hipStream_t s);
 int conv_wrw_planes_dispatch(ConvWrwParams &p, int ns, hipStream_t s);
+
+// convgemm_split.hip: bf16 TENSORS (p.xb): one bf16 plane of weights (bound with ns = 1), x loaded as bf16, the epilogue's
+// tensors bf16 or fp32 by p.yb; an error when the shape has no instantiation or no planes are bound (there is no
+// fp32 kernel that could read these tensors)
+int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s);
 
 // convgemm_split.hip: bf16-plane arithmetic for the forward-type kernels; -1 = not handled (mode off / weights not
 // registered / shape not instantiated), otherwise the launch's return code

@@ -85,9 +85,23 @@ __host__ __device__ constexpr int product_b(int ns, int k) {
     return ns == 3 ? (k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 1 : k == 4 ? 0 : 0) : (ns == 2 ? (k == 0 ? 1 : 0) : 0);
 }
 
-template <int NS, int RTW, int NCT, int EPI, int TAPS>
+// IOB: 0 = fp32 tensors (operands split / rounded while they are staged); 1 = x and the epilogue's tensors are bf16 in HBM
+// (NS = 1 only: nothing to split — 8-byte loads go to LDS as they are, results leave as bf16); 2 = x bf16, epilogue fp32
+// (the coupling's end conv: its output (m, logs) feeds the log-determinant and stays fp32).
+// NSA (bf16 tensors only): planes of the WEIGHTS.  1 = weights rounded to bf16; 3 = the exact fp32 weights as h + m + l
+// against the one activation plane (three MFMAs per step, small terms first) — used by the convolutions with fp32 results:
+// the coupling's end conv, whose `logs` rows are summed over every frame into the log-determinant (a weight rounding is
+// the only error there that repeats in every frame and so adds up coherently instead of averaging out), and the start
+// conv's input gradient that is added into an fp32 flow gradient.  Both are 1x1 convolutions: the two extra MFMAs per
+// step are noise in their run time.  (At configs[2] sizes the log-det error is dominated by the round-off of the stored
+// hidden tensors; this removes the one term that would grow with T.)
+template <int NS, int RTW, int NCT, int EPI, int TAPS, int IOB = 0, int NSA = NS>
 __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p, const unsigned short *__restrict__ wpl,
                                                                 long plane_stride) {
+    static_assert(IOB == 0 || NS == 1, "bf16 tensors carry one plane");
+    static_assert(IOB != 0 || NSA == NS, "operand planes pair up in the split arithmetic");
+    constexpr bool XB = IOB != 0, YB = IOB == 1;
+    constexpr int ES = XB ? 2 : 4;                   // bytes per activation element in HBM
     constexpr int WGR = 64 * RTW, NT = 16 * NCT, XC = NT + 16, KG = 6, G2C = KG / 2;
     constexpr int RP = 40;                           // bf16 per LDS row (32 used + 8 pad): 80 B = 20 dwords
     constexpr int PLANE16 = G2C * XC * RP;           // bf16 elements per plane image
@@ -127,9 +141,9 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
     // ---- weights: bf16 planes, element order of the fp32 packing; range-checked buffer loads (rows beyond M and groups
     // beyond G return zeros through an out-of-range offset)
     const int wbytes = TAPS * G * p.M * 32;          // one plane
-    __amdgpu_buffer_rsrc_t wrs[NS];
+    __amdgpu_buffer_rsrc_t wrs[NSA];
 #pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
+    for (int pl = 0; pl < NSA; ++pl)
         wrs[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(wpl + pl * plane_stride), 0, wbytes, 0x00020000);
     int wvo[RTW];
 #pragma unroll
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         wvo[r] = row_ok(lr) ? (grow(lr) * 16 + lk * 4) * 2 : wbytes;
     }
     const int wtap = G * p.M * 32, wgrp = p.M * 32;  // bytes
-    i32x4 a[3][RTW][NS];
+    i32x4 a[3][RTW][NSA];
     auto wload = [&](int c, int s, int slot) {       // weights of step s of chunk c (s may run past the chunk: next chunk)
         if (s >= S) { s -= S; c += 1; }
         const int g = c * KG + 2 * (s / TAPS), tap = s % TAPS;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 #pragma unroll
         for (int r = 0; r < RTW; ++r)
 #pragma unroll
-            for (int pl = 0; pl < NS; ++pl) {
+            for (int pl = 0; pl < NSA; ++pl) {
                 const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs[pl], wvo[r], so0, 0));
                 const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wrs[pl], wvo[r], so1, 0));
                 a[slot][r][pl] = i32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -156,27 +170,28 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 
     // ---- activations: the staging map of convgemm_wd_kernel (thread = channel kk of a group, frame quad qq, group
     // parity gsel; pieces (group gsel + 2 gi, quad qq + 8 jq)); the group pair of piece gi is gi, its half is gsel
-    const float *xb = p.x + (long)b * p.x_bs;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
     float *Ms = smem + NS * PLANE16 / 2;             // [XC]
     constexpr int NQ = (XC / 4 + 7) / 8, NG = KG / 2;
     static_assert(NQ * NG * 256 >= X4, "piece map covers the chunk");
     const int kk = tid & 15, qq = (tid >> 4) & 7, gsel = tid >> 7;
     const int c_first = p.x2 ? p.x_split : p.Cin;
-    const int xbytes = c_first * p.T * 4;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, xbytes, 0x00020000);
-    const int x2bytes = p.x2 ? (p.Cin - p.x_split) * p.T * 4 : 0;
+    const int xbytes = c_first * p.T * ES;
+    const char *xb8 = reinterpret_cast<const char *>(p.x) + (long)b * p.x_bs * ES;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb8), 0, xbytes, 0x00020000);
+    const int x2bytes = p.x2 ? (p.Cin - p.x_split) * p.T * ES : 0;
     const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.x2 ? p.x2 + (long)b * p.x2_bs : xb), 0, x2bytes, 0x00020000);
+        const_cast<char *>(p.x2 ? reinterpret_cast<const char *>(p.x2) + (long)b * p.x2_bs * ES : xb8), 0, x2bytes, 0x00020000);
     int xvo[NQ];
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq) {
         const int t = ts + (qq + 8 * jq) * 4;
         const bool ok = (qq + 8 * jq < XC / 4) && t >= 0 && t < p.T;
-        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * 4 : 0x7fffffff;
+        xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * ES : 0x7fffffff;
     }
     const int dbase = (qq * 4) * RP + (kk >> 2) * 8 + gsel * 4 + (kk & 3);     // bf16 index inside a plane image
-    f32x4 xreg[NG][NQ];
+    f32x4 xreg[XB ? 1 : NG][XB ? 1 : NQ];
+    i32x2 xregb[XB ? NG : 1][XB ? NQ : 1];           // bf16 tensors: 4 frames of one channel = 8 bytes
     if (p.mask_in && tid < XC) {
         const int t = ts + tid;
         Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
@@ -187,9 +202,14 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-            for (int jq = 0; jq < NQ; ++jq)
-                xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * 4, 0));
+            for (int jq = 0; jq < NQ; ++jq) {
+                if constexpr (XB)
+                    xregb[gi][jq] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * ES, 0));
+                else
+                    xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * ES, 0));
+            }
     };
     auto xstore = [&]() {
 #pragma unroll
@@ -197,17 +217,28 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 #pragma unroll
             for (int jq = 0; jq < NQ; ++jq)
                 if (qq + 8 * jq < XC / 4) {
-                    f32x4 v = xreg[gi][jq];
-                    if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
                     unsigned short *d = Xh + dbase + (gi * XC + 32 * jq) * RP;
+                    if constexpr (XB) {                  // already bf16: the 0 / 1 mask selects, nothing is rounded
+                        unsigned w0 = (unsigned)xregb[gi][jq][0], w1 = (unsigned)xregb[gi][jq][1];
+                        if (p.mask_in) {
+                            const f32x4 m = *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
+                            w0 = (m[0] != 0.f ? (w0 & 0xffffu) : 0u) | (m[1] != 0.f ? (w0 & 0xffff0000u) : 0u);
+                            w1 = (m[2] != 0.f ? (w1 & 0xffffu) : 0u) | (m[3] != 0.f ? (w1 & 0xffff0000u) : 0u);
+                        }
+                        d[0] = (unsigned short)w0; d[RP] = (unsigned short)(w0 >> 16);
+                        d[2 * RP] = (unsigned short)w1; d[3 * RP] = (unsigned short)(w1 >> 16);
+                    } else {
+                        f32x4 v = xreg[gi][jq];
+                        if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
 #pragma unroll
-                    for (int f = 0; f < 4; f += 2) {
-                        unsigned o[NS];
-                        split_planes2<NS>(v[f], v[f + 1], o);
+                        for (int f = 0; f < 4; f += 2) {
+                            unsigned o[NS];
+                            split_planes2<NS>(v[f], v[f + 1], o);
 #pragma unroll
-                        for (int pl = 0; pl < NS; ++pl) {
-                            d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
-                            d[pl * PLANE16 + (f + 1) * RP] = (unsigned short)(o[pl] >> 16);
+                            for (int pl = 0; pl < NS; ++pl) {
+                                d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
+                                d[pl * PLANE16 + (f + 1) * RP] = (unsigned short)(o[pl] >> 16);
+                            }
                         }
                     }
                 }
@@ -242,12 +273,20 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
                 if (q + 1 < S * NCT) bfetch(q + 1, (q + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);  // the next tile's LDS reads stay ahead of this tile's MFMAs
 #pragma unroll
-                for (int r = 0; r < RTW; ++r)
+                for (int r = 0; r < RTW; ++r) {
+                    if constexpr (IOB != 0) {
 #pragma unroll
-                    for (int k = 0; k < n_products(NS); ++k)
-                        acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, a[s % 3][r][product_a(NS, k)]),
-                            __builtin_bit_cast(bf16x8, bv[q & 1][product_b(NS, k)]), acc[r][cc], 0, 0, 0);
+                        for (int k = NSA - 1; k >= 0; --k)          // weight planes l, m, h against the one activation plane
+                            acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[s % 3][r][k]), __builtin_bit_cast(bf16x8, bv[q & 1][0]), acc[r][cc], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < n_products(NS); ++k)
+                            acc[r][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a[s % 3][r][product_a(NS, k)]),
+                                __builtin_bit_cast(bf16x8, bv[q & 1][product_b(NS, k)]), acc[r][cc], 0, 0, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             wload(c, s + 3, s % 3);                 // refill the slot just consumed: three steps of lead
@@ -263,9 +302,9 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         GLOWTTS_TRACE_POINT(3 + 2 * (c & 3));
     }
     if (p.vec_epilogue) {
-        conv_epilogue_lds<RTW, NCT, EPI>(p, acc, smem, b, t0, tile_m, wave, lane);
+        conv_epilogue_lds<RTW, NCT, EPI, YB>(p, acc, smem, b, t0, tile_m, wave, lane);
     } else {
-        conv_epilogue<RTW, NCT, EPI>(p, acc, b, t0, tile_m, wave, lane);
+        conv_epilogue<RTW, NCT, EPI, YB>(p, acc, b, t0, tile_m, wave, lane);
     }
     GLOWTTS_TRACE_POINT(10);
 }
@@ -607,7 +646,7 @@ static bool find_planes(const float *wp, int ns, const unsigned short **out, lon
     return true;
 }
 
-template <int NS, int RTW, int NCT, int EPI, int TAPS>
+template <int NS, int RTW, int NCT, int EPI, int TAPS, int IOB = 0, int NSA = NS>
 static int launch_split(ConvGemmParams &p, const unsigned short *planes, long stride, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;
     constexpr size_t lds_pipe = (size_t)NS * 3 * (NT + 16) * 80 + (size_t)(NT + 16) * sizeof(float);
@@ -617,13 +656,34 @@ static int launch_split(ConvGemmParams &p, const unsigned short *planes, long st
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>), lds, "glowtts_conv (split)")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS, IOB, NSA>), lds, "glowtts_conv (split)")) return rc_;
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
     dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
-    hipLaunchKernelGGL((convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS>), grid, dim3(256), lds, s, p, planes, stride);
+    hipLaunchKernelGGL((convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS, IOB, NSA>), grid, dim3(256), lds, s, p, planes, stride);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv (split)");
+}
+
+// bf16 tensors: the instantiations a flow block needs (csrc/wn_stack.hip, io = 1)
+template <int IOB>
+static int dispatch_bf16_io(ConvGemmParams &p, int epi, bool big, bool n5, const unsigned short *pl, long st, hipStream_t s) {
+#define GLOWTTS_BF16_CASE(E, R, TP)                                                    \
+    if (epi == E && (R == 2) == big && p.taps == TP)                                   \
+        return n5 ? launch_split<1, R, 5, E, TP, IOB, (IOB == 2 ? 3 : 1)>(p, pl, st, s)  \
+                  : launch_split<1, R, 4, E, TP, IOB, (IOB == 2 ? 3 : 1)>(p, pl, st, s);
+    GLOWTTS_BF16_CASE(EPI_PLAIN, 1, 1)       // fp32 results (IOB == 2): exact weights, three planes
+    GLOWTTS_BF16_CASE(EPI_ADD, 1, 1)         // ... and the start conv's input gradient added into an fp32 flow gradient
+    if constexpr (IOB == 1) {
+        GLOWTTS_BF16_CASE(EPI_GATE, 2, 5)
+        GLOWTTS_BF16_CASE(EPI_RESSKIP, 2, 1)
+        GLOWTTS_BF16_CASE(EPI_RESSKIP_LAST, 1, 1)
+        GLOWTTS_BF16_CASE(EPI_GATEBWD, 1, 1)
+        GLOWTTS_BF16_CASE(EPI_ADD, 1, 5)
+        GLOWTTS_BF16_CASE(EPI_PLAIN, 1, 5)
+    }
+#undef GLOWTTS_BF16_CASE
+    return -1;
 }
 
 template <int NS>
@@ -680,6 +740,9 @@ int conv_wrw_planes_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     const bool n5 = (p.T % 80 == 0) || ((p.T + 79) / 80) * 80 <= ((p.T + 63) / 64) * 64;
     if (ns == 3 && p.taps == 5 && p.M % 32 == 0) return n5 ? launch_wrw_planes<3, 5, 5, 2>(p, s) : launch_wrw_planes<3, 5, 4, 2>(p, s);
     if (ns == 3 && p.taps == 1) return n5 ? launch_wrw_planes<3, 1, 5, 4>(p, s) : launch_wrw_planes<3, 1, 4, 4>(p, s);
+    // one plane = the tensors ARE bf16 (flow blocks with bf16 activations in HBM)
+    if (ns == 1 && p.taps == 5 && p.M % 32 == 0) return n5 ? launch_wrw_planes<1, 5, 5, 2>(p, s) : launch_wrw_planes<1, 5, 4, 2>(p, s);
+    if (ns == 1 && p.taps == 1) return n5 ? launch_wrw_planes<1, 1, 5, 4>(p, s) : launch_wrw_planes<1, 1, 4, 4>(p, s);
     return -1;
 }
 
@@ -699,6 +762,18 @@ int conv_wrw_split_dispatch(ConvWrwParams &p, hipStream_t s) {
     if (ns == 2) return dispatch_wrw_split_ns<2>(p, s);
     if (ns == 1) return dispatch_wrw_split_ns<1>(p, s);
     return -1;
+}
+
+int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s) {
+    GLOWTTS_CHECK_ARG(pipe_ok && (p.T % 4) == 0, "glowtts_conv (bf16 tensors): needs T %% 4 == 0 and 16-byte aligned rows");
+    const unsigned short *pl = nullptr;
+    long st = 0;
+    GLOWTTS_CHECK_ARG(find_planes(p.wp, 3, &pl, &st), "glowtts_conv (bf16 tensors): the packed weights have no bf16 planes bound "
+                      "(glowtts_split_planes(wp, n, planes, 3) + glowtts_conv_bind_planes_ns(wp, n, planes, 3))");
+    const int rc = p.yb ? dispatch_bf16_io<1>(p, epi, big, n5, pl, st, s) : dispatch_bf16_io<2>(p, epi, big, n5, pl, st, s);
+    GLOWTTS_CHECK_ARG(rc >= 0, "glowtts_conv (bf16 tensors): no kernel for epilogue %d, taps %d, M %d, output %s", epi, p.taps, p.M,
+                      p.yb ? "bf16" : "fp32");
+    return rc;
 }
 
 // called first by dispatch_convgemm: -1 = not handled here (mode off, weights not registered, shape not instantiated)
@@ -742,6 +817,15 @@ extern "C" int glowtts_conv_bind_planes(const float *wp, long n, const unsigned 
     t_bound.n = wp ? n : 0;
     t_bound.planes = wp ? planes : nullptr;
     t_bound.ns = wp ? g_conv_math : 0;           // the planes were written for the mode in force now
+    return 0;
+}
+
+extern "C" int glowtts_conv_bind_planes_ns(const float *wp, long n, const unsigned short *planes, int n_planes) {
+    GLOWTTS_CHECK_ARG(wp == nullptr || (planes && n > 0 && n_planes >= 1 && n_planes <= 3), "glowtts_conv_bind_planes_ns: bad arguments");
+    t_bound.wp = wp;
+    t_bound.n = wp ? n : 0;
+    t_bound.planes = wp ? planes : nullptr;
+    t_bound.ns = wp ? n_planes : 0;
     return 0;
 }
 

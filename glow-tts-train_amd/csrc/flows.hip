@@ -297,12 +297,16 @@ __global__ __launch_bounds__(256) void invconv_bwd_kernel(const float *__restric
 //   bwd : gz = dz mask ; dy = W^T gz ; dW += gz y^T ; dym = dy mask ; dx = dym exp(logs) ; dlogs += dym exp(logs) x ;
 //         dbias += dym   (+ the log-det terms)                                      traffic: fwd 2X, bwd 3X  (was 4X / 6X)
 // ------------------------------------------------------------------------------------------------------------
-template <int N, int V>
-__global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+template <int N, int V, bool B16 = false>
+__global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const void *__restrict__ x, const float *__restrict__ mask,
                                                                   const float *__restrict__ logs, const float *__restrict__ bias,
                                                                   const float *__restrict__ w, const float *__restrict__ logdet_w,
-                                                                  const float *__restrict__ x_len, float *__restrict__ z,
-                                                                  float *__restrict__ logdet, int B, int C, int T) {
+                                                                  const float *__restrict__ x_len, void *__restrict__ z,
+                                                                  float *__restrict__ logdet, int B, int C, int T,
+                                                                  void *__restrict__ z0h) {
+    // z0h (optional): a bf16 copy (B, C/2, T) of the FIRST half of z — what the coupling's start conv reads when the
+    // hidden tensors are bf16 but the flow tensor itself stays fp32
+    using IO = VecIO<V, B16>;
     __shared__ float red[4];
     const int TV = T / V;
     const int G = C / N;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const float *_
         for (int k = 0; k < N; ++k) {
             const int ch = invconv_channel<N>(k, g, C);
             const float e = expf(logs[ch]), bi = bias[ch];
-            Vec<V> xv = Vec<V>::load(x + ((long)b * C + ch) * T + (long)tv * V);
+            Vec<V> xv = IO::load(x, ((long)b * C + ch) * T + (long)tv * V);
 #pragma unroll
             for (int j = 0; j < V; ++j) y[k][j] = (bi + e * xv[j]) * mv[j];
         }
@@ -336,7 +340,9 @@ __global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const float *_
                 for (int k = 0; k < N; ++k) s += wr[o * N + k] * y[k][j];
                 acc[j] = s * mv[j];
             }
-            acc.store(z + ((long)b * C + invconv_channel<N>(o, g, C)) * T + (long)tv * V);
+            const int cho = invconv_channel<N>(o, g, C);
+            IO::store(z, ((long)b * C + cho) * T + (long)tv * V, acc);
+            if (z0h != nullptr && cho < C / 2) VecIO<V, true>::store(z0h, ((long)b * (C / 2) + cho) * T + (long)tv * V, acc);
         }
     }
     if (logdet != nullptr && blockIdx.x == 0) {
@@ -350,14 +356,15 @@ __global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const float *_
 
 // grid (G, slabs): every thread of a workgroup works on the same channel group, so the 2N per-channel sums and the N*N
 // matrix sums reduce inside the workgroup and leave as one atomic each.
-template <int N, int V>
-__global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+template <int N, int V, bool B16 = false>
+__global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const void *__restrict__ x, const float *__restrict__ mask,
                                                                   const float *__restrict__ logs, const float *__restrict__ bias,
                                                                   const float *__restrict__ w, const float *__restrict__ w_inv,
-                                                                  const float *__restrict__ dz, const float *__restrict__ dlogdet,
-                                                                  const float *__restrict__ x_len, float *__restrict__ dx,
+                                                                  const void *__restrict__ dz, const float *__restrict__ dlogdet,
+                                                                  const float *__restrict__ x_len, void *__restrict__ dx,
                                                                   float *__restrict__ dlogs, float *__restrict__ dbias,
                                                                   float *__restrict__ dw, int B, int C, int T, int nb) {
+    using IO = VecIO<V, B16>;
     const int TV = T / V;
     const int g = blockIdx.x;
     const int b0 = blockIdx.y * nb, b1 = min(B, b0 + nb);
@@ -383,8 +390,8 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const float *_
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const long off = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
-            xv[k] = Vec<V>::load(x + off);
-            gz[k] = Vec<V>::load(dz + off);
+            xv[k] = IO::load(x, off);
+            gz[k] = IO::load(dz, off);
 #pragma unroll
             for (int j = 0; j < V; ++j) gz[k][j] *= mv[j];
         }
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const float *_
                 al[k] += dym * e[k] * xv[k][j];
                 ab[k] += dym;
             }
-            o.store(dx + ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V);
+            IO::store(dx, ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V, o);
         }
     }
     // one LDS round for all 2N + N*N sums, then ONE atomic instruction per output cache line: same-line float atomics
@@ -454,10 +461,11 @@ __device__ __forceinline__ float coupling_logs(float raw, bool sig) {
 }
 
 // grid (chunks, B): each workgroup stays inside one utterance so logdet[b] takes one atomic per workgroup.
-template <int V, bool REV>
-__global__ __launch_bounds__(256) void coupling_fwd_kernel(const float *__restrict__ x, const float *__restrict__ out,
-                                                           const float *__restrict__ mask, float *__restrict__ z,
+template <int V, bool REV, bool B16 = false>
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(const void *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ mask, void *__restrict__ z,
                                                            float *__restrict__ logdet, int C, int T, int sig) {
+    using IO = VecIO<V, B16>;
     __shared__ float red[4];
     const int b = blockIdx.y;
     const int TV = T / V;
@@ -468,8 +476,8 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(const float *__restri
         const int c = i / TV, tv = i % TV;
         const long o0 = ((long)b * C + c) * T + (long)tv * V;
         const long o1 = o0 + (long)half * T;
-        Vec<V> x0 = Vec<V>::load(x + o0);
-        Vec<V> x1 = Vec<V>::load(x + o1);
+        Vec<V> x0 = IO::load(x, o0);
+        Vec<V> x1 = IO::load(x, o1);
         Vec<V> m = Vec<V>::load(out + o0);
         Vec<V> lr = Vec<V>::load(out + o1);
         Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
@@ -484,8 +492,8 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(const float *__restri
                 ld += l * mv[j];
             }
         }
-        x0.store(z + o0);
-        z1.store(z + o1);
+        IO::store(z, o0, x0);
+        IO::store(z, o1, z1);
     }
     if (!REV) {
         ld = block_sum_256(ld, red);
@@ -493,11 +501,12 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(const float *__restri
     }
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void coupling_bwd_kernel(const float *__restrict__ x, const float *__restrict__ out,
-                                                           const float *__restrict__ mask, const float *__restrict__ dz,
-                                                           const float *__restrict__ dlogdet, float *__restrict__ dx,
-                                                           float *__restrict__ dout, int C, int T, int sig) {
+template <int V, bool B16 = false, bool D16 = B16>      // B16: flow tensors (x, dz, dx) bf16 ; D16: dout bf16
+__global__ __launch_bounds__(256) void coupling_bwd_kernel(const void *__restrict__ x, const float *__restrict__ out,
+                                                           const float *__restrict__ mask, const void *__restrict__ dz,
+                                                           const float *__restrict__ dlogdet, void *__restrict__ dx,
+                                                           void *__restrict__ dout, int C, int T, int sig) {
+    using IO = VecIO<V, B16>;
     const int b = blockIdx.y;
     const int TV = T / V;
     const int half = C / 2;
@@ -507,10 +516,10 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float *__restri
         const int c = i / TV, tv = i % TV;
         const long o0 = ((long)b * C + c) * T + (long)tv * V;
         const long o1 = o0 + (long)half * T;
-        Vec<V> x1 = Vec<V>::load(x + o1);
+        Vec<V> x1 = IO::load(x, o1);
         Vec<V> lr = Vec<V>::load(out + o1);
-        Vec<V> g0 = Vec<V>::load(dz + o0);
-        Vec<V> g1 = Vec<V>::load(dz + o1);
+        Vec<V> g0 = IO::load(dz, o0);
+        Vec<V> g1 = IO::load(dz, o1);
         Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
         Vec<V> dx1, dm, dl;
 #pragma unroll
@@ -528,10 +537,10 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float *__restri
             }
             dl[j] = dlp;
         }
-        g0.store(dx + o0);
-        dx1.store(dx + o1);
-        dm.store(dout + o0);
-        dl.store(dout + o1);
+        IO::store(dx, o0, g0);
+        IO::store(dx, o1, dx1);
+        VecIO<V, D16>::store(dout, o0, dm);
+        VecIO<V, D16>::store(dout, o1, dl);
     }
 }
 
@@ -664,8 +673,10 @@ extern "C" int glowtts_invconv_bwd(const float *x, const float *mask, const floa
     GLOWTTS_LAUNCH_CHECK("glowtts_invconv_bwd");
 }
 
-extern "C" int glowtts_coupling_fwd(const float *x, const float *out, const float *mask, float *z, float *logdet,
-                                    int B, int C, int T, int sigmoid_scale, int reverse, glowtts_stream_t stream) {
+// `_io` forms: io = 1 -> the flow tensors (x, z / dz, dx, and dout) are bf16 in HBM; (m, logs) = `out`, masks, log-dets
+// and all arithmetic stay fp32
+extern "C" int glowtts_coupling_fwd_io(const void *x, const float *out, const float *mask, void *z, float *logdet,
+                                       int B, int C, int T, int sigmoid_scale, int reverse, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && out && mask && z, "glowtts_coupling_fwd: null pointer");
     GLOWTTS_CHECK_ARG(reverse || logdet, "glowtts_coupling_fwd: forward needs logdet");
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && (C % 2) == 0 && T >= 0, "glowtts_coupling_fwd: bad shape");
@@ -677,19 +688,25 @@ extern "C" int glowtts_coupling_fwd(const float *x, const float *out, const floa
     const int gmax = reverse ? 64 : 16;          // forward: one logdet[b] atomic per workgroup, same cache line for 16 b
     if (gx > gmax) gx = gmax;
     dim3 grid(gx, B);
-    if (reverse) {
-        if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, true>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
-        else    hipLaunchKernelGGL((coupling_fwd_kernel<1, true>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
-    } else {
-        if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, false>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
-        else    hipLaunchKernelGGL((coupling_fwd_kernel<1, false>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale);
-    }
+#define GLOWTTS_CPL(REV, B16)                                                                                                      \
+    do {                                                                                                                            \
+        if (v4) hipLaunchKernelGGL((coupling_fwd_kernel<4, REV, B16>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale); \
+        else    hipLaunchKernelGGL((coupling_fwd_kernel<1, REV, B16>), grid, dim3(256), 0, s, x, out, mask, z, logdet, C, T, sigmoid_scale); \
+    } while (0)
+    if (io) { if (reverse) GLOWTTS_CPL(true, true); else GLOWTTS_CPL(false, true); }
+    else    { if (reverse) GLOWTTS_CPL(true, false); else GLOWTTS_CPL(false, false); }
+#undef GLOWTTS_CPL
     GLOWTTS_LAUNCH_CHECK("glowtts_coupling_fwd");
 }
 
-extern "C" int glowtts_coupling_bwd(const float *x, const float *out, const float *mask, const float *dz,
-                                    const float *dlogdet, float *dx, float *dout, int B, int C, int T,
-                                    int sigmoid_scale, glowtts_stream_t stream) {
+extern "C" int glowtts_coupling_fwd(const float *x, const float *out, const float *mask, float *z, float *logdet,
+                                    int B, int C, int T, int sigmoid_scale, int reverse, glowtts_stream_t stream) {
+    return glowtts_coupling_fwd_io(x, out, mask, z, logdet, B, C, T, sigmoid_scale, reverse, 0, stream);
+}
+
+extern "C" int glowtts_coupling_bwd_io(const void *x, const float *out, const float *mask, const void *dz,
+                                       const float *dlogdet, void *dx, void *dout, int B, int C, int T,
+                                       int sigmoid_scale, int io, int io_dout, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && out && mask && dz && dx && dout, "glowtts_coupling_bwd: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && (C % 2) == 0 && T >= 0, "glowtts_coupling_bwd: bad shape");
     if ((long)B * C * T == 0) return 0;
@@ -699,25 +716,45 @@ extern "C" int glowtts_coupling_bwd(const float *x, const float *out, const floa
     int gx = cdiv(items, 256);
     if (gx > 64) gx = 64;
     dim3 grid(gx, B);
-    if (v4) hipLaunchKernelGGL((coupling_bwd_kernel<4>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
-    else    hipLaunchKernelGGL((coupling_bwd_kernel<1>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale);
+    GLOWTTS_CHECK_ARG(!io || io_dout, "glowtts_coupling_bwd: bf16 flow tensors go with a bf16 dout");
+#define GLOWTTS_CPB(B16, D16)                                                                                                       \
+    do {                                                                                                                             \
+        if (v4) hipLaunchKernelGGL((coupling_bwd_kernel<4, B16, D16>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale); \
+        else    hipLaunchKernelGGL((coupling_bwd_kernel<1, B16, D16>), grid, dim3(256), 0, s, x, out, mask, dz, dlogdet, dx, dout, C, T, sigmoid_scale); \
+    } while (0)
+    if (io) GLOWTTS_CPB(true, true);
+    else if (io_dout) GLOWTTS_CPB(false, true);
+    else GLOWTTS_CPB(false, false);
+#undef GLOWTTS_CPB
     GLOWTTS_LAUNCH_CHECK("glowtts_coupling_bwd");
 }
 
-#define FUSED_DISPATCH(KERNEL, GRID, ...)                                                               \
+extern "C" int glowtts_coupling_bwd(const float *x, const float *out, const float *mask, const float *dz,
+                                    const float *dlogdet, float *dx, float *dout, int B, int C, int T,
+                                    int sigmoid_scale, glowtts_stream_t stream) {
+    return glowtts_coupling_bwd_io(x, out, mask, dz, dlogdet, dx, dout, B, C, T, sigmoid_scale, 0, 0, stream);
+}
+
+#define FUSED_DISPATCH_T(KERNEL, B16, GRID, ...)                                                        \
     do {                                                                                                \
         if (n_split == 4) {                                                                             \
-            if (v4) hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
-            else    hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+            if (v4) hipLaunchKernelGGL((KERNEL<4, 4, B16>), GRID, dim3(256), 0, s, __VA_ARGS__);        \
+            else    hipLaunchKernelGGL((KERNEL<4, 1, B16>), GRID, dim3(256), 0, s, __VA_ARGS__);        \
         } else {                                                                                        \
-            if (v4) hipLaunchKernelGGL((KERNEL<2, 4>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
-            else    hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+            if (v4) hipLaunchKernelGGL((KERNEL<2, 4, B16>), GRID, dim3(256), 0, s, __VA_ARGS__);        \
+            else    hipLaunchKernelGGL((KERNEL<2, 1, B16>), GRID, dim3(256), 0, s, __VA_ARGS__);        \
         }                                                                                               \
     } while (0)
+#define FUSED_DISPATCH(KERNEL, GRID, ...)                                                               \
+    do {                                                                                                \
+        if (io) FUSED_DISPATCH_T(KERNEL, true, GRID, __VA_ARGS__);                                      \
+        else    FUSED_DISPATCH_T(KERNEL, false, GRID, __VA_ARGS__);                                     \
+    } while (0)
 
-extern "C" int glowtts_actnorm_invconv_fwd(const float *x, const float *mask, const float *logs, const float *bias,
-                                           const float *w, const float *logdet_w, const float *x_len, float *z,
-                                           float *logdet, int B, int C, int T, int n_split, glowtts_stream_t stream) {
+extern "C" int glowtts_actnorm_invconv_fwd_io(const void *x, const float *mask, const float *logs, const float *bias,
+                                              const float *w, const float *logdet_w, const float *x_len, void *z,
+                                              float *logdet, void *z0h, int B, int C, int T, int n_split, int io,
+                                              glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && mask && logs && bias && w && z, "glowtts_actnorm_invconv_fwd: null pointer");
     GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_actnorm_invconv_fwd: n_split=%d (fused path: 2 or 4)", n_split);
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_actnorm_invconv_fwd: bad shape");
@@ -727,14 +764,20 @@ extern "C" int glowtts_actnorm_invconv_fwd(const float *x, const float *mask, co
     const bool v4 = can_vec4(T, {x, mask, z});
     const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
     dim3 grid(cdiv(n, 256));
-    FUSED_DISPATCH(actnorm_invconv_fwd_kernel, grid, x, mask, logs, bias, w, logdet_w, x_len, z, logdet, B, C, T);
+    FUSED_DISPATCH(actnorm_invconv_fwd_kernel, grid, x, mask, logs, bias, w, logdet_w, x_len, z, logdet, B, C, T, z0h);
     GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_invconv_fwd");
 }
 
-extern "C" int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *logs, const float *bias,
-                                           const float *w, const float *w_inv, const float *dz, const float *dlogdet,
-                                           const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B,
-                                           int C, int T, int n_split, glowtts_stream_t stream) {
+extern "C" int glowtts_actnorm_invconv_fwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                           const float *w, const float *logdet_w, const float *x_len, float *z,
+                                           float *logdet, int B, int C, int T, int n_split, glowtts_stream_t stream) {
+    return glowtts_actnorm_invconv_fwd_io(x, mask, logs, bias, w, logdet_w, x_len, z, logdet, nullptr, B, C, T, n_split, 0, stream);
+}
+
+extern "C" int glowtts_actnorm_invconv_bwd_io(const void *x, const float *mask, const float *logs, const float *bias,
+                                              const float *w, const float *w_inv, const void *dz, const float *dlogdet,
+                                              const float *x_len, void *dx, float *dlogs, float *dbias, float *dw, int B,
+                                              int C, int T, int n_split, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && mask && logs && bias && w && dz && dx && dlogs && dbias && dw, "glowtts_actnorm_invconv_bwd: null pointer");
     GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_actnorm_invconv_bwd: n_split=%d (fused path: 2 or 4)", n_split);
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_actnorm_invconv_bwd: bad shape");
@@ -750,4 +793,12 @@ extern "C" int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, co
     dim3 grid(G, (B + nb - 1) / nb);
     FUSED_DISPATCH(actnorm_invconv_bwd_kernel, grid, x, mask, logs, bias, w, w_inv, dz, dlogdet, x_len, dx, dlogs, dbias, dw, B, C, T, nb);
     GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_invconv_bwd");
+}
+
+extern "C" int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *logs, const float *bias,
+                                           const float *w, const float *w_inv, const float *dz, const float *dlogdet,
+                                           const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B,
+                                           int C, int T, int n_split, glowtts_stream_t stream) {
+    return glowtts_actnorm_invconv_bwd_io(x, mask, logs, bias, w, w_inv, dz, dlogdet, x_len, dx, dlogs, dbias, dw, B, C, T,
+                                          n_split, 0, stream);
 }

@@ -11,8 +11,9 @@ namespace glowtts {
 // ------------------------------------------------------------------------------------------------------------
 // squeeze: thread -> (b, c, t'), reads n consecutive frames (8 B for n = 2), writes n rows (each coalesced in t').
 // ------------------------------------------------------------------------------------------------------------
+template <bool B16>     // B16: the SQUEEZED tensor is bf16 in HBM (the un-squeezed one — mel frames, latent — is always fp32)
 __global__ __launch_bounds__(256) void squeeze_kernel(const float *__restrict__ x, const float *__restrict__ mask,
-                                                      float *__restrict__ xs, float *__restrict__ ms, int B, int C, int T,
+                                                      void *__restrict__ xs, float *__restrict__ ms, int B, int C, int T,
                                                       int n) {
     const int Ts = T / n;
     const long total = (long)B * C * Ts;
@@ -24,11 +25,16 @@ __global__ __launch_bounds__(256) void squeeze_kernel(const float *__restrict__ 
     const int b = (int)(row / C);
     const float m = mask ? mask[(long)b * T + (long)ts * n + (n - 1)] : 1.0f;
     const float *src = x + row * T + (long)ts * n;
-    for (int s = 0; s < n; ++s) xs[((long)b * n * C + (long)s * C + c) * Ts + ts] = src[s] * m;
+    for (int s = 0; s < n; ++s) {
+        Vec<1> v;
+        v.d = src[s] * m;
+        VecIO<1, B16>::store(xs, ((long)b * n * C + (long)s * C + c) * Ts + ts, v);
+    }
     if (c == 0 && ms) ms[(long)b * Ts + ts] = m;
 }
 
-__global__ __launch_bounds__(256) void unsqueeze_kernel(const float *__restrict__ xs, const float *__restrict__ ms,
+template <bool B16>
+__global__ __launch_bounds__(256) void unsqueeze_kernel(const void *__restrict__ xs, const float *__restrict__ ms,
                                                         float *__restrict__ x, float *__restrict__ mask_out, int B, int C,
                                                         int Ts, int n) {
     const long total = (long)B * C * Ts;
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(256) void unsqueeze_kernel(const float *__restrict_
     const int b = (int)(row / C);
     const float m = ms ? ms[(long)b * Ts + ts] : 1.0f;
     float *dst = x + row * (long)Ts * n + (long)ts * n;
-    for (int s = 0; s < n; ++s) dst[s] = xs[((long)b * n * C + (long)s * C + c) * Ts + ts] * m;
+    for (int s = 0; s < n; ++s) dst[s] = VecIO<1, B16>::load(xs, ((long)b * n * C + (long)s * C + c) * Ts + ts).d * m;
     if (c == 0 && mask_out)
         for (int s = 0; s < n; ++s) mask_out[(long)b * Ts * n + (long)ts * n + s] = m;
 }
@@ -206,24 +212,37 @@ static inline int reduce_grid(long nv) {
 
 using namespace glowtts;
 
-extern "C" int glowtts_squeeze(const float *x, const float *mask, float *xs, float *ms, int B, int C, int T, int n,
-                               glowtts_stream_t stream) {
+// `_io` forms: io = 1 -> the squeezed tensor (xs) is bf16 in HBM, the un-squeezed one stays fp32
+extern "C" int glowtts_squeeze_io(const float *x, const float *mask, void *xs, float *ms, int B, int C, int T, int n, int io,
+                                  glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && xs, "glowtts_squeeze: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && n >= 1, "glowtts_squeeze: bad shape");
     const long total = (long)B * C * (T / n);
     if (total == 0) return 0;
-    hipLaunchKernelGGL(squeeze_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xs, ms, B, C, T, n);
+    if (io) hipLaunchKernelGGL(squeeze_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xs, ms, B, C, T, n);
+    else    hipLaunchKernelGGL(squeeze_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, mask, xs, ms, B, C, T, n);
     GLOWTTS_LAUNCH_CHECK("glowtts_squeeze");
 }
 
-extern "C" int glowtts_unsqueeze(const float *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq,
-                                 int n, glowtts_stream_t stream) {
+extern "C" int glowtts_squeeze(const float *x, const float *mask, float *xs, float *ms, int B, int C, int T, int n,
+                               glowtts_stream_t stream) {
+    return glowtts_squeeze_io(x, mask, xs, ms, B, C, T, n, 0, stream);
+}
+
+extern "C" int glowtts_unsqueeze_io(const void *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq,
+                                    int n, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(xs && x, "glowtts_unsqueeze: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && Tsq >= 0 && n >= 1, "glowtts_unsqueeze: bad shape");
     const long total = (long)B * C * Tsq;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(unsqueeze_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xs, ms, x, mask_out, B, C, Tsq, n);
+    if (io) hipLaunchKernelGGL(unsqueeze_kernel<true>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xs, ms, x, mask_out, B, C, Tsq, n);
+    else    hipLaunchKernelGGL(unsqueeze_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xs, ms, x, mask_out, B, C, Tsq, n);
     GLOWTTS_LAUNCH_CHECK("glowtts_unsqueeze");
+}
+
+extern "C" int glowtts_unsqueeze(const float *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq,
+                                 int n, glowtts_stream_t stream) {
+    return glowtts_unsqueeze_io(xs, ms, x, mask_out, B, C, Tsq, n, 0, stream);
 }
 
 extern "C" int glowtts_mle_fwd(const float *z, const float *m, const float *logs, const float *mask, float *acc,

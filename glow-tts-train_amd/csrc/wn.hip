@@ -129,10 +129,11 @@ __global__ __launch_bounds__(256) void res_skip_fwd_kernel(const float *__restri
     }
 }
 
-template <int V, bool LAST>
-__global__ __launch_bounds__(256) void res_skip_bwd_kernel(const float *__restrict__ dx_out, const float *__restrict__ dskip,
-                                                           const float *__restrict__ mask, float *__restrict__ dx,
-                                                           float *__restrict__ drs, int B, int H, int T) {
+template <int V, bool LAST, bool B16 = false>
+__global__ __launch_bounds__(256) void res_skip_bwd_kernel(const void *__restrict__ dx_out, const void *__restrict__ dskip,
+                                                           const float *__restrict__ mask, void *__restrict__ dx,
+                                                           void *__restrict__ drs, int B, int H, int T) {
+    using IO = VecIO<V, B16>;
     const int TV = T / V;
     const long n = (long)B * H * TV;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -143,19 +144,19 @@ __global__ __launch_bounds__(256) void res_skip_bwd_kernel(const float *__restri
     const int b = (int)(row / H);
     const long oh = row * T + (long)tv * V;
     Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
-    Vec<V> ds = Vec<V>::load(dskip + oh);
+    Vec<V> ds = IO::load(dskip, oh);
     if (LAST) {
 #pragma unroll
         for (int j = 0; j < V; ++j) ds[j] *= mv[j];
-        ds.store(drs + oh);
+        IO::store(drs, oh, ds);
     } else {
         const long o2 = ((long)b * 2 * H + c) * T + (long)tv * V;
-        Vec<V> gx = Vec<V>::load(dx_out + oh);
+        Vec<V> gx = IO::load(dx_out, oh);
 #pragma unroll
         for (int j = 0; j < V; ++j) gx[j] *= mv[j];
-        gx.store(drs + o2);
-        ds.store(drs + o2 + (long)H * T);
-        if (dx) gx.store(dx + oh);
+        IO::store(drs, o2, gx);
+        IO::store(drs, o2 + (long)H * T, ds);
+        if (dx) IO::store(dx, oh, gx);
     }
 }
 
@@ -220,8 +221,8 @@ extern "C" int glowtts_res_skip_fwd(const float *x, const float *rs, const float
     GLOWTTS_LAUNCH_CHECK("glowtts_res_skip_fwd");
 }
 
-extern "C" int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *mask, float *dx, float *drs,
-                                    int B, int H, int T, int last, glowtts_stream_t stream) {
+extern "C" int glowtts_res_skip_bwd_io(const void *dx_out, const void *dskip, const float *mask, void *dx, void *drs,
+                                       int B, int H, int T, int last, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(dskip && mask && drs, "glowtts_res_skip_bwd: null pointer");
     GLOWTTS_CHECK_ARG(last || dx_out, "glowtts_res_skip_bwd: dx_out required unless last");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0, "glowtts_res_skip_bwd: bad shape");
@@ -230,12 +231,18 @@ extern "C" int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, con
     const bool v4 = can_vec4(T, {dx_out, dskip, mask, dx, drs});
     const long n = (long)B * H * (v4 ? T / 4 : T);
     dim3 grid(cdiv(n, 256));
-    if (last) {
-        if (v4) hipLaunchKernelGGL((res_skip_bwd_kernel<4, true>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T);
-        else    hipLaunchKernelGGL((res_skip_bwd_kernel<1, true>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T);
-    } else {
-        if (v4) hipLaunchKernelGGL((res_skip_bwd_kernel<4, false>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T);
-        else    hipLaunchKernelGGL((res_skip_bwd_kernel<1, false>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T);
-    }
+#define GLOWTTS_RSB(LAST, B16)                                                                                                     \
+    do {                                                                                                                            \
+        if (v4) hipLaunchKernelGGL((res_skip_bwd_kernel<4, LAST, B16>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T); \
+        else    hipLaunchKernelGGL((res_skip_bwd_kernel<1, LAST, B16>), grid, dim3(256), 0, s, dx_out, dskip, mask, dx, drs, B, H, T); \
+    } while (0)
+    if (io) { if (last) GLOWTTS_RSB(true, true); else GLOWTTS_RSB(false, true); }
+    else    { if (last) GLOWTTS_RSB(true, false); else GLOWTTS_RSB(false, false); }
+#undef GLOWTTS_RSB
     GLOWTTS_LAUNCH_CHECK("glowtts_res_skip_bwd");
+}
+
+extern "C" int glowtts_res_skip_bwd(const float *dx_out, const float *dskip, const float *mask, float *dx, float *drs,
+                                    int B, int H, int T, int last, glowtts_stream_t stream) {
+    return glowtts_res_skip_bwd_io(dx_out, dskip, mask, dx, drs, B, H, T, last, 0, stream);
 }

@@ -52,9 +52,29 @@ using namespace glowtts;
 
 #define WN_TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
 
-extern "C" int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask,
-                              const unsigned char *drop, float drop_scale, float *xs, float *acts, float *ts, float *skip,
-                              int B, int H, int T, int taps, int dil_rate, glowtts_stream_t stream) {
+// element-typed slab arithmetic: io = 0 -> fp32 tensors, io = 1 -> bf16 tensors (same shapes, same element offsets)
+static inline const void *at(const void *base, long elems, int io) {
+    return base ? static_cast<const char *>(base) + elems * (io ? 2 : 4) : nullptr;
+}
+static inline void *at(void *base, long elems, int io) {
+    return base ? static_cast<char *>(base) + elems * (io ? 2 : 4) : nullptr;
+}
+
+// weight gradient of y = conv(x) for either tensor type: the fp32 kernels, or (bf16 tensors) the plane kernel fed with ONE
+// plane — the tensor itself.  The plane kernel takes no masks: its callers hand it gradients that are masked already.
+static int wrw_any(const void *x, long x_bs, const void *d, long d_bs, const float *mask_d, float *dwp, float *dbias, int B,
+                   int Cin, int M, int T, int taps, int dil, int pad, int io, glowtts_stream_t stream) {
+    if (!io)
+        return glowtts_conv_wrw(static_cast<const float *>(x), x_bs, static_cast<const float *>(d), d_bs, mask_d, nullptr, dwp,
+                                dbias, B, Cin, M, T, taps, dil, pad, stream);
+    GLOWTTS_CHECK_ARG(dil == 1 && pad == (taps - 1) / 2 && !mask_d, "glowtts (bf16 tensors): weight gradient needs dilation 1, 'same' padding, pre-masked gradients");
+    return glowtts_conv_wrw_planes(static_cast<const uint16_t *>(x), 0, x_bs, static_cast<const uint16_t *>(d), 0, d_bs, dwp, dbias,
+                                   B, Cin, M, T, taps, 1, stream);
+}
+
+extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
+                                 const unsigned char *drop, float drop_scale, void *xs, void *acts, void *ts, void *skip,
+                                 int B, int H, int T, int taps, int dil_rate, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(layers && x && mask && acts && ts && skip, "glowtts_wn_fwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_fwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_fwd: bad shape");
@@ -63,68 +83,81 @@ extern "C" int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, cons
     for (int i = 0; i < n_layers; ++i, dil *= dil_rate) {
         const glowtts_wn_layer &L = layers[i];
         const bool last = i == n_layers - 1;
-        const float *x_i = i == 0 ? x : xs + (long)(i - 1) * BHT;
+        const void *x_i = i == 0 ? x : at((const void *)xs, (long)(i - 1) * BHT, io);
         const int pad = (int)((taps * dil - dil) / 2);
-        WN_TRY(glowtts_conv_gate_fwd(x_i, L.wf_in, L.b_in, nullptr, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale,
-                                     acts + (long)i * BHT, ts + (long)i * 2 * BHT, B, H, T, taps, (int)dil, pad, stream));
+        WN_TRY(glowtts_conv_gate_fwd_io(x_i, L.wf_in, L.b_in, nullptr, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale,
+                                        at(acts, (long)i * BHT, io), at(ts, (long)i * 2 * BHT, io), B, H, T, taps, (int)dil, pad,
+                                        io, stream));
         // x_{i+1} = (x_i + rs[:H]) mask ; skip += rs[H:]   (skip accumulates in place: same thread reads and writes an element)
-        WN_TRY(glowtts_conv_res_skip_fwd(acts + (long)i * BHT, L.wf_rs, L.b_rs, mask, last ? nullptr : x_i,
-                                         i == 0 ? nullptr : skip, last ? nullptr : xs + (long)i * BHT, skip, B, H, T,
-                                         last ? 1 : 0, stream));
+        WN_TRY(glowtts_conv_res_skip_fwd_io(at((const void *)acts, (long)i * BHT, io), L.wf_rs, L.b_rs, mask, last ? nullptr : x_i,
+                                            i == 0 ? nullptr : skip, last ? nullptr : at(xs, (long)i * BHT, io), skip, B, H, T,
+                                            last ? 1 : 0, io, stream));
     }
     return 0;
 }
 
-extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *xs,
-                              const float *acts, const float *ts, const float *mask, const unsigned char *drop,
-                              float drop_scale, const float *dskip, float *d_rs, float *d_xin, float *dx,
-                              const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
-                              int H, int T, int taps, int dil_rate, int two_source, glowtts_stream_t wgrad_stream,
-                              glowtts_stream_t stream) {
+extern "C" int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask,
+                              const unsigned char *drop, float drop_scale, float *xs, float *acts, float *ts, float *skip,
+                              int B, int H, int T, int taps, int dil_rate, glowtts_stream_t stream) {
+    return glowtts_wn_fwd_io(layers, n_layers, x, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate, 0, stream);
+}
+
+extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const void *xs,
+                                 const void *acts, const void *ts, const float *mask, const unsigned char *drop,
+                                 float drop_scale, const void *dskip, void *d_rs, void *d_xin, void *dx,
+                                 const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
+                                 int H, int T, int taps, int dil_rate, int two_source, int mask_input_grad, int io,
+                                 glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(layers && x && acts && ts && mask && dskip && d_rs && d_xin && dx, "glowtts_wn_bwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_bwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_bwd: bad shape");
+    GLOWTTS_CHECK_ARG(!io || (!two_source && mask_input_grad), "glowtts_wn_bwd: bf16 tensors use the d_rs form with a masked input gradient");
     hipStream_t ms = (hipStream_t)stream;
     hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
     const long BHT = (long)B * H * T;
     long dil = 1;
     for (int i = 1; i < n_layers; ++i) dil *= dil_rate;
-    const float *dsk = dskip;
+    const void *dsk = dskip;
     WN_TRY(order_after(ms, ws));                                    // accumulators were cleared on the main stream
     if (two_source) {
         // The launch sequence of convops.WNFn._backward_layers in its two-source form, layer by layer: d_rs = [dx_{i+1} mask ;
         // dskip] is never written (gate_bwd and wrw2 read its halves from the two tensors), each weight-gradient kernel goes to
         // the second stream as soon as its operands exist, and only d_xin / dx live per layer.  d_rs needs B*H*T floats (the
-        // last layer's masked dskip).
+        // last layer's masked dskip).  fp32 tensors only.
         GLOWTTS_CHECK_ARG(dil_rate == 1 && H % 192 == 0 && T % 4 == 0, "glowtts_wn_bwd: two-source form needs dilation 1, H %% 192 == 0, T %% 4 == 0");
         const int pad = (taps - 1) / 2;
+        const float *xf = static_cast<const float *>(x), *xsf = static_cast<const float *>(xs);
+        const float *actsf = static_cast<const float *>(acts), *tsf = static_cast<const float *>(ts);
+        float *d_rsf = static_cast<float *>(d_rs), *d_xinf = static_cast<float *>(d_xin), *dxf = static_cast<float *>(dx);
+        const float *dskf = static_cast<const float *>(dskip);
         for (int i = n_layers - 1; i >= 0; --i) {
             const glowtts_wn_layer &L = layers[i];
             const bool last = i == n_layers - 1;
-            const float *x_i = i == 0 ? x : xs + (long)(i - 1) * BHT;
-            const float *acts_i = acts + (long)i * BHT, *ts_i = ts + (long)i * 2 * BHT;
+            const float *x_i = i == 0 ? xf : xsf + (long)(i - 1) * BHT;
+            const float *acts_i = actsf + (long)i * BHT, *ts_i = tsf + (long)i * 2 * BHT;
             const unsigned char *drop_i = drop ? drop + (long)i * 2 * BHT : nullptr;
-            float *dxin_i = d_xin + (long)i * 2 * BHT, *dx_i = dx + (long)i * BHT;
-            const float *half = last ? nullptr : dx + (long)(i + 1) * BHT;       // left the layer above already masked
+            float *dxin_i = d_xinf + (long)i * 2 * BHT, *dx_i = dxf + (long)i * BHT;
+            const float *half = last ? nullptr : dxf + (long)(i + 1) * BHT;       // left the layer above already masked
             if (last) {
-                WN_TRY(glowtts_res_skip_bwd(nullptr, dskip, mask, nullptr, d_rs, B, H, T, 1, stream));
-                dsk = d_rs;
+                WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
+                dskf = d_rsf;
                 WN_TRY(order_after(ms, ws));
-                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, d_rs, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
+                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, d_rsf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
                                         1, 0, (glowtts_stream_t)ws));
-                WN_TRY(glowtts_conv_gate_bwd(d_rs, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, H, H, T, stream));
+                WN_TRY(glowtts_conv_gate_bwd(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, H, H, T, stream));
             } else {
                 WN_TRY(order_after(ms, ws));
-                WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dsk, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
+                WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dskf, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
                                          T, 1, 1, 0, (glowtts_stream_t)ws));
-                WN_TRY(glowtts_conv_gate_bwd(half, dsk, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, 2 * H, H, T, stream));
+                WN_TRY(glowtts_conv_gate_bwd(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, 2 * H, H, T, stream));
             }
             WN_TRY(order_after(ms, ws));
             WN_TRY(glowtts_conv_wrw(x_i, (long)H * T, dxin_i, (long)2 * H * T, nullptr, nullptr, L.dwp_in, L.db_in, B, H, 2 * H, T,
                                     taps, 1, pad, (glowtts_stream_t)ws));
             // dx_i = (residual path) dx_{i+1} + (conv path) W_in^T (*) d_xin, masked unless it is the stack's own input gradient
-            WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, i > 0 ? mask : nullptr, half, (long)H * T, dx_i,
-                                    (long)H * T, B, 2 * H, H, T, taps, 1, (taps - 1) - pad, 0, i > 0 ? 1 : 0, 0, stream));
+            const bool m_out = i > 0 || mask_input_grad;
+            WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, m_out ? mask : nullptr, half, (long)H * T, dx_i,
+                                    (long)H * T, B, 2 * H, H, T, taps, 1, (taps - 1) - pad, 0, m_out ? 1 : 0, 0, stream));
         }
         if (unpack_desc)
             WN_TRY(glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows, (glowtts_stream_t)ws));
@@ -135,20 +168,20 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
         const bool last = i == n_layers - 1;
         const int m_rs = last ? H : 2 * H;
         const int pad = (int)((taps * dil - dil) / 2);
-        const float *x_i = i == 0 ? x : xs + (long)(i - 1) * BHT;
-        const float *acts_i = acts + (long)i * BHT, *ts_i = ts + (long)i * 2 * BHT;
-        float *drs_i = d_rs + (long)i * 2 * BHT, *dxin_i = d_xin + (long)i * 2 * BHT, *dx_i = dx + (long)i * BHT;
+        const void *ts_i = at(ts, (long)i * 2 * BHT, io);
+        void *drs_i = at(d_rs, (long)i * 2 * BHT, io), *dxin_i = at(d_xin, (long)i * 2 * BHT, io), *dx_i = at(dx, (long)i * BHT, io);
         // d_rs = [dx_{i+1} mask ; dskip]   (last layer: dskip mask, which also becomes dskip of the layers below)
-        WN_TRY(glowtts_res_skip_bwd(last ? nullptr : dx + (long)(i + 1) * BHT, dsk, mask, nullptr, drs_i, B, H, T,
-                                    last ? 1 : 0, stream));
+        WN_TRY(glowtts_res_skip_bwd_io(last ? nullptr : at((const void *)dx, (long)(i + 1) * BHT, io), dsk, mask, nullptr, drs_i, B, H, T,
+                                       last ? 1 : 0, io, stream));
         if (last) dsk = drs_i;
         // d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs)
-        WN_TRY(glowtts_conv_gate_bwd(drs_i, nullptr, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i, B,
-                                     m_rs, H, T, stream));
+        WN_TRY(glowtts_conv_gate_bwd_io(drs_i, nullptr, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i, B,
+                                        m_rs, H, T, io, stream));
         // dx_i = (residual path) d_rs[:H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
-        WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, nullptr, last ? nullptr : drs_i,
-                                last ? 0 : (long)2 * H * T, dx_i, (long)H * T, B, 2 * H, H, T, taps, (int)dil,
-                                (int)((taps - 1) * dil - pad), 0, 0, 0, stream));
+        const bool m_out = i == 0 && mask_input_grad;
+        WN_TRY(glowtts_conv_fwd_io(dxin_i, (long)2 * H * T, L.wb_in, nullptr, m_out ? mask : nullptr, last ? nullptr : drs_i,
+                                   last ? 0 : (long)2 * H * T, dx_i, (long)H * T, B, 2 * H, H, T, taps, (int)dil,
+                                   (int)((taps - 1) * dil - pad), 0, m_out ? 1 : 0, 0, io, io, stream));
     }
     // the whole dx chain of the stack is queued first; the weight gradients follow on their own stream, where they run
     // beside the chain of whatever backward comes next (per-layer interleaving made the two streams fight for the
@@ -161,17 +194,27 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
         const bool last = i == n_layers - 1;
         const int m_rs = last ? H : 2 * H;
         const int pad = (int)((taps * dil - dil) / 2);
-        const float *x_i = i == 0 ? x : xs + (long)(i - 1) * BHT;
-        const float *acts_i = acts + (long)i * BHT;
-        float *drs_i = d_rs + (long)i * 2 * BHT, *dxin_i = d_xin + (long)i * 2 * BHT;
-        WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, drs_i, (long)m_rs * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, m_rs,
-                                T, 1, 1, 0, (glowtts_stream_t)ws));
-        WN_TRY(glowtts_conv_wrw(x_i, (long)H * T, dxin_i, (long)2 * H * T, nullptr, nullptr, L.dwp_in, L.db_in, B, H, 2 * H,
-                                T, taps, (int)dil, pad, (glowtts_stream_t)ws));
+        const void *x_i = i == 0 ? x : at(xs, (long)(i - 1) * BHT, io);
+        const void *acts_i = at(acts, (long)i * BHT, io);
+        const void *drs_i = at((const void *)d_rs, (long)i * 2 * BHT, io), *dxin_i = at((const void *)d_xin, (long)i * 2 * BHT, io);
+        WN_TRY(wrw_any(acts_i, (long)H * T, drs_i, (long)m_rs * T, nullptr, L.dwp_rs, L.db_rs, B, H, m_rs, T, 1, 1, 0, io,
+                       (glowtts_stream_t)ws));
+        WN_TRY(wrw_any(x_i, (long)H * T, dxin_i, (long)2 * H * T, nullptr, L.dwp_in, L.db_in, B, H, 2 * H, T, taps, (int)dil, pad, io,
+                       (glowtts_stream_t)ws));
     }
     if (unpack_desc)                                                // behind the weight-gradient kernels, on their stream
         WN_TRY(glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows, (glowtts_stream_t)ws));
     return 0;
+}
+
+extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *xs,
+                              const float *acts, const float *ts, const float *mask, const unsigned char *drop,
+                              float drop_scale, const float *dskip, float *d_rs, float *d_xin, float *dx,
+                              const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
+                              int H, int T, int taps, int dil_rate, int two_source, glowtts_stream_t wgrad_stream,
+                              glowtts_stream_t stream) {
+    return glowtts_wn_bwd_io(layers, n_layers, x, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx, unpack_desc,
+                             unpack_prefix, n_conv, total_rows, B, H, T, taps, dil_rate, two_source, 0, 0, wgrad_stream, stream);
 }
 
 // ---- a whole flow block per call ---------------------------------------------------------------------------------------
@@ -179,11 +222,21 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
 // Python path drove it as five autograd nodes per block (fused ActNorm+InvConv, start conv, WN, end conv, affine apply):
 // ~120 us of interpreter / autograd time per block forward and ~180 us backward on top of the launches themselves,
 // 3 ms of the ~19 ms host time of a config-2 step.  The launch sequence below is the same one, kernel for kernel.
-extern "C" int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
-                                      const unsigned char *drop, float drop_scale, float *y, float *h0, float *xs,
-                                      float *acts, float *ts, float *skip, float *out, float *z, float *logdet, int B, int C,
-                                      int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
-                                      glowtts_stream_t stream) {
+// io bit 0: the HIDDEN tensors of the coupling network (h0, xs, acts, ts, skip and every gradient among them, dout) are bf16
+// in HBM; io bit 1 (needs bit 0): the FLOW tensor (x, y, z and their gradients) as well.  `out` = (m, logs) feeds the
+// log-determinant and stays fp32 together with every log-det, mask, parameter and parameter gradient; all arithmetic
+// accumulates in fp32.  With io == 1 the start conv reads y0h, a bf16 copy (B, C/2, T) of y's first half written by the
+// fused ActNorm + InvConv kernel (unused otherwise, may be NULL).
+extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
+                                         const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs,
+                                         void *acts, void *ts, void *skip, float *out, void *z, float *logdet, int B, int C,
+                                         int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int io,
+                                         glowtts_stream_t stream) {
+    const int io_h = io & 1, io_f = (io >> 1) & 1;
+    GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
+    GLOWTTS_CHECK_ARG(io != 1 || y0h, "glowtts_flow_block_fwd: io = 1 needs the y0h buffer");
+    const void *start_in = io == 1 ? y0h : y;
+    const long start_bs = io == 1 ? (long)(C / 2) * T : (long)C * T;
     GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && z && logdet,
                       "glowtts_flow_block_fwd: null pointer");
     GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->w_inv && blk->logdet_w && (!blk->pack_desc || blk->pack_prefix),
@@ -197,14 +250,74 @@ extern "C" int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float
         WN_TRY(glowtts_pack_weight_multi(blk->pack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, stream));
     WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
     // flows 3i, 3i+1: y = W ((bias + e^logs x) mask) mask ; logdet = (sum logs + log det W * C/n) x_len
-    WN_TRY(glowtts_actnorm_invconv_fwd(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet, B, C, T, n_split,
-                                       stream));
+    WN_TRY(glowtts_actnorm_invconv_fwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet,
+                                          io == 1 ? y0h : nullptr, B, C, T, n_split, io_f, stream));
     // flow 3i+2: h = start(y[:, :C/2]) mask  ->  WN  ->  out = end(h)  ->  z = [y0 ; (m + e^logs y1) mask], logdet += sum logs mask
-    WN_TRY(glowtts_conv_fwd(y, CT, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1, 0, stream));
-    WN_TRY(glowtts_wn_fwd(blk->layers, blk->n_layers, h0, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
-                          stream));
-    WN_TRY(glowtts_conv_fwd(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, stream));
-    return glowtts_coupling_fwd(y, out, mask, z, logdet, B, C, T, sigmoid_scale, 0, stream);
+    WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1,
+                               0, io_h, io_h, stream));
+    WN_TRY(glowtts_wn_fwd_io(blk->layers, blk->n_layers, h0, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
+                             io_h, stream));
+    WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
+                               stream));
+    return glowtts_coupling_fwd_io(y, out, mask, z, logdet, B, C, T, sigmoid_scale, 0, io_f, stream);
+}
+
+extern "C" int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
+                                      const unsigned char *drop, float drop_scale, float *y, float *h0, float *xs,
+                                      float *acts, float *ts, float *skip, float *out, float *z, float *logdet, int B, int C,
+                                      int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
+                                      glowtts_stream_t stream) {
+    return glowtts_flow_block_fwd_io(blk, x, mask, x_len, drop, drop_scale, y, nullptr, h0, xs, acts, ts, skip, out, z, logdet, B, C,
+                                     H, T, taps, dil_rate, n_split, sigmoid_scale, 0, stream);
+}
+
+extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
+                                         const unsigned char *drop, float drop_scale, const void *y, const void *y0h, const void *h0,
+                                         const void *xs, const void *acts, const void *ts, const void *skip, const float *out,
+                                         const void *dz, const float *dlogdet, void *dy, void *dout, void *dskip, void *d_rs,
+                                         void *d_xin, void *dx_wn, void *dx, int B, int C, int H, int T, int taps, int dil_rate,
+                                         int n_split, int sigmoid_scale, int two_source, int io, glowtts_stream_t wgrad_stream,
+                                         glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && dz && dy && dout && dskip && d_rs &&
+                      d_xin && dx_wn && dx, "glowtts_flow_block_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->unpack_desc && blk->pack_prefix && blk->dwp_all && blk->dlogs &&
+                      blk->dbias && blk->dw, "glowtts_flow_block_bwd: incomplete block table");
+    GLOWTTS_CHECK_ARG(!io || !two_source, "glowtts_flow_block_bwd: bf16 tensors use the d_rs form");
+    const int io_h = io & 1, io_f = (io >> 1) & 1;
+    GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
+    GLOWTTS_CHECK_ARG(io != 1 || y0h, "glowtts_flow_block_bwd: io = 1 needs the y0h buffer");
+    const void *start_in = io == 1 ? y0h : y;
+    const long start_bs = io == 1 ? (long)(C / 2) * T : (long)C * T;
+    hipStream_t ms = (hipStream_t)stream;
+    hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
+    const long CT = (long)C * T, HT = (long)H * T;
+    // every packed weight-gradient accumulator of the block in one fill (the kernels add into it with atomics)
+    hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ms);
+    if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
+    // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
+    WN_TRY(glowtts_coupling_bwd_io(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, io_f, io_h, stream));
+    // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(wrw_any(skip, HT, dout, CT, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, io_h, (glowtts_stream_t)ws));
+    WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0, 0, 0, io_h, io_h,
+                               stream));
+    // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block).
+    // With bf16 tensors the stack masks its own input gradient: the start conv's weight gradient then needs no mask.
+    WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, nullptr,
+                             nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, io_h, io_h, wgrad_stream, stream));
+    // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,
+                   (glowtts_stream_t)ws));
+    WN_TRY(glowtts_conv_fwd_io(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, io_h, io_f,
+                               stream));
+    // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets
+    WN_TRY(glowtts_actnorm_invconv_bwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,
+                                          blk->dbias, blk->dw, B, C, T, n_split, io_f, stream));
+    // the second stream finishes the block: after this point on `ws` EVERY parameter gradient of the block is complete
+    // (the three ActNorm / InvConv gradients were produced on the chain, hence the ordering edge)
+    WN_TRY(order_after(ms, ws));
+    return glowtts_unpack_weight_grad_multi(blk->unpack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, (glowtts_stream_t)ws);
 }
 
 extern "C" int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
@@ -214,35 +327,7 @@ extern "C" int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float
                                       float *dskip, float *d_rs, float *d_xin, float *dx_wn, float *dx, int B, int C, int H,
                                       int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int two_source,
                                       glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
-    GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && dz && dy && dout && dskip && d_rs &&
-                      d_xin && dx_wn && dx, "glowtts_flow_block_bwd: null pointer");
-    GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->unpack_desc && blk->pack_prefix && blk->dwp_all && blk->dlogs &&
-                      blk->dbias && blk->dw, "glowtts_flow_block_bwd: incomplete block table");
-    hipStream_t ms = (hipStream_t)stream;
-    hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
-    const long CT = (long)C * T, HT = (long)H * T;
-    // every packed weight-gradient accumulator of the block in one fill (the kernels add into it with atomics)
-    hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ms);
-    if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
-    // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
-    WN_TRY(glowtts_coupling_bwd(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, stream));
-    // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain
-    WN_TRY(order_after(ms, ws));
-    WN_TRY(glowtts_conv_wrw(skip, HT, dout, CT, nullptr, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, (glowtts_stream_t)ws));
-    WN_TRY(glowtts_conv_fwd(dout, CT, blk->wb_end, nullptr, nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0, 0, 0, stream));
-    // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block)
-    WN_TRY(glowtts_wn_bwd(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, nullptr,
-                          nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, wgrad_stream, stream));
-    // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
-    WN_TRY(order_after(ms, ws));
-    WN_TRY(glowtts_conv_wrw(y, CT, dx_wn, HT, mask, nullptr, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0,
-                            (glowtts_stream_t)ws));
-    WN_TRY(glowtts_conv_fwd(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, stream));
-    // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets
-    WN_TRY(glowtts_actnorm_invconv_bwd(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,
-                                       blk->dbias, blk->dw, B, C, T, n_split, stream));
-    // the second stream finishes the block: after this point on `ws` EVERY parameter gradient of the block is complete
-    // (the three ActNorm / InvConv gradients were produced on the chain, hence the ordering edge)
-    WN_TRY(order_after(ms, ws));
-    return glowtts_unpack_weight_grad_multi(blk->unpack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, (glowtts_stream_t)ws);
+    return glowtts_flow_block_bwd_io(blk, x, mask, x_len, drop, drop_scale, y, nullptr, h0, xs, acts, ts, skip, out, dz, dlogdet, dy, dout,
+                                     dskip, d_rs, d_xin, dx_wn, dx, B, C, H, T, taps, dil_rate, n_split, sigmoid_scale, two_source,
+                                     0, wgrad_stream, stream);
 }

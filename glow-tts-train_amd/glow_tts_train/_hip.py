@@ -72,6 +72,22 @@ _SIGNATURES = {
     # a whole flow block per call (csrc/wn_stack.hip); the first argument is a HOST struct glowtts_flow_block
     "glowtts_flow_block_fwd": [_P, _P, _P, _P, _P, _F] + [_P] * 9 + [_I] * 8,
     "glowtts_flow_block_bwd": [_P, _P, _P, _P, _P, _F] + [_P] * 16 + [_I] * 9 + [_P],
+    # `_io` forms (bf16 activation tensors in HBM: BASELINE configs[2]); the trailing int before the stream(s) is the io flag
+    "glowtts_flow_block_fwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 10 + [_I] * 9,
+    "glowtts_flow_block_bwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 17 + [_I] * 10 + [_P],
+    "glowtts_squeeze_io": [_P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "glowtts_unsqueeze_io": [_P, _P, _P, _P, _I, _I, _I, _I, _I],
+    "glowtts_conv_fwd_io": [_P, _L, _P, _P, _P, _P, _L, _P, _L] + [_I] * 12,
+    "glowtts_conv_gate_fwd_io": [_P, _P, _P, _P, _P, _F, _P, _P] + [_I] * 7,
+    "glowtts_conv_res_skip_fwd_io": [_P] * 8 + [_I] * 5,
+    "glowtts_conv_gate_bwd_io": [_P, _P, _P, _P, _P, _F, _P] + [_I] * 5,
+    "glowtts_res_skip_bwd_io": [_P] * 5 + [_I] * 5,
+    "glowtts_actnorm_invconv_fwd_io": [_P] * 10 + [_I] * 5,
+    "glowtts_actnorm_invconv_bwd_io": [_P] * 13 + [_I] * 5,
+    "glowtts_coupling_fwd_io": [_P, _P, _P, _P, _P] + [_I] * 6,
+    "glowtts_coupling_bwd_io": [_P] * 7 + [_I] * 6,
+    "glowtts_wn_fwd_io": [_P, _I, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 6,
+    "glowtts_wn_bwd_io": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
 }
 
 
@@ -92,7 +108,7 @@ class FlowBlock(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
-                           "glowtts_conv_bind_planes"])
+                           "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -125,6 +141,8 @@ def load() -> ctypes.CDLL:
     lib.glowtts_conv_math.argtypes = [_I]
     lib.glowtts_conv_bind_planes.restype = _I
     lib.glowtts_conv_bind_planes.argtypes = [_P, _L, _P]
+    lib.glowtts_conv_bind_planes_ns.restype = _I
+    lib.glowtts_conv_bind_planes_ns.argtypes = [_P, _L, _P, _I]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -203,6 +221,16 @@ def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] 
     if wp is None:
         lib.glowtts_conv_bind_planes(None, 0, None)
     elif lib.glowtts_conv_bind_planes(wp.data_ptr(), wp.numel(), planes.data_ptr()) != 0:
+        raise RuntimeError(lib.glowtts_last_error().decode())
+
+
+def conv_bind_planes_ns(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] = None, n_planes: int = 1):
+    """Bind (None: unbind) `n_planes` bf16 planes of a packed-weight buffer for this thread's next convolution launches,
+    whatever glowtts_conv_math says (bf16-tensor flow blocks bind ONE plane: the weights rounded to bf16)."""
+    lib = load()
+    if wp is None:
+        lib.glowtts_conv_bind_planes_ns(None, 0, None, 0)
+    elif lib.glowtts_conv_bind_planes_ns(wp.data_ptr(), wp.numel(), planes.data_ptr(), int(n_planes)) != 0:
         raise RuntimeError(lib.glowtts_last_error().decode())
 
 

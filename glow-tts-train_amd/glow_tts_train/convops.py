@@ -364,6 +364,7 @@ class WNPackPlan:
         self.version = getattr(self, "version", 0) + 1
 
     def pack(self):
+        self.pack_count = getattr(self, "pack_count", 0) + 1      # (planes made from the packed weights go stale here)
         call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
         if _SPLIT_MATH[0] and self.want_planes:   # bf16-plane arithmetic is on: refresh the planes of the new weights
             if self.wp_planes is None:
@@ -774,6 +775,28 @@ class FlowBlockPlan:
         self.plan = WNPackPlan(want_planes=True)
         self._key = None
 
+    def bind(self, io: bool):
+        """Planes for the calling thread's next convolution launches.  bf16 tensors (io): the three bf16 planes h + m + l of
+        the freshly packed weights, made here (one elementwise launch over the block's packed buffer) — plane h alone is the
+        weight rounded to bf16, which is what every convolution but the end conv reads; else whatever glowtts_conv_math asks."""
+        plan = self.plan
+        if not io:
+            return ("math", plan.bind())
+        n = plan.wp_arena.numel()
+        if getattr(self, "_planes_io", None) is None or self._planes_io.numel() != 3 * n:
+            self._planes_io = torch.empty(3 * n, device=plan.wp_arena.device, dtype=torch.int16)
+        if getattr(self, "_planes_io_version", None) != (plan.version, plan.pack_count):
+            call("glowtts_split_planes", ptr(plan.wp_arena), n, ptr(self._planes_io), 3)
+            self._planes_io_version = (plan.version, plan.pack_count)
+        _hip.conv_bind_planes_ns(plan.wp_arena, self._planes_io, 3)
+        return ("io", True)
+
+    def unbind(self, bound):
+        if bound[0] == "io":
+            _hip.conv_bind_planes_ns(None)
+        else:
+            self.plan.unbind(bound[1])
+
     @staticmethod
     def conv_params(params, n_layers):
         """(v, g, bias) triples in the plan's order: start, end, then (in, res/skip) per WN layer."""
@@ -834,6 +857,15 @@ def flow_block_eligible(actnorm, invconv, coupling, x, g) -> bool:
                for p in flow_block_params(actnorm, invconv, coupling))
 
 
+def flow_block_bf16_ok(coupling, x_shape) -> bool:
+    """Shapes the bf16-tensor kernels are instantiated for (csrc/convgemm_split.hip, dispatch_bf16_io): the default coupling
+    network (5 taps, dilation 1, hidden width 192) on a flow tensor whose halves are whole 16-channel groups, T % 4 == 0."""
+    wn = coupling.wn
+    B, C, T = x_shape
+    return (wn.kernel_size[0] == 5 and wn.dilation_rate == 1 and wn.hidden_channels == 192 and C % 32 == 0 and T % 4 == 0
+            and T > 0)
+
+
 def flow_block_params(actnorm, invconv, coupling):
     wn = coupling.wn
     out = [actnorm.logs, actnorm.bias, invconv.weight, coupling.start.weight_v, coupling.start.weight_g, coupling.start.bias,
@@ -851,20 +883,29 @@ class FlowBlockFn(Function):
     @staticmethod
     def forward(ctx, x, m2, x_len, drop, cfg, bplan, *params):
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = cfg
-        x = f32(x.contiguous())
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
+        # io (csrc: the `_io` entry points): 0 = fp32 tensors; 1 = the coupling network's hidden tensors bf16 in HBM, the
+        # flow tensor fp32; 3 = the flow tensor bf16 as well
+        fdt = torch.bfloat16 if io & 2 else torch.float32
+        adt = torch.bfloat16 if io & 1 else torch.float32
+        x = x.contiguous()
+        if x.dtype != fdt:
+            raise RuntimeError(f"FlowBlockFn: flow tensor is {x.dtype}, the block runs with {fdt} flow tensors")
         B, C, T = x.shape
         dev = x.device
         plan = bplan.plan
         plan.ensure(FlowBlockPlan.conv_params(params, n_layers), n_convs=2 + 2 * n_layers)
         plan.pack()
-        bound = plan.bind()
+        bound = bplan.bind(io)
         try:
             new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                      # noqa: E731
-            y, out, z = new(B, C, T), new(B, C, T), new(B, C, T)
-            h0, skip = new(B, H, T), new(B, H, T)
-            acts, ts = new(n_layers, B, H, T), new(n_layers, B, 2 * H, T)
-            xs = new(n_layers - 1, B, H, T) if n_layers > 1 else None
+            act = lambda *shape: torch.empty(shape, device=dev, dtype=adt)                                # noqa: E731
+            y, z = torch.empty(B, C, T, device=dev, dtype=fdt), torch.empty(B, C, T, device=dev, dtype=fdt)
+            out = new(B, C, T)
+            y0h = act(B, C // 2, T) if io == 1 else None      # bf16 copy of y's first half for the start conv
+            h0, skip = act(B, H, T), act(B, H, T)
+            acts, ts = act(n_layers, B, H, T), act(n_layers, B, 2 * H, T)
+            xs = act(n_layers - 1, B, H, T) if n_layers > 1 else None
             logdet = new(B)
             winv = new(n_split * n_split + 1)
             if p_drop > 0.0 and (drop is None or tuple(drop.shape) != (n_layers, B, 2 * H, T) or not drop.is_contiguous()):
@@ -875,13 +916,13 @@ class FlowBlockFn(Function):
             tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
             taps = params[8].shape[2]
             scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-            call("glowtts_flow_block_fwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), scale, ptr(y), ptr(h0),
-                 ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(z), ptr(logdet), B, C, H, T, taps, dil_rate, n_split,
-                 int(sigmoid_scale))
+            call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), scale, ptr(y), ptr(y0h),
+                 ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(z), ptr(logdet), B, C, H, T, taps, dil_rate, n_split,
+                 int(sigmoid_scale), int(io))
         finally:
-            plan.unbind(bound)
+            bplan.unbind(bound)
         ctx.save_for_backward(x, m2, x_len, y, h0, acts, ts, skip, out, winv, *([] if xs is None else [xs]),
-                              *([] if drop is None else [drop]))
+                              *([] if drop is None else [drop]), *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplan, ctx.params, ctx.taps, ctx.scale = cfg, bplan, params, taps, scale
         return z, logdet
 
@@ -889,41 +930,47 @@ class FlowBlockFn(Function):
     @once_differentiable
     def backward(ctx, dz, dlogdet):
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = ctx.cfg
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = ctx.cfg
+        fdt = torch.bfloat16 if io & 2 else torch.float32
+        adt = torch.bfloat16 if io & 1 else torch.float32
         sv = list(ctx.saved_tensors)
         x, m2, x_len, y, h0, acts, ts, skip, out, winv = sv[:10]
         rest = sv[10:]
         xs = rest.pop(0) if n_layers > 1 else None
         drop = rest.pop(0) if p_drop > 0 else None
+        y0h = rest.pop(0) if io == 1 else None
         params, bplan = ctx.params, ctx.bplan
         plan = bplan.plan
         B, C, T = x.shape
         dev = x.device
         if not all(p.grad is not None and p.grad.is_contiguous() for p in params):
             raise RuntimeError("FlowBlockFn.backward: a parameter gradient buffer disappeared between forward and backward")
-        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                          # noqa: E731
+        new = lambda *shape: torch.empty(shape, device=dev, dtype=adt)                                    # noqa: E731
+        flow = lambda *shape: torch.empty(shape, device=dev, dtype=fdt)                                   # noqa: E731
         dz = dz.contiguous() if dz is not None else torch.zeros_like(x)
-        dlogdet = dlogdet.contiguous() if dlogdet is not None else torch.zeros(B, device=dev)
+        if dz.dtype != fdt:
+            dz = dz.to(fdt)
+        dlogdet = dlogdet.contiguous().float() if dlogdet is not None else torch.zeros(B, device=dev)
         wgrad = _WgradStream(dev)
-        two_src = wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
-        dy, dout, dx = new(B, C, T), new(B, C, T), new(B, C, T)
+        two_src = (not io) and wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
+        dy, dout, dx = flow(B, C, T), new(B, C, T), flow(B, C, T)
         dskip = new(B, H, T)
         d_rs = new(B, H, T) if two_src else new(n_layers, B, 2 * H, T)
         d_xin, dx_wn = new(n_layers, B, 2 * H, T), new(n_layers, B, H, T)
         tab = bplan.table(params, n_layers)
         tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
-        bound = plan.bind()
+        bound = bplan.bind(io)
         try:
-            call("glowtts_flow_block_bwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), ctx.scale, ptr(y),
-                 ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(dz), ptr(dlogdet), ptr(dy), ptr(dout), ptr(dskip),
+            call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), ctx.scale, ptr(y),
+                 ptr(y0h), ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(dz), ptr(dlogdet), ptr(dy), ptr(dout), ptr(dskip),
                  ptr(d_rs), ptr(d_xin), ptr(dx_wn), ptr(dx), B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale),
-                 int(two_src), wgrad.side.cuda_stream if wgrad.enabled else None)
+                 int(two_src), int(io), wgrad.side.cuda_stream if wgrad.enabled else None)
         finally:
-            plan.unbind(bound)
+            bplan.unbind(bound)
         live = [p for p in params if p is not None]
         _mark_direct(live, True)
         if wgrad.enabled:
-            for t in (y, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn):     # read by the second stream after this returns
+            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn):     # read by the second stream after this returns
                 if t is not None:
                     t.record_stream(wgrad.side)
             with torch.cuda.stream(wgrad.side):          # every gradient of the block is complete at this point of THAT stream

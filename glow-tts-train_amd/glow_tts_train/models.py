@@ -121,9 +121,51 @@ class FlowSpecDecoder(nn.Module):
                               sigmoid_scale=sigmoid_scale),
             ])
 
+    # bf16-tensor modes (BASELINE configs[2]; reference: the autocast branch, train.py:116-121).  `io_bf16`:
+    #   "all" (or True) — every activation of the flow stack lives in HBM as bf16: the squeezed flow tensor between the flows
+    #       and the hidden tensors of every coupling network (start-conv output, the WN stack's layer inputs, gate outputs,
+    #       stored tanh / sigmoid, skip sum, and all their gradients);
+    #   "hidden" — only the hidden tensors (28 H of the 6.5 C + 28 H elements a block moves per column); the invertible chain
+    #       itself stays fp32, as it does under the reference's autocast (its elementwise flows multiply by fp32 parameters).
+    # Parameters, masks, (m, logs), log-determinants, parameter gradients and all arithmetic stay fp32 in both.  Measured at
+    # B=64 / T=1000 / 12 blocks (tools/bf16_logdet_probe.py): log-det within 1-3e-3 of the fp32 path in either mode — the error
+    # is the 2^-9 round-off of the stored hidden tensors, ~5e-3 rms on (m, logs) per block, not the flow tensor's.
+    # Set `decoder.io_bf16` (train.train_step(fp16_run=True) sets "all") or GLOWTTS_IO=bf16|bf16-hidden.  Applies to training
+    # forwards whose blocks all run as native flow blocks at instantiated shapes; anything else runs the fp32 path.
+    io_bf16 = {"bf16": "all", "bf16-hidden": "hidden"}.get(__import__("os").environ.get("GLOWTTS_IO", "fp32"), False)
+
+    def _blocks(self):
+        """[(ActNorm, InvConvNear, CouplingBlock), ...] when the flow list has the standard layout, else None."""
+        fl = list(self.flows)
+        if len(fl) % 3:
+            return None
+        out = []
+        for i in range(0, len(fl), 3):
+            if not (isinstance(fl[i], ActNorm) and isinstance(fl[i + 1], InvConvNear) and isinstance(fl[i + 2], CouplingBlock)):
+                return None
+            out.append((fl[i], fl[i + 1], fl[i + 2]))
+        return out
+
+    def _use_bf16(self, x, g, reverse) -> int:
+        """0 = fp32 tensors, 1 = hidden tensors bf16, 3 = hidden and flow tensors bf16 (csrc `io` flags)."""
+        if not self.io_bf16 or reverse or not x.is_cuda:
+            return 0
+        blocks = self._blocks()
+        if not blocks:
+            return 0
+        b, c, t = x.shape
+        shape = (b, c * self.n_sqz, t // self.n_sqz)
+        if not all(convops.flow_block_eligible(a, i, c_, x, g) and convops.flow_block_bf16_ok(c_, shape) for a, i, c_ in blocks):
+            return 0
+        return 1 if self.io_bf16 == "hidden" else 3
+
     def forward(self, x, x_mask, g=None, reverse=False):
+        io = self._use_bf16(x, g, reverse)
+        flow16 = bool(io & 2)
         if self.n_sqz > 1:
-            x, x_mask = squeeze(x, x_mask, self.n_sqz)
+            x, x_mask = squeeze(x, x_mask, self.n_sqz, io_bf16=flow16)
+        elif flow16:
+            x = x.to(torch.bfloat16)
         if reverse:
             for f in reversed(self.flows):
                 x, _ = f(x, x_mask, g=g, reverse=True)
@@ -149,14 +191,14 @@ class FlowSpecDecoder(nn.Module):
                 nxt = self.flows[i + 1] if i + 1 < len(self.flows) else None
                 cpl = self.flows[i + 2] if i + 2 < len(self.flows) else None
                 if (isinstance(f, ActNorm) and isinstance(nxt, InvConvNear) and isinstance(cpl, CouplingBlock)
-                        and convops.flow_block_eligible(f, nxt, cpl, x, g)):
+                        and (io or convops.flow_block_eligible(f, nxt, cpl, x, g))):
                     # the whole block [ActNorm, InvConvNear, CouplingBlock] as one autograd node, one native call each way
                     wn = cpl.wn
                     if not hasattr(cpl, "_block_plan"):
                         cpl._block_plan = convops.FlowBlockPlan()
                     drop, wn._drop_pre = getattr(wn, "_drop_pre", None), None
                     cfg = (nxt.n_split, bool(cpl.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0,
-                           wn.dilation_rate, wn.n_layers, wn.hidden_channels)
+                           wn.dilation_rate, wn.n_layers, wn.hidden_channels, io)
                     x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan,
                                                   *convops.flow_block_params(f, nxt, cpl))
                     i += 3
@@ -171,7 +213,9 @@ class FlowSpecDecoder(nn.Module):
                 logdets.append(logdet)
             logdet_tot = torch.stack(logdets, 0).sum(0) if len(logdets) > 1 else (logdets[0] if logdets else 0)
         if self.n_sqz > 1:
-            x, x_mask = unsqueeze(x, x_mask, self.n_sqz)
+            x, x_mask = unsqueeze(x, x_mask, self.n_sqz, io_bf16=flow16)
+        elif flow16:
+            x = x.float()
         return x, logdet_tot
 
     def store_inverse(self):

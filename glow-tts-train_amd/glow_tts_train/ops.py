@@ -286,18 +286,19 @@ class ResSkipFn(Function):
 
 # ----------------------------------------------------------------------------------------------------------------
 class SqueezeFn(Function):
-    """utils.py:135-147 (time -> channel fold, masked); backward is the unsqueeze kernel with the same mask."""
+    """utils.py:135-147 (time -> channel fold, masked); backward is the unsqueeze kernel with the same mask.
+    io: the squeezed tensor is bf16 in HBM (the flow decoder's bf16-tensor mode); the un-squeezed side is always fp32."""
 
     @staticmethod
-    def forward(ctx, x, m2, n):
+    def forward(ctx, x, m2, n, io=False):
         x = f32(_c(x))
         B, C, T = x.shape
         Ts = T // n
-        xs = torch.empty(B, C * n, Ts, device=x.device, dtype=torch.float32)
+        xs = torch.empty(B, C * n, Ts, device=x.device, dtype=torch.bfloat16 if io else torch.float32)
         ms = torch.empty(B, Ts, device=x.device, dtype=torch.float32)
-        call("glowtts_squeeze", ptr(x), ptr(m2), ptr(xs), ptr(ms), B, C, T, n)
+        call("glowtts_squeeze_io", ptr(x), ptr(m2), ptr(xs), ptr(ms), B, C, T, n, int(io))
         ctx.save_for_backward(ms)
-        ctx.n, ctx.T = n, T
+        ctx.n, ctx.T, ctx.io = n, T, bool(io)
         ctx.mark_non_differentiable(ms)
         return xs, ms
 
@@ -306,6 +307,8 @@ class SqueezeFn(Function):
     def backward(ctx, dxs, _dms):
         (ms,) = ctx.saved_tensors
         dxs = _c(dxs)
+        if ctx.io and dxs.dtype != torch.bfloat16:
+            dxs = dxs.to(torch.bfloat16)
         B, Cn, Ts = dxs.shape
         n = ctx.n
         if ctx.T == Ts * n:
@@ -313,26 +316,28 @@ class SqueezeFn(Function):
         else:  # frames cut off by the floor division get zero gradient
             dx = torch.zeros(B, Cn // n, ctx.T, device=dxs.device, dtype=torch.float32)
         if ctx.T == Ts * n:
-            call("glowtts_unsqueeze", ptr(dxs), ptr(ms), ptr(dx), None, B, Cn // n, Ts, n)
+            call("glowtts_unsqueeze_io", ptr(dxs), ptr(ms), ptr(dx), None, B, Cn // n, Ts, n, int(ctx.io))
         else:
             tmp = torch.empty(B, Cn // n, Ts * n, device=dxs.device, dtype=torch.float32)
-            call("glowtts_unsqueeze", ptr(dxs), ptr(ms), ptr(tmp), None, B, Cn // n, Ts, n)
+            call("glowtts_unsqueeze_io", ptr(dxs), ptr(ms), ptr(tmp), None, B, Cn // n, Ts, n, int(ctx.io))
             dx[:, :, : Ts * n] = tmp
-        return dx, None, None
+        return dx, None, None, None
 
 
 class UnsqueezeFn(Function):
-    """utils.py:150-160; backward is the squeeze kernel (mask value per squeezed column)."""
+    """utils.py:150-160; backward is the squeeze kernel (mask value per squeezed column).  io: the squeezed INPUT is bf16."""
 
     @staticmethod
-    def forward(ctx, xs, ms, n):
-        xs = f32(_c(xs))
+    def forward(ctx, xs, ms, n, io=False):
+        xs = _c(xs)
+        if xs.dtype != (torch.bfloat16 if io else torch.float32):
+            raise RuntimeError(f"glow_tts_train: unsqueeze got {xs.dtype} with io={io}")
         B, Cn, Ts = xs.shape
         x = torch.empty(B, Cn // n, Ts * n, device=xs.device, dtype=torch.float32)
         mo = torch.empty(B, Ts * n, device=xs.device, dtype=torch.float32)
-        call("glowtts_unsqueeze", ptr(xs), ptr(ms), ptr(x), ptr(mo), B, Cn // n, Ts, n)
+        call("glowtts_unsqueeze_io", ptr(xs), ptr(ms), ptr(x), ptr(mo), B, Cn // n, Ts, n, int(io))
         ctx.save_for_backward(mo)
-        ctx.n = n
+        ctx.n, ctx.io = n, bool(io)
         ctx.mark_non_differentiable(mo)
         return x, mo
 
@@ -340,12 +345,12 @@ class UnsqueezeFn(Function):
     @once_differentiable
     def backward(ctx, dx, _dmo):
         (mo,) = ctx.saved_tensors
-        dx = _c(dx)
+        dx = f32(_c(dx))
         B, C, T = dx.shape
         n = ctx.n
-        dxs = torch.empty(B, C * n, T // n, device=dx.device, dtype=torch.float32)
-        call("glowtts_squeeze", ptr(dx), ptr(mo), ptr(dxs), None, B, C, T, n)
-        return dxs, None, None
+        dxs = torch.empty(B, C * n, T // n, device=dx.device, dtype=torch.bfloat16 if ctx.io else torch.float32)
+        call("glowtts_squeeze_io", ptr(dx), ptr(mo), ptr(dxs), None, B, C, T, n, int(ctx.io))
+        return dxs, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------

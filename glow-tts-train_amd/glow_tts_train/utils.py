@@ -107,21 +107,22 @@ def clip_grad_value_(parameters, clip_value, norm_type=2):
     return _FlatGradView(sumsq, float(norm_type))
 
 
-def squeeze(x, x_mask=None, n_sqz=2):
-    """Fold n_sqz consecutive frames into channels (reference utils.py:135-147)."""
+def squeeze(x, x_mask=None, n_sqz=2, io_bf16=False):
+    """Fold n_sqz consecutive frames into channels (reference utils.py:135-147).  `io_bf16`: the squeezed tensor leaves as
+    bf16 (the flow decoder's bf16-tensor mode; not part of the reference signature)."""
     b, c, t = x.size()
     if x_mask is None:
-        x_mask = torch.ones(b, 1, t, device=x.device, dtype=x.dtype)
-    xs, ms = ops.SqueezeFn.apply(x, ops.mask2d(x_mask), n_sqz)
+        x_mask = torch.ones(b, 1, t, device=x.device, dtype=torch.float32)
+    xs, ms = ops.SqueezeFn.apply(x, ops.mask2d(x_mask), n_sqz, bool(io_bf16))
     return xs, ms.unsqueeze(1)
 
 
-def unsqueeze(x, x_mask=None, n_sqz=2):
-    """Inverse of squeeze (reference utils.py:150-160)."""
+def unsqueeze(x, x_mask=None, n_sqz=2, io_bf16=False):
+    """Inverse of squeeze (reference utils.py:150-160).  `io_bf16`: the squeezed input is bf16; the result is fp32."""
     b, c, t = x.size()
     if x_mask is None:
-        x_mask = torch.ones(b, 1, t, device=x.device, dtype=x.dtype)
-    xu, mu = ops.UnsqueezeFn.apply(x, ops.mask2d(x_mask), n_sqz)
+        x_mask = torch.ones(b, 1, t, device=x.device, dtype=torch.float32)
+    xu, mu = ops.UnsqueezeFn.apply(x, ops.mask2d(x_mask), n_sqz, bool(io_bf16))
     return xu, mu.unsqueeze(1)
 
 

@@ -278,6 +278,81 @@ int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float *x, const 
                            float *dx_wn, float *dx, int B, int C, int H, int T, int taps, int dil_rate, int n_split,
                            int sigmoid_scale, int two_source, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 
+/* ---- bf16 tensors in HBM (BASELINE configs[2]): the `_io` forms ---------------------------------------------------------
+ * Same operators, same shapes and element indexing; `io` (or io_x / io_y) = 1 declares the ACTIVATION tensors bf16 in HBM
+ * (void pointers), 0 = fp32 (then each is exactly the function without the suffix).  What stays fp32 in either case:
+ * parameters, packed weights, biases, masks, conditioning rows, log-determinants, the coupling's (m, logs) = `out`, every
+ * parameter gradient, and all arithmetic: bf16 operands go through v_mfma_f32_16x16x32_bf16 with fp32 accumulation, the
+ * elementwise flows widen to fp32 in registers, results are rounded to nearest even on the way out
+ * (reference: the autocast branch train.py:116-121, whose conv / matmul outputs are half precision).
+ * Convolutions read bf16 planes of the packed weights: glowtts_split_planes(wp, n, planes, 3) after every packing, then
+ * glowtts_conv_bind_planes_ns(wp, n, planes, 3) on the launching thread (wp = NULL unbinds).  Plane 0 is the weight rounded
+ * to bf16 and is all a convolution with bf16 results reads; one with fp32 results (io_y = 0: the coupling's end conv, whose
+ * `logs` rows are summed into the log-determinant) multiplies the bf16 activations by all three planes, i.e. by the exact
+ * fp32 weights — a weight rounding repeats in every frame and would add up coherently in that sum.  The weight gradient for
+ * bf16 tensors is glowtts_conv_wrw_planes with n_planes = 1 (the "plane" is the tensor itself; no masks: callers pass
+ * gradients that are masked already).  Limits: T % 4 == 0, dilation 1 for the weight gradient; shapes of a flow block.
+ *   conv_fwd_io        : io_x = x (and the implied second source), io_y = y and addend
+ *   conv_gate_fwd_io / conv_res_skip_fwd_io / conv_gate_bwd_io / res_skip_bwd_io : io = every activation tensor
+ *   actnorm_invconv_*_io, coupling_*_io : io = the flow tensors x, z, dz, dx; `out` stays fp32; coupling_bwd's io_dout = its
+ *       dout (the end conv's output gradient: a hidden-side tensor); actnorm_invconv_fwd's z0h (may be NULL) receives a
+ *       bf16 copy (B, C/2, T) of z's first half for a bf16 start conv behind an fp32 flow tensor
+ *   squeeze_io / unsqueeze_io : io = the SQUEEZED tensor only (mel frames / the latent handed to the loss stay fp32)
+ *   wn_*_io : io = every slab; wn_bwd_io's mask_input_grad = 1 multiplies the stack's own input gradient by the mask
+ *       (required with io = 1, where the two-source form is not available)
+ *   flow_block_*_io : io bit 0 = the coupling network's hidden tensors (h0, xs, acts, ts, skip, their gradients, dout), bit 1
+ *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
+ *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads */
+int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);
+int glowtts_conv_fwd_io(const void *x, long x_bs, const float *wp, const float *bias, const float *mask, const void *addend,
+                        long addend_bs, void *y, long y_bs, int B, int Cin, int M, int T, int taps, int dil, int pad,
+                        int mask_in, int mask_out, int mask_add, int io_x, int io_y, glowtts_stream_t stream);
+int glowtts_conv_gate_fwd_io(const void *x, const float *wp, const float *bias, const float *cond, const unsigned char *drop,
+                             float drop_scale, void *acts, void *ts, int B, int H, int T, int taps, int dil, int pad, int io,
+                             glowtts_stream_t stream);
+int glowtts_conv_res_skip_fwd_io(const void *acts, const float *wp, const float *bias, const float *mask, const void *x_in,
+                                 const void *skip_in, void *x_out, void *skip_out, int B, int H, int T, int last, int io,
+                                 glowtts_stream_t stream);
+int glowtts_conv_gate_bwd_io(const void *d_rs, const void *d_rs2, const float *wp_b, const void *ts,
+                             const unsigned char *drop, float drop_scale, void *d_pre, int B, int M_rs, int H, int T, int io,
+                             glowtts_stream_t stream);
+int glowtts_res_skip_bwd_io(const void *dx_out, const void *dskip, const float *mask, void *dx, void *drs, int B, int H,
+                            int T, int last, int io, glowtts_stream_t stream);
+int glowtts_actnorm_invconv_fwd_io(const void *x, const float *mask, const float *logs, const float *bias, const float *w,
+                                   const float *logdet_w, const float *x_len, void *z, float *logdet, void *z0h, int B, int C,
+                                   int T, int n_split, int io, glowtts_stream_t stream);
+int glowtts_actnorm_invconv_bwd_io(const void *x, const float *mask, const float *logs, const float *bias, const float *w,
+                                   const float *w_inv, const void *dz, const float *dlogdet, const float *x_len, void *dx,
+                                   float *dlogs, float *dbias, float *dw, int B, int C, int T, int n_split, int io,
+                                   glowtts_stream_t stream);
+int glowtts_coupling_fwd_io(const void *x, const float *out, const float *mask, void *z, float *logdet, int B, int C, int T,
+                            int sigmoid_scale, int reverse, int io, glowtts_stream_t stream);
+int glowtts_coupling_bwd_io(const void *x, const float *out, const float *mask, const void *dz, const float *dlogdet,
+                            void *dx, void *dout, int B, int C, int T, int sigmoid_scale, int io, int io_dout,
+                            glowtts_stream_t stream);
+int glowtts_squeeze_io(const float *x, const float *mask, void *xs, float *ms, int B, int C, int T, int n, int io,
+                       glowtts_stream_t stream);
+int glowtts_unsqueeze_io(const void *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq, int n, int io,
+                         glowtts_stream_t stream);
+int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
+                      const unsigned char *drop, float drop_scale, void *xs, void *acts, void *ts, void *skip, int B, int H,
+                      int T, int taps, int dil_rate, int io, glowtts_stream_t stream);
+int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const void *xs, const void *acts,
+                      const void *ts, const float *mask, const unsigned char *drop, float drop_scale, const void *dskip,
+                      void *d_rs, void *d_xin, void *dx, const long long *unpack_desc, const int *unpack_prefix, int n_conv,
+                      int total_rows, int B, int H, int T, int taps, int dil_rate, int two_source, int mask_input_grad, int io,
+                      glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
+int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
+                              const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs, void *acts, void *ts,
+                              void *skip, float *out, void *z, float *logdet, int B, int C, int H, int T, int taps,
+                              int dil_rate, int n_split, int sigmoid_scale, int io, glowtts_stream_t stream);
+int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
+                              const unsigned char *drop, float drop_scale, const void *y, const void *y0h, const void *h0, const void *xs,
+                              const void *acts, const void *ts, const void *skip, const float *out, const void *dz,
+                              const float *dlogdet, void *dy, void *dout, void *dskip, void *d_rs, void *d_xin, void *dx_wn,
+                              void *dx, int B, int C, int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
+                              int two_source, int io, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
+
 /* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
  * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)
  * (head h = channels [h*dk, (h+1)*dk)); emb_k / emb_v: (1 or H, 2*window+1, dk) or NULL (no relative terms);
