@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--no-split-math", action="store_true",
                     help="skip the extra leg that times the same step with the WN convolutions in bf16x6 split arithmetic")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: add a leg (`bf16_io`, beside `value`, never instead of it) that times the same step with the flow "
+                         "decoder's activation tensors kept in HBM as bf16 (BASELINE configs[2]'s arithmetic; use with --batch 64 "
+                         "--t-mel 1000 for its sizes)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="N=1 rehearsal: open a one-rank RCCL group and run the DP reducer's real launch path (buckets "
                          "all-reduced from the comm stream during backward); reported under `comm`, for inspection only")
@@ -371,6 +375,35 @@ def main():
             out["split_math"] = None
         finally:
             convops.set_conv_math(previous)         # the roofline pass below measures the native kernels
+
+    # ---- extra leg (not `value`): bf16 activation tensors in HBM for the flow decoder (decoder.io_bf16 = "all")
+    if args.dtype == "bf16" and mode == "eager":
+        dec = model.decoder
+        dec.io_bf16 = "all"
+        try:
+            for _ in range(3):
+                step_fn()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loss = step_fn()
+            fence()
+            dtb = time.perf_counter() - t1
+            if world > 1:
+                tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtb = float(tt)
+            out["bf16_io"] = {"value": frames / dtb, "unit": "mel-frames/s", "ms_per_step": 1e3 * dtb / args.steps,
+                              "dtype": "bf16 tensors / fp32 accumulate", "loss_after_these_further_steps": float(loss),
+                              "what": "flow decoder: squeezed flow tensor and every hidden tensor of the coupling networks bf16 in "
+                                      "HBM, v_mfma_f32_16x16x32_bf16 with fp32 accumulation, fp32 parameters / (m, logs) / "
+                                      "log-determinants / parameter gradients; text encoder and losses as in `value`"}
+            log(f"bf16-tensor leg: {out['bf16_io']['ms_per_step']:.2f} ms/step")
+        except Exception as exc:
+            log(f"bf16-tensor leg failed ({type(exc).__name__}: {exc}); reported as null")
+            out["bf16_io"] = None
+        finally:
+            dec.io_bf16 = False
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if reducer is not None:

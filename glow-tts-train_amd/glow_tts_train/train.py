@@ -52,23 +52,36 @@ def train(train_loader, config, model_dir: Path, model=None, optimizer=None, glo
     return global_step
 
 
-def train_batch(model, optimizer, batch, grad_clip: float, reducer=None) -> torch.Tensor:
-    """One optimisation step on one already-resident batch; returns the (device) loss tensor, un-synchronised."""
+def train_batch(model, optimizer, batch, grad_clip: float, reducer=None, scaler=None) -> torch.Tensor:
+    """One optimisation step on one already-resident batch; returns the (device) loss tensor, un-synchronised.
+    `scaler` (a torch GradScaler, reduced-precision runs only): the reference's sequence train.py:133-141 — scale the loss,
+    un-scale the gradients before clipping, let the scaler skip the update on overflow."""
     x, x_lengths, y, y_lengths, speaker_ids = batch
     optimizer.zero_grad()
+    flat = getattr(optimizer, "_optim", optimizer)
     with zero_scope(y.device):          # the step's atomically-accumulated temporaries share one zero fill
         (z, z_m, z_logs, logdet, z_mask), _, (_attn, logw, logw_) = model(x, x_lengths, y, y_lengths, g=speaker_ids)
         loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, x_lengths)
-        loss.backward()
+        (loss if scaler is None else scaler.scale(loss)).backward()
         join_side_streams()             # the encoder branch ran (forward and backward) on a second stream
         flush_groups()                  # weight gradients still packed in a ConvGroup (none, unless a backward was skipped)
         if reducer is not None:
             reducer.finish()
         loss = loss.detach()
-    flat = getattr(optimizer, "_optim", optimizer)
+    if scaler is not None:
+        scaler.unscale_(flat)
     if not (hasattr(flat, "clip_grad_value_") and flat.clip_grad_value_(grad_clip) is not None):
         clip_grad_value_(model.parameters(), grad_clip)
-    optimizer.step()
+    if scaler is None:
+        optimizer.step()
+    else:
+        # train.py:140: scaler.step(optimizer._optim).  The reference's wrapper never sees that call, so its Noam counter
+        # stands still in fp16 runs (SURVEY.md Q6); here the schedule lives on the device inside FlatAdam.step and advances
+        # with every update that is actually applied — the host mirror follows it.
+        scaler.step(flat)
+        scaler.update()
+        if hasattr(optimizer, "_update_learning_rate"):
+            optimizer._update_learning_rate()
     return loss
 
 
@@ -108,18 +121,29 @@ class GraphedTrainStep:
 
 def train_step(global_step: int, epoch: int, model, optimizer, config, train_loader, fp16_run: bool = False,
                scaler=None, reducer=None, on_loss: typing.Optional[typing.Callable] = None) -> int:
-    """Same signature and return value as the reference's `train_step` (train.py:91-100); fp32 only (the reference's
-    fp16 branch bypasses the Noam schedule)."""
-    if fp16_run:
-        raise NotImplementedError("glow_tts_train (MI355X build): fp16_run is not implemented; the path is fp32")
+    """Same signature and return value as the reference's `train_step` (train.py:91-100).
+
+    `fp16_run` (reference train.py:116-121, 133-141: `autocast()` + GradScaler) selects the reduced-precision form of THIS
+    build: the flow decoder keeps its activation tensors in HBM as bf16 (`decoder.io_bf16 = "all"`, models.FlowSpecDecoder)
+    with fp32 parameters, log-determinants and accumulation.  bf16 has fp32's exponent range, so no loss scaling is needed:
+    `scaler` may be None; a GradScaler that is passed in is driven exactly as the reference drives it."""
     from .dataset import DeviceBatches
 
     model.train()
+    bare = model.module if hasattr(model, "module") else model
+    decoder = getattr(bare, "decoder", None)
+    before = getattr(decoder, "io_bf16", False)
+    if fp16_run and decoder is not None and not before:
+        decoder.io_bf16 = "all"
     losses = []
     device = next(model.parameters()).device
-    for batch in DeviceBatches(train_loader, device):      # batch k+1 is copied to HBM while step k runs
-        losses.append(train_batch(model, optimizer, batch, config.grad_clip, reducer))
-        global_step += 1
+    try:
+        for batch in DeviceBatches(train_loader, device):      # batch k+1 is copied to HBM while step k runs
+            losses.append(train_batch(model, optimizer, batch, config.grad_clip, reducer, scaler if fp16_run else None))
+            global_step += 1
+    finally:
+        if decoder is not None:
+            decoder.io_bf16 = before
     if losses and on_loss is not None:
         on_loss(epoch, float(torch.stack(losses).mean()), global_step)   # ONE sync per epoch
     return global_step

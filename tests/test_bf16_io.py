@@ -186,3 +186,62 @@ def test_config3_full_size_logdet_tolerance(G, mode, ld_tol, z_tol):
     assert _per_element(l1, l0, lens) < 2e-4, _per_element(l1, l0, lens)
     assert rel_err(z1, z0) < z_tol, rel_err(z1, z0)
     assert torch.isfinite(z1).all()
+
+
+def test_fp16_run_selects_bf16_tensors_and_trains(G):
+    """train.train_step(fp16_run=True) (reference train.py:133-141) runs the bf16-tensor decoder, with and without a
+    GradScaler, and its losses follow the fp32 run of the same batches."""
+    from glow_tts_train import config, optimize
+    from glow_tts_train.train import train_step
+
+    cfg = config.TrainingConfig()
+    cfg.model.num_symbols = 60
+    cfg.model.n_blocks_dec = 2
+    cfg.model.n_layers_enc = 1
+
+    def batches():
+        g = torch.Generator().manual_seed(4)
+        out = []
+        for _ in range(3):
+            x = torch.randint(1, 60, (4, 20), generator=g)
+            xl = torch.tensor([20, 18, 15, 11])
+            y = torch.randn(4, 80, 96, generator=g)
+            yl = torch.tensor([96, 88, 72, 56])
+            out.append((x * (torch.arange(20)[None] < xl[:, None]), xl, y * (torch.arange(96)[None, None] < yl[:, None, None]), yl, None))
+        return out
+
+    results = {}
+    for tag, fp16, scaler in (("fp32", False, None), ("bf16", True, None), ("bf16+scaler", True, "make")):
+        torch.manual_seed(1234)
+        model, opt = G.models.setup_model(cfg, use_cuda=True)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        for f in model.decoder.flows:
+            if hasattr(f, "wn"):
+                f.wn.p_dropout = 0.0
+        with torch.no_grad():
+            for f in model.decoder.flows:
+                if hasattr(f, "end"):
+                    f.end.weight.normal_(0, 0.01)
+        seen = []
+        orig = G.convops.FlowBlockFn.forward
+        G.convops.FlowBlockFn.forward = staticmethod(lambda ctx, x, *a, _o=orig: (seen.append(x.dtype), _o(ctx, x, *a))[1])
+        losses = []
+        try:
+            sc = torch.amp.GradScaler("cuda", init_scale=1024.0) if scaler else None
+            step = train_step(1, 1, model, opt, cfg, batches(), fp16_run=fp16, scaler=sc,
+                              on_loss=lambda e, l, s_: losses.append(l))
+        finally:
+            G.convops.FlowBlockFn.forward = orig
+        assert step == 4 and opt.step_num == 4
+        assert set(seen) == ({torch.bfloat16} if fp16 else {torch.float32}), seen
+        assert model.decoder.io_bf16 is False                      # restored after the epoch
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+        results[tag] = (losses[0], opt._optim.flat_p.clone())
+    l32 = results["fp32"][0]
+    for tag in ("bf16", "bf16+scaler"):
+        assert abs(results[tag][0] - l32) < 2e-2 * abs(l32), (tag, results[tag][0], l32)
+    # the scaler only rescales: same parameters as the unscaled bf16 run up to the round-off of bf16 gradients times 1024
+    d = (results["bf16+scaler"][1] - results["bf16"][1]).abs().max()
+    assert float(d) < 2e-2, float(d)
