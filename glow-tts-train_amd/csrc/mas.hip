@@ -37,7 +37,8 @@ __device__ unsigned long long g_mas_trace[1024 * 8];
 template <int R>
 __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ value, float *__restrict__ path,
                                                   const int *__restrict__ t_xs, const int *__restrict__ t_ys,
-                                                  int Tx, int Ty, int log2tc, int nblk32, int gdirs) {
+                                                  int Tx, int Ty, int log2tc, int nblk32, int gdirs,
+                                                  int *__restrict__ first_out, int *__restrict__ tok_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROWPAD = R * 64 + 1;
     const int TC = 1 << log2tc;
@@ -219,6 +220,19 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     MAS_TRACE(3);
     __syncthreads();
 
+    // ---- optional by-products of the search: the spans (first frame of every text row; first[Tx] = t_y) and the token of
+    // every frame (-1 past the utterance) — what the expansion z_m = attn^T x_m and log(sum attn) need instead of the path
+    if (first_out != nullptr)
+        for (int x = threadIdx.x; x <= Tx; x += 256) first_out[(size_t)b * (Tx + 1) + x] = first[x];
+    if (tok_out != nullptr && ((Ty & 3) != 0 || (reinterpret_cast<uintptr_t>(path) & 15u) != 0)) {
+        for (int y = threadIdx.x; y < Ty; y += 256) {
+            int t = -1;
+            for (int x = 0; x < tx; ++x)
+                if (y >= first[x] && y < first[x + 1]) t = x;
+            tok_out[(size_t)b * Ty + y] = t;
+        }
+    }
+
     // ---- path write: all waves, coalesced -------------------------------------------------------------------------
     float *pb = path + (size_t)b * Tx * Ty;
     if ((Ty & 3) == 0 && ((reinterpret_cast<uintptr_t>(path) & 15u) == 0)) {
@@ -229,13 +243,17 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
             const int y = q << 2;
             float4 *dst = reinterpret_cast<float4 *>(pb) + q;
             int lo = first[0];
+            int tk0 = -1, tk1 = -1, tk2 = -1, tk3 = -1;
 #pragma unroll 4
             for (int x = 0; x < Tx; ++x) {
                 const int hi = first[x + 1];               // same address in every lane: an LDS broadcast
-                dst[(size_t)x * ty4] = make_float4((y + 0 >= lo && y + 0 < hi) ? 1.0f : 0.0f, (y + 1 >= lo && y + 1 < hi) ? 1.0f : 0.0f,
-                                                   (y + 2 >= lo && y + 2 < hi) ? 1.0f : 0.0f, (y + 3 >= lo && y + 3 < hi) ? 1.0f : 0.0f);
+                const bool i0 = y + 0 >= lo && y + 0 < hi, i1 = y + 1 >= lo && y + 1 < hi, i2 = y + 2 >= lo && y + 2 < hi,
+                           i3 = y + 3 >= lo && y + 3 < hi;
+                dst[(size_t)x * ty4] = make_float4(i0 ? 1.0f : 0.0f, i1 ? 1.0f : 0.0f, i2 ? 1.0f : 0.0f, i3 ? 1.0f : 0.0f);
+                tk0 = i0 ? x : tk0; tk1 = i1 ? x : tk1; tk2 = i2 ? x : tk2; tk3 = i3 ? x : tk3;
                 lo = hi;
             }
+            if (tok_out != nullptr) *reinterpret_cast<int4 *>(tok_out + (size_t)b * Ty + y) = make_int4(tk0, tk1, tk2, tk3);
         }
     } else {
         const int n = Tx * Ty;
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
 
 template <int R>
 static int launch_mas(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B, int Tx,
-                      int Ty, hipStream_t stream) {
+                      int Ty, int *first_out, int *tok_out, hipStream_t stream) {
     const int nblk32 = (Ty + 31) / 32;
     const size_t budget = 150 * 1024;
     const size_t first_b = (((size_t)(Tx + 1) * 4 + 15) & ~(size_t)15);
@@ -267,37 +285,45 @@ static int launch_mas(const float *value, float *path, const int32_t *t_x, const
     static LdsLimit limit;   // per device: raised only when a launch needs more than any earlier one
     if (int rc_ = limit.ensure(reinterpret_cast<const void *>(&mas_kernel<R>), bytes, "glowtts_mas_path")) return rc_;
     hipLaunchKernelGGL(mas_kernel<R>, dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
-                       nblk32, gdirs);
+                       nblk32, gdirs, first_out, tok_out);
     GLOWTTS_LAUNCH_CHECK("glowtts_mas_path");
 }
 
 }  // namespace glowtts
 
-extern "C" int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B,
-                                int Tx, int Ty, glowtts_stream_t stream) {
+extern "C" int glowtts_mas_path_spans(const float *value, float *path, int32_t *first, int32_t *tok, const int32_t *t_x,
+                                      const int32_t *t_y, int B, int Tx, int Ty, glowtts_stream_t stream) {
     using namespace glowtts;
     GLOWTTS_CHECK_ARG(value && path && t_x && t_y, "glowtts_mas_path: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && Tx >= 0 && Ty >= 0, "glowtts_mas_path: negative size");
     if (B == 0 || Tx == 0 || Ty == 0) return 0;
     GLOWTTS_CHECK_ARG(Tx <= 2048, "glowtts_mas_path: Tx=%d exceeds the 2048-token limit of this build", Tx);
     GLOWTTS_CHECK_ARG((long)Tx * Ty < (1L << 31), "glowtts_mas_path: lattice too large");
+    GLOWTTS_CHECK_ARG(!tok || (Ty & 3) != 0 || aligned16(tok), "glowtts_mas_path: tok must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int r = (Tx + 63) / 64;
+#define GLOWTTS_MAS(R) return launch_mas<R>(value, path, t_x, t_y, B, Tx, Ty, first, tok, s)
     switch (r) {
-        case 1: return launch_mas<1>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 2: return launch_mas<2>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 3: return launch_mas<3>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 4: return launch_mas<4>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 5: return launch_mas<5>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 6: return launch_mas<6>(value, path, t_x, t_y, B, Tx, Ty, s);
-        case 7: case 8: return launch_mas<8>(value, path, t_x, t_y, B, Tx, Ty, s);
+        case 1: GLOWTTS_MAS(1);
+        case 2: GLOWTTS_MAS(2);
+        case 3: GLOWTTS_MAS(3);
+        case 4: GLOWTTS_MAS(4);
+        case 5: GLOWTTS_MAS(5);
+        case 6: GLOWTTS_MAS(6);
+        case 7: case 8: GLOWTTS_MAS(8);
         default: break;
     }
     // beyond 512 tokens (no realistic utterance; the reference's Cython loop has no limit, so neither fails here)
-    if (r <= 12) return launch_mas<12>(value, path, t_x, t_y, B, Tx, Ty, s);
-    if (r <= 16) return launch_mas<16>(value, path, t_x, t_y, B, Tx, Ty, s);
-    if (r <= 24) return launch_mas<24>(value, path, t_x, t_y, B, Tx, Ty, s);
-    return launch_mas<32>(value, path, t_x, t_y, B, Tx, Ty, s);
+    if (r <= 12) GLOWTTS_MAS(12);
+    if (r <= 16) GLOWTTS_MAS(16);
+    if (r <= 24) GLOWTTS_MAS(24);
+    GLOWTTS_MAS(32);
+#undef GLOWTTS_MAS
+}
+
+extern "C" int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B,
+                                int Tx, int Ty, glowtts_stream_t stream) {
+    return glowtts_mas_path_spans(value, path, nullptr, nullptr, t_x, t_y, B, Tx, Ty, stream);
 }
 
 #ifdef GLOWTTS_TRACE

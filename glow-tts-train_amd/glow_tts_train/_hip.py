@@ -25,6 +25,10 @@ _F = ctypes.c_float
 # name -> argument ctypes (every function returns int; the trailing stream argument is appended automatically)
 _SIGNATURES = {
     "glowtts_mas_path": [_P, _P, _P, _P, _I, _I, _I],
+    "glowtts_mas_path_spans": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_align_logp": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "glowtts_align_expand_fwd": [_P, _P, _P, _I, _I, _I, _I],
+    "glowtts_align_expand_bwd": [_P, _P, _P, _I, _I, _I, _I],
     "glowtts_mask_len": [_P, _P, _I, _I],
     "glowtts_actnorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_actnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],

@@ -21,6 +21,7 @@ from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 
 _actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
 _flow_block_apply = _hip.direct_apply(convops.FlowBlockFn)
+_align_expand_apply = _hip.direct_apply(ops.AlignExpandFn)
 
 _LOGGER = logging.getLogger("glow_tts_train.models")
 
@@ -318,6 +319,19 @@ class FlowGenerator(nn.Module):
                 t.record_stream(main)
         else:
             z, logdet = self.decoder(y, z_mask, g=g, reverse=False)
+        if x.is_cuda:
+            # one contraction for the lattice, the search, then z_m / z_logs by GATHER through the frame -> token map the search
+            # kernel hands out (the reference's four bmm's with a one-hot matrix, ~25 launches, become 4)
+            mean_only = self.mean_only and not x_logs.requires_grad
+            with torch.no_grad():
+                logp = ops.align_logp(x_m, None if mean_only else x_logs, z)
+                path, first, tok = ops.mas_path_spans(logp, x_lengths, y_lengths)
+            attn = path.unsqueeze(1)
+            z_m = _align_expand_apply(x_m, tok, first)
+            z_logs = torch.zeros_like(z_m) if mean_only else _align_expand_apply(x_logs, tok, first)
+            counts = (first[:, 1:] - first[:, :-1]).to(x_mask.dtype).unsqueeze(1)          # = sum(attn, -1)
+            logw_ = torch.log(1e-8 + counts) * x_mask
+            return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
         attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
         with torch.no_grad():
             logp = self._pairwise_log_likelihood(x_m, x_logs, z)

@@ -394,6 +394,57 @@ def mas_path(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -> torch
     return path
 
 
+def mas_path_spans(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor):
+    """The search plus its by-products: (path (B,Tx,Ty) 0/1 fp32, first (B,Tx+1) int32, tok (B,Ty) int32)."""
+    value = f32(_c(value.detach()))
+    B, Tx, Ty = value.shape
+    path = torch.empty_like(value)
+    first = torch.empty(B, Tx + 1, device=value.device, dtype=torch.int32)
+    tok = torch.empty(B, Ty, device=value.device, dtype=torch.int32)
+    t_x = t_x.to(device=value.device, dtype=torch.int32).contiguous()
+    t_y = t_y.to(device=value.device, dtype=torch.int32).contiguous()
+    call("glowtts_mas_path_spans", ptr(value), ptr(path), ptr(first), ptr(tok), ptr(t_x), ptr(t_y), B, Tx, Ty)
+    return path, first, tok
+
+
+def align_logp(x_m: torch.Tensor, x_logs: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:
+    """log N(z_t'; x_m_t, exp(x_logs_t)) for every (token, frame) pair -> (B, Tx, Ty) (reference models.py:362-376), one
+    kernel.  x_logs None = log-std 0 (mean_only)."""
+    x_m, z = f32(_c(x_m.detach())), f32(_c(z.detach()))
+    xl = None if x_logs is None else f32(_c(x_logs.detach()))
+    B, C, Tx = x_m.shape
+    Ty = z.shape[2]
+    logp = torch.empty(B, Tx, Ty, device=z.device, dtype=torch.float32)
+    call("glowtts_align_logp", ptr(x_m), ptr(xl), ptr(z), ptr(logp), B, C, Tx, Ty)
+    return logp
+
+
+class AlignExpandFn(Function):
+    """z_stats = attn^T stats for a hard monotonic path (reference models.py:383-392) as a gather by the frame -> token map
+    the search kernel wrote; backward = segment sums over the tokens' spans."""
+
+    @staticmethod
+    def forward(ctx, stats, tok, first):
+        stats = f32(_c(stats))
+        B, D, Tx = stats.shape
+        Ty = tok.shape[1]
+        out = torch.empty(B, D, Ty, device=stats.device, dtype=torch.float32)
+        call("glowtts_align_expand_fwd", ptr(stats), ptr(tok), ptr(out), B, D, Tx, Ty)
+        ctx.save_for_backward(first)
+        ctx.shape = (B, D, Tx, Ty)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (first,) = ctx.saved_tensors
+        B, D, Tx, Ty = ctx.shape
+        dout = f32(_c(dout))
+        dstats = torch.empty(B, D, Tx, device=dout.device, dtype=torch.float32)
+        call("glowtts_align_expand_bwd", ptr(dout), ptr(first), ptr(dstats), B, D, Tx, Ty)
+        return dstats, None, None
+
+
 class RelAttnFn(Function):
     """Windowed relative-position self-attention (attentions.py:214-264) on the MFMA kernels of csrc/attention.hip.
     q, k, v: (B, H*dk, T); emb_k / emb_v: (1|H, 2w+1, dk) or None; m2: (B, T) sequence mask.  Returns (out, p_attn)."""

@@ -47,6 +47,27 @@ int glowtts_abi_version(void);
  */
 int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const int32_t *t_y,
                      int B, int Tx, int Ty, glowtts_stream_t stream);
+/* the same search, also handing out what its backtrack already knows (either may be NULL):
+ * first (B, Tx + 1) int32: first[b, x] = first frame of text row x (rows >= t_x and first[b, Tx]: t_y) — row x owns the
+ *   frames [first[x], first[x+1]), so sum_y path[x, y] = first[x+1] - first[x]  (models.py:393);
+ * tok (B, Ty) int32: the text row of every frame, -1 for frames >= t_y. */
+int glowtts_mas_path_spans(const float *value, float *path, int32_t *first, int32_t *tok, const int32_t *t_x,
+                           const int32_t *t_y, int B, int Tx, int Ty, glowtts_stream_t stream);
+
+/* ---- alignment-side glue of FlowGenerator.forward (csrc/align.hip; reference models.py:361-393) -------------------------
+ * align_logp : logp[b, x, y] = log N(z[b, :, y]; x_m[b, :, x], exp(x_logs[b, :, x])) summed over the C channels — the
+ *   (B, Tx, Ty) lattice of the alignment search (models.py:362-376: two bmm's + two channel sums + elementwise ops) as one
+ *   fp32-MFMA contraction over k = 2C per utterance.  x_logs may be NULL (mean_only: log-std 0).  x_m, x_logs (B, C, Tx),
+ *   z (B, C, Ty).
+ * align_expand_fwd : out[b, d, y] = stats[b, d, tok[b, y]] (0 where tok < 0) = attn^T stats for the hard path the search
+ *   returned (models.py:383-392: a bmm with one-hot rows) ; stats (B, D, Tx), out (B, D, Ty)
+ * align_expand_bwd : dstats[b, d, x] = sum of dout[b, d, y] over y in [first[b, x], first[b, x+1])  (WRITTEN, no atomics) */
+int glowtts_align_logp(const float *x_m, const float *x_logs, const float *z, float *logp, int B, int C, int Tx, int Ty,
+                       glowtts_stream_t stream);
+int glowtts_align_expand_fwd(const float *stats, const int32_t *tok, float *out, int B, int D, int Tx, int Ty,
+                             glowtts_stream_t stream);
+int glowtts_align_expand_bwd(const float *dout, const int32_t *first, float *dstats, int B, int D, int Tx, int Ty,
+                             glowtts_stream_t stream);
 
 /* ---- sequence lengths from a mask: x_len[b] = sum_t mask[b, t]  (layers.py:187,245) ------------------------ */
 int glowtts_mask_len(const float *mask, float *x_len, int B, int T, glowtts_stream_t stream);

@@ -144,6 +144,42 @@ def test_mas_ties_and_quantised(G):
     assert (got == O.mas_numpy(v * mask, txs, tys)).all()
 
 
+@pytest.mark.parametrize("b,c,tx,ty,mean_only", [(3, 80, 37, 101, False), (2, 80, 160, 800, True), (1, 6, 5, 9, False),
+                                                   (2, 100, 60, 64, False)])
+def test_align_logp_and_expand_vs_oracle(G, b, c, tx, ty, mean_only):
+    """csrc/align.hip against the oracle's restatement of models.py:362-376 / 383-393: the (token, frame) log-likelihood
+    lattice as one contraction, the spans / frame -> token map the search kernel hands out, and z_m = attn^T x_m as a gather
+    with its segment-sum backward."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(b * 100 + tx)
+    x_m = torch.randn(b, c, tx)
+    x_logs = torch.zeros(b, c, tx) if mean_only else 0.3 * torch.randn(b, c, tx)
+    z = torch.randn(b, c, ty)
+    want = O.align_logp(x_m, x_logs, z)
+    got = G.ops.align_logp(dev(x_m), None if mean_only else dev(x_logs), dev(z))
+    assert rel_err(got, want) < 1e-5, rel_err(got, want)
+    txs = torch.tensor([tx, max(1, tx - 3), max(1, tx // 2)][:b], dtype=torch.int32)
+    tys = torch.maximum(txs, torch.tensor([ty, ty - 4, ty // 2][:b], dtype=torch.int32))
+    path, first, tok = G.ops.mas_path_spans(got, txs.cuda(), tys.cuda())
+    assert torch.equal(path, G.ops.mas_path(got, txs.cuda(), tys.cuda()))
+    path, first, tok = path.cpu(), first.cpu(), tok.cpu()
+    assert torch.equal((first[:, 1:] - first[:, :-1]).float(), path.sum(-1))
+    for j in range(b):
+        ty_j, tx_j = int(tys[j]), int(txs[j])
+        assert torch.equal(tok[j, :ty_j].long(), path[j, :, :ty_j].argmax(0)) and (tok[j, ty_j:] == -1).all()
+        assert int(first[j, 0]) == 0 and (first[j, tx_j:] == ty_j).all()
+    stats = x_m.clone().requires_grad_(True)
+    ref = torch.matmul(path.transpose(1, 2), stats.transpose(1, 2)).transpose(1, 2)
+    r = torch.randn(b, c, ty)
+    (ref * r).sum().backward()
+    sd = dev(x_m).requires_grad_(True)
+    out = G.ops.AlignExpandFn.apply(sd, tok.cuda(), first.cuda())
+    (out * r.cuda()).sum().backward()
+    assert_close(out, ref, what="expand", rtol=0, atol=0)
+    assert_close(sd.grad, stats.grad, what="expand grad", rtol=1e-5, atol=1e-5)
+
+
 # =============================================================================================== flows vs golden
 @pytest.mark.parametrize("name", ["actnorm_c8", "actnorm_c160"])
 def test_actnorm_golden(G, name):
@@ -518,7 +554,9 @@ def test_generator_forward_vs_oracle_full_config2(G):
 
     hp = O.HParams(n_vocab=148)
     assert hp.n_blocks_dec == 12 and hp.n_layers_enc == 6 and hp.hidden_channels == 192
-    sd, model = _oracle_pair(G, hp, seed=21)
+    # end convs N(0, 0.02): with the 0.05 of the smaller tests each of the 12 couplings scales its half of the tensor by up
+    # to e^2, and the last-bit differences between the CPU's and the MFMA's summation orders grow to 1.3e-3 of max |z|
+    sd, model = _oracle_pair(G, hp, seed=21, end_std=0.02)
     torch.manual_seed(3)
     b, tx, ty = 32, 160, 800
     yl = torch.linspace(ty, ty // 2, b).long()
@@ -533,7 +571,7 @@ def test_generator_forward_vs_oracle_full_config2(G):
         loss_o = O.mle_loss(zo, zo_m, zo_logs, ldo, zo_mask)
         errs = {"z": rel_err(z, zo), "logdet": rel_err(logdet, ldo), "x_m": rel_err(x_m, xo_m), "logw": rel_err(logw, logw_o),
                 "loss": abs(float(loss) - float(loss_o)) / abs(float(loss_o))}
-        assert all(v < REL for v in errs.values()), errs
+        assert all(v < REL for v in errs.values()), " ".join(f"{k}={v:.2e}" for k, v in errs.items())
         # the search itself: same fp32 lattice in, same path out
         logp_o = O.align_logp(xo_m, xo_logs, zo)
         yl2 = (yl // 2) * 2
