@@ -39,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, = fp32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF headline includes 2:1 sparsity)
 
 
 def parse():
@@ -343,14 +344,19 @@ def main():
     if comm is not None:
         out["comm"] = comm
 
-    # ---- extra leg (not `value`): the same step with the WN convolutions' fp32 operands split into bf16 planes and the
-    # six products above 2^-24 formed on the bf16 matrix pipe ("bf16x6", csrc/convgemm_split.hip): fp32-equivalent results
-    # (tests/test_conv_math.py: error against fp64 no larger than the native fp32 MFMA kernels'), opt-in at run time
-    # (GLOWTTS_CONV_MATH=bf16x6+wrw).  `value` above is always the native fp32 MFMA path.
-    if not args.no_split_math and mode == "eager":
-        from glow_tts_train import convops
+    # ---- second arithmetic leg (not `value`).  The WN-stack convolutions have two fp32 forms: the native fp32 MFMA
+    # (v_mfma_f32_16x16x4_f32) and "bf16x6+wrw" — each fp32 operand split EXACTLY into three bf16 planes, the six products
+    # above 2^-24 formed on the bf16 matrix pipe, fp32 accumulation (csrc/convgemm_split.hip): fp32-equivalent results
+    # (tests/test_conv_math.py: error against fp64 no larger than the native kernels'; every golden / oracle GPU test runs in
+    # both forms at the same tolerances).  `value` is the package default (config.conv_math names it); this leg is the other.
+    from glow_tts_train import convops
 
-        previous = convops.set_conv_math("bf16x6+wrw")
+    default_math = convops.conv_math_name()
+    other_math = "fp32" if default_math != "fp32" else "bf16x6+wrw"
+    out["config"]["conv_math"] = default_math
+    if not args.no_split_math and mode == "eager":
+        previous = convops.set_conv_math(other_math)
+        key = "native_fp32" if other_math == "fp32" else "split_math"
         try:
             for _ in range(3):
                 step_fn()
@@ -364,17 +370,17 @@ def main():
                 tt = torch.tensor([dts], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dts = float(tt)
-            out["split_math"] = {"mode": "bf16x6+wrw", "value": frames / dts, "unit": "mel-frames/s",
-                                 "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
-                                 "arithmetic": "WN convolutions (forward, backward-data, weight gradient): fp32 operands as 3 "
-                                               "bf16 planes, 6 products per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate; "
-                                               "everything else as in `value`"}
-            log(f"split-math leg: {out['split_math']['ms_per_step']:.2f} ms/step")
-        except Exception as exc:                    # the extra leg must never cost the run its native result
-            log(f"split-math leg failed ({type(exc).__name__}: {exc}); reported as null")
-            out["split_math"] = None
+            out[key] = {"mode": other_math, "value": frames / dts, "unit": "mel-frames/s",
+                        "ms_per_step": 1e3 * dts / args.steps, "loss_after_these_further_steps": float(loss),
+                        "arithmetic": ("WN convolutions on the native fp32 MFMA (v_mfma_f32_16x16x4_f32)" if other_math == "fp32" else
+                                       "WN convolutions (forward, backward-data, weight gradient): fp32 operands as 3 bf16 planes, "
+                                       "6 products per pair on v_mfma_f32_16x16x32_bf16, fp32 accumulate") + "; everything else as in `value`"}
+            log(f"{key} leg ({other_math}): {out[key]['ms_per_step']:.2f} ms/step")
+        except Exception as exc:                    # the extra leg must never cost the run its result
+            log(f"{key} leg failed ({type(exc).__name__}: {exc}); reported as null")
+            out[key] = None
         finally:
-            convops.set_conv_math(previous)         # the roofline pass below measures the native kernels
+            convops.set_conv_math(previous)         # the roofline pass below measures the default form again
 
     # ---- extra leg (not `value`): bf16 activation tensors in HBM for the flow decoder (decoder.io_bf16 = "all")
     if args.dtype == "bf16" and mode == "eager":
@@ -429,7 +435,7 @@ def main():
             row = {"launches_per_step": len(ms) // n_inst, "mean_us": round(1e3 * mean_ms, 2),
                    "total_ms_per_step": round(sum(ms) / n_inst, 3)}
             m = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", name)
-            if m:       # dense contraction on the fp32 MFMA: algorithmic FLOPs = 2 * M * K * taps * columns
+            if m:       # dense contraction on the MFMA: algorithmic (fp32) FLOPs = 2 * M * K * taps * columns
                 flops = 2.0 * int(m.group(2)) * int(m.group(3)) * int(m.group(4)) * int(m.group(5)) * int(m.group(6))
                 row.update(alg_GFLOP=round(flops / 1e9, 3), TFLOPs=round(flops / (mean_ms * 1e-3) / 1e12, 2))
                 mfma[name] = row
@@ -444,18 +450,44 @@ def main():
         dom = max(mfma, key=lambda k: mfma[k]["total_ms_per_step"]) if mfma else None
         conv_ms = sum(v["total_ms_per_step"] for v in mfma.values())
         conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
+
+        def on_bf16_pipe(tag):
+            """Does this launch run as the bf16-plane kernel in the mode being measured?  (the WN stack's convolutions)"""
+            base, _, wrw = default_math.partition("+")
+            if base != "bf16x6":
+                return False
+            m_ = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+)", tag)
+            name_, M_, K_, taps_ = m_.group(1), int(m_.group(2)), int(m_.group(3)), int(m_.group(4))
+            if name_ in ("glowtts_conv_gate_fwd", "glowtts_conv_res_skip_fwd", "glowtts_conv_gate_bwd"):
+                return True
+            if name_ == "glowtts_conv_fwd":
+                return taps_ == 5 and K_ == 2 * H and M_ == H
+            if name_ in ("glowtts_conv_wrw", "glowtts_conv_wrw2"):
+                return wrw == "wrw" and K_ == H and ((taps_ == 5 and M_ == 2 * H) or (taps_ == 1 and M_ in (H, 2 * H)))
+            return False
+
         if dom is not None:
-            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS,
-                               "traffic": pmc_traffic(dom)}
+            if on_bf16_pipe(dom):
+                # six bf16 products per fp32 product: the pipe's work is 6 x the algorithmic FLOPs, its roof the dense bf16 peak
+                pipe = 6.0 * mfma[dom]["TFLOPs"]
+                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(pipe, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": pipe / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom),
+                                   "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)",
+                                   "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
+                                   "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
+            else:
+                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS,
+                                   "traffic": pmc_traffic(dom), "pipe": "fp32 MFMA"}
         else:
             dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": hbm[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
         out["roofline"].update({
+            "conv_math": default_math,
             "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
                                   "TFLOPs": round(conv_flop / conv_ms, 2) if conv_ms else None,
-                                  "frac": round(conv_flop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None},
+                                  "vs_fp32_mfma_peak": round(conv_flop / conv_ms / FP32_MFMA_PEAK_TFLOPS, 4) if conv_ms else None},
             # leads with the bytes the fused kernels actually have to move (`frac`); SURVEY's un-fused numerator second
             "invertible_subset": {"ms_per_step": round(sub_ms, 3), "alg_GB": round(sub_bytes / 1e9, 3),
                                   "GBps": round(sub_bytes / (sub_ms * 1e-3) / 1e9, 1) if sub_ms else None,

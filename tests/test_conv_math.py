@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def M():
-    """Package handles + a guard that restores native fp32 after every test."""
+    """Package handles + a guard that restores the package's default arithmetic after every test."""
     from glow_tts_train import _hip, convops, layers
 
     _hip.load()
@@ -27,12 +27,11 @@ def M():
 
     ns = NS()
     ns.hip, ns.convops, ns.layers = _hip, convops, layers
-    before = _hip.conv_math(None)
+    before = convops.conv_math_name()
     yield ns
     _hip.conv_bind_planes(None)
     _PLANES.clear()
-    _hip.conv_math(before)
-    convops._SPLIT_MATH[0] = (before & 3) != 0
+    convops.set_conv_math(before)
 
 
 _PLANES = {}
