@@ -106,12 +106,28 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
                      "glowtts_coupling_bwd")
 
 
-def pmc_traffic(kernel_tag):
+# bench tag -> (HIP kernel, grid size) of the committed counter passes, per arithmetic of the WN convolutions
+_PMC_KERNEL = {
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_split_kernel<3,5,5,2,false> grid=129024",
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32"): "convwrw_fp_kernel<5,5,2> grid=196608",
+    ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
+    ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
+}
+
+
+def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
     """HBM-side bytes per launch of `kernel_tag` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
-    collected from inside this process): profiles/r01_pmc_traffic.json, measured with tools/microbench_conv.py on the
-    same kernel and shape and corrected as MI355X_MICROARCH.md prescribes.  None when no measurement exists."""
+    collected from inside this process): profiles/r02_pmc.json — tools/pmc_passes.sh over this same bench command, one counter
+    group per run, combined per kernel and grid size by tools/pmc_combine.py as MI355X_MICROARCH.md prescribes (FETCH_SIZE
+    doubled on gfx950); round 1's table (native kernels, profiles/r01_pmc_traffic.json) as the fallback.  None when no
+    measurement exists."""
+    here = os.path.dirname(os.path.abspath(__file__))
     try:
-        table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        key = _PMC_KERNEL.get((kernel_tag, math if math.startswith("bf16x6") else "fp32"))
+        if key is not None and math.startswith("bf16x6"):
+            table = json.load(open(os.path.join(here, "profiles", "r02_pmc.json")))
+            return table[key]["traffic_bytes"]
+        table = json.load(open(os.path.join(here, "profiles", "r01_pmc_traffic.json")))
         return table[kernel_tag]["traffic_bytes"]
     except Exception:
         return None
@@ -471,14 +487,14 @@ def main():
                 # six bf16 products per fp32 product: the pipe's work is 6 x the algorithmic FLOPs, its roof the dense bf16 peak
                 pipe = 6.0 * mfma[dom]["TFLOPs"]
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(pipe, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": pipe / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom),
+                                   "unit": "TFLOP/s", "frac": pipe / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, default_math),
                                    "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)",
                                    "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
                                    "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
             else:
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS,
-                                   "traffic": pmc_traffic(dom), "pipe": "fp32 MFMA"}
+                                   "traffic": pmc_traffic(dom, "fp32"), "pipe": "fp32 MFMA"}
         else:
             dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,
