@@ -850,7 +850,8 @@ static int launch_convgemm_wd(ConvGemmParams &p, hipStream_t s) {
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
-                     aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
+                     aligned16(p.drop) && aligned16(p.gate_pos) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) &&
+                     (EPI != EPI_GATE || p.H % 4 == 0);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
     if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_wd_kernel<RTW, NCT, EPI, TAPS>), lds, "glowtts_conv")) return rc_;
     const int ntile_t = (p.T + NT - 1) / NT;
@@ -977,6 +978,28 @@ extern "C" int glowtts_conv_fwd_io(const void *x, long x_bs, const float *wp, co
     p.y0 = static_cast<float *>(y); p.xb = io_x; p.yb = io_y;
     p.x_bs = x_bs; p.y_bs = y_bs; p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
     p.mask_in = mask_in; p.mask_out = mask_out; p.mask_add = mask_add; p.r_bs = addend_bs;
+    return addend ? dispatch_convgemm<EPI_ADD>(p, (hipStream_t)stream) : dispatch_convgemm<EPI_PLAIN>(p, (hipStream_t)stream);
+}
+
+// conv_fwd with the elementwise neighbours of the text encoder's convolutions folded into the epilogue (fp32 tensors):
+//   forward : y = dropout(relu(conv(x) [+ addend] [* mask]))     relu, (drop keep bytes (B, M, T), drop_scale) optional
+//   backward-data of such a conv's CONSUMER: gate_pos = the forward's output g (B, M, T): the conv result is multiplied by
+//   gate_scale where g > 0 and zeroed elsewhere (ReLU' and the dropout in one test: g = 0 wherever either cut), then
+//   [+ addend] [* mask].   (reference: attentions.py:373-381 FFN, layers.py:73-80 prenet)
+extern "C" int glowtts_conv_fwd_act(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
+                                    const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T,
+                                    int taps, int dil, int pad, int mask_in, int mask_out, int mask_add, int relu,
+                                    const unsigned char *drop, float drop_scale, const float *gate_pos, float gate_scale,
+                                    glowtts_stream_t stream) {
+    if (int rc = check_conv_common("glowtts_conv_fwd_act", x, wp, B, Cin, M, T, taps, dil, pad)) return rc;
+    GLOWTTS_CHECK_ARG(y, "glowtts_conv_fwd_act: null output");
+    GLOWTTS_CHECK_ARG(!(mask_in || mask_out || mask_add) || mask, "glowtts_conv_fwd_act: mask flag without mask");
+    if ((long)B * T == 0) return 0;
+    ConvGemmParams p{};
+    p.x = x; p.wp = wp; p.bias = bias; p.mask = mask; p.r0 = addend; p.y0 = y;
+    p.x_bs = x_bs; p.y_bs = y_bs; p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
+    p.mask_in = mask_in; p.mask_out = mask_out; p.mask_add = mask_add; p.r_bs = addend_bs;
+    p.relu = relu; p.drop = drop; p.drop_scale = drop_scale; p.gate_pos = gate_pos; p.gate_scale = gate_scale;
     return addend ? dispatch_convgemm<EPI_ADD>(p, (hipStream_t)stream) : dispatch_convgemm<EPI_PLAIN>(p, (hipStream_t)stream);
 }
 

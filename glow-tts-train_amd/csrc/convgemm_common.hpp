@@ -43,6 +43,10 @@ struct ConvGemmParams {
     int mask_add;            // ADD: multiply the addend by mask
     int vec_epilogue;        // pipelined kernel: 16-byte epilogue through LDS (all epilogue tensors 16-byte aligned)
     float drop_scale;        // 1 / (1 - p)
+    int relu;                // PLAIN / ADD: y = max(y, 0) after bias (and mask_out), before the dropout below
+    const float *gate_pos;   // PLAIN / ADD (backward-data of a conv that follows ReLU [+ dropout]): (B, M, T) tensor g; the
+    float gate_scale;        //   conv result is multiplied by gate_scale where g > 0 and zeroed elsewhere, before the addend.
+                             //   PLAIN / ADD also honour `drop` / `drop_scale` (keep bytes (B, M, T)) as the last step
     int xb;                  // 1: x / x2 are bf16 tensors (same element indexing; convgemm_split.hip NS = 1 only)
     int yb;                  // 1: the epilogue's tensors y0, y1, r0, r1 are bf16 (bias, mask, cond stay fp32)
 };
@@ -124,13 +128,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                 float v = acc[r][c][reg];
                 if (p.bias) v += p.bias[row];
                 const float m = mk ? mk[t] : 1.f;
-                if (EPI == EPI_PLAIN) {
+                if (EPI == EPI_PLAIN || EPI == EPI_ADD) {
+                    const long od = ((long)b * p.M + row) * p.T + t;         // dense (B, M, T) side tensors
+                    if (p.gate_pos) v = p.gate_pos[od] > 0.f ? v * p.gate_scale : 0.f;
+                    if (EPI == EPI_ADD) {
+                        const float add = E::ld1(p.r0, (long)b * p.r_bs + (long)row * p.T + t);
+                        v += p.mask_add ? add * m : add;
+                    }
                     if (p.mask_out) v *= m;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.drop) v = p.drop[od] ? v * p.drop_scale : 0.f;
                     E::st1(p.y0, (long)b * p.y_bs + (long)row * p.T + t, v);
-                } else if (EPI == EPI_ADD) {
-                    const float add = E::ld1(p.r0, (long)b * p.r_bs + (long)row * p.T + t);
-                    const float sum = v + (p.mask_add ? add * m : add);
-                    E::st1(p.y0, (long)b * p.y_bs + (long)row * p.T + t, p.mask_out ? sum * m : sum);
                 } else if (EPI == EPI_RESSKIP) {
                     // rows [0,H): residual -> next layer input ; rows [H,2H): skip accumulation  (layers.py:157-159)
                     if (row < p.H) {
@@ -340,8 +348,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         const int rc = ok ? row : 0, tc = ok ? t : 0;               // clamped: always a valid address
         ra[i] = zero4; rb[i] = zero4; ka[i] = 0x01010101u; kb[i] = 0x01010101u;
         rm[i] = mk ? ld4(mk + tc) : one4;
-        if (EPI == EPI_ADD) {
-            ra[i] = E::ld4(p.r0, (long)b * p.r_bs + (long)rc * p.T + tc);
+        if (EPI == EPI_PLAIN || EPI == EPI_ADD) {
+            const long od = ((long)b * p.M + rc) * p.T + tc;
+            if (EPI == EPI_ADD) ra[i] = E::ld4(p.r0, (long)b * p.r_bs + (long)rc * p.T + tc);
+            if (p.gate_pos) rb[i] = ld4(p.gate_pos + od);
+            if (p.drop) ka[i] = *reinterpret_cast<const unsigned int *>(p.drop + od);
         } else if (EPI == EPI_RESSKIP) {
             const bool res = rc < p.H;
             const long o = ((long)b * p.H + (res ? rc : rc - p.H)) * p.T + tc;
@@ -369,15 +380,26 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         float4 v = ld4(Ls + lr * LP + q * 4);
         if (p.bias) { const float bb = p.bias[row]; v.x += bb; v.y += bb; v.z += bb; v.w += bb; }
         const float4 m = rm[i], a = ra[i];
-        if (EPI == EPI_PLAIN) {
-            if (p.mask_out) { v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w; }
-            E::st4(p.y0, (long)b * p.y_bs + (long)row * p.T + t, v);
-        } else if (EPI == EPI_ADD) {
-            float4 ad = a;
-            if (p.mask_add) { ad.x *= m.x; ad.y *= m.y; ad.z *= m.z; ad.w *= m.w; }
-            float4 o = make_float4(v.x + ad.x, v.y + ad.y, v.z + ad.z, v.w + ad.w);
-            if (p.mask_out) { o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-            E::st4(p.y0, (long)b * p.y_bs + (long)row * p.T + t, o);
+        if (EPI == EPI_PLAIN || EPI == EPI_ADD) {
+            float o[4] = {v.x, v.y, v.z, v.w};
+            const float mm[4] = {m.x, m.y, m.z, m.w};
+            if (p.gate_pos) {
+                const float g[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) o[jj] = g[jj] > 0.f ? o[jj] * p.gate_scale : 0.f;
+            }
+            if (EPI == EPI_ADD) {
+                const float ad[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) o[jj] += p.mask_add ? ad[jj] * mm[jj] : ad[jj];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (p.mask_out) o[jj] *= mm[jj];
+                if (p.relu) o[jj] = fmaxf(o[jj], 0.f);
+                if (p.drop) o[jj] = ((ka[i] >> (8 * jj)) & 0xffu) ? o[jj] * p.drop_scale : 0.f;
+            }
+            E::st4(p.y0, (long)b * p.y_bs + (long)row * p.T + t, make_float4(o[0], o[1], o[2], o[3]));
         } else if (EPI == EPI_RESSKIP) {
             if (row < p.H) {
                 const long o = ((long)b * p.H + row) * p.T + t;

@@ -25,29 +25,42 @@ __device__ __forceinline__ float ln_column_sum(float v, float (*sh)[kLnCols], in
     return s;
 }
 
-// forward: y = gamma * (v - mean) * rstd + beta, v = x (+ res);  stats[b][0][t] = mean, stats[b][1][t] = rstd
-__global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
-                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                 float *__restrict__ y, float *__restrict__ stats, int C,
-                                                                 int T, float eps) {
+// The value that is normalised: v = x * mask_x[b, t] (+ res * keep * drop_scale).  mask_x folds the `x * x_mask` that opens
+// every transformer layer (attentions.py:64), (drop, drop_scale) the dropout on the branch output that is added back
+// (`self.drop(y)`, attentions.py:67,71): neither product is ever written to HBM.
+struct LnIn {
+    const float *x, *res, *mask_x;
+    const unsigned char *drop;
+    float drop_scale;
+    __device__ __forceinline__ float at(long o, float m) const {
+        float v = x[o] * m;
+        if (res) {
+            float r = res[o];
+            if (drop) r = drop[o] ? r * drop_scale : 0.f;
+            v += r;
+        }
+        return v;
+    }
+};
+
+// forward: y = gamma * (v - mean) * rstd + beta;  stats[b][0][t] = mean, stats[b][1][t] = rstd
+__global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(LnIn in, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float *__restrict__ y,
+                                                                 float *__restrict__ stats, int C, int T, float eps) {
     __shared__ float sh[kLnSlices][kLnCols];
     const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int b = blockIdx.y, t = blockIdx.x * kLnCols + col;
     const bool ok = t < T;
     const long base = (long)b * C * T + (ok ? t : 0);
+    const float mx = in.mask_x ? in.mask_x[(long)b * T + (ok ? t : 0)] : 1.f;
     float a = 0.f;
 #pragma unroll 4
-    for (int c = slice; c < C; c += kLnSlices) {
-        float v = x[base + (long)c * T];
-        if (res) v += res[base + (long)c * T];
-        a += v;
-    }
+    for (int c = slice; c < C; c += kLnSlices) a += in.at(base + (long)c * T, mx);
     const float mean = ln_column_sum(a, sh, col, slice) / C;
     float q = 0.f;                               // two-pass variance, as the reference: mean((v - mean)^2)
 #pragma unroll 4
     for (int c = slice; c < C; c += kLnSlices) {
-        float v = x[base + (long)c * T];
-        if (res) v += res[base + (long)c * T];
+        const float v = in.at(base + (long)c * T, mx);
         q += (v - mean) * (v - mean);
     }
     const float var = ln_column_sum(q, sh, col, slice) / C;
@@ -59,18 +72,16 @@ __global__ __launch_bounds__(256) void chan_layernorm_fwd_kernel(const float *__
     if (!ok) return;
 #pragma unroll 4
     for (int c = slice; c < C; c += kLnSlices) {
-        float v = x[base + (long)c * T];
-        if (res) v += res[base + (long)c * T];
+        const float v = in.at(base + (long)c * T, mx);
         y[base + (long)c * T] = (v - mean) * rstd * gamma[c] + beta[c];
     }
 }
 
 // backward, input part: with xhat = (v - mean) rstd, g = dy * gamma:  dv = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))
-// (dv is the gradient of x AND of res)
-__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
-                                                                 const float *__restrict__ gamma, const float *__restrict__ stats,
-                                                                 const float *__restrict__ dy, float *__restrict__ dx, int C,
-                                                                 int T) {
+// dx = dv * mask_x ; dres = dv * keep * drop_scale (written only when `dres` is given: without dropout dres == dx)
+__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(LnIn in, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ stats, const float *__restrict__ dy,
+                                                                 float *__restrict__ dx, float *__restrict__ dres, int C, int T) {
     __shared__ float sh[kLnSlices][kLnCols];
     const int col = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int b = blockIdx.y, t = blockIdx.x * kLnCols + col;
@@ -78,11 +89,11 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float *__
     const long base = (long)b * C * T + (ok ? t : 0);
     const float mean = stats[((long)b * 2 + 0) * T + (ok ? t : 0)];
     const float rstd = stats[((long)b * 2 + 1) * T + (ok ? t : 0)];
+    const float mx = in.mask_x ? in.mask_x[(long)b * T + (ok ? t : 0)] : 1.f;
     float a = 0.f, q = 0.f;
 #pragma unroll 4
     for (int c = slice; c < C; c += kLnSlices) {
-        float v = x[base + (long)c * T];
-        if (res) v += res[base + (long)c * T];
+        const float v = in.at(base + (long)c * T, mx);
         const float g = dy[base + (long)c * T] * gamma[c];
         a += g;
         q += g * (v - mean) * rstd;
@@ -92,17 +103,17 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float *__
     if (!ok) return;
 #pragma unroll 4
     for (int c = slice; c < C; c += kLnSlices) {
-        float v = x[base + (long)c * T];
-        if (res) v += res[base + (long)c * T];
-        const float xh = (v - mean) * rstd;
-        dx[base + (long)c * T] = rstd * (dy[base + (long)c * T] * gamma[c] - mg - xh * mgx);
+        const long o = base + (long)c * T;
+        const float xh = (in.at(o, mx) - mean) * rstd;
+        const float dv = rstd * (dy[o] * gamma[c] - mg - xh * mgx);
+        dx[o] = dv * mx;
+        if (dres) dres[o] = in.drop ? (in.drop[o] ? dv * in.drop_scale : 0.f) : dv;
     }
 }
 
 // backward, parameter part: dgamma[c] += sum_{b,t} dy * xhat ;  dbeta[c] += sum_{b,t} dy
 // grid (C, slabs of utterances): rows (b, c, :) are contiguous in t, one block sum and one atomic pair per workgroup
-__global__ __launch_bounds__(256) void chan_layernorm_bwd_param_kernel(const float *__restrict__ x, const float *__restrict__ res,
-                                                                       const float *__restrict__ stats,
+__global__ __launch_bounds__(256) void chan_layernorm_bwd_param_kernel(LnIn in, const float *__restrict__ stats,
                                                                        const float *__restrict__ dy, float *__restrict__ dgamma,
                                                                        float *__restrict__ dbeta, int B, int C, int T, int nb) {
     __shared__ float red[4];
@@ -114,8 +125,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_param_kernel(const flo
     for (int i = threadIdx.x; i < items; i += 256) {
         const int b = b0 + i / T, t = i % T;
         const long o = ((long)b * C + c) * T + t;
-        float v = x[o];
-        if (res) v += res[o];
+        const float v = in.at(o, in.mask_x ? in.mask_x[(long)b * T + t] : 1.f);
         const float d = dy[o];
         dg += d * (v - stats[((long)b * 2 + 0) * T + t]) * stats[((long)b * 2 + 1) * T + t];
         db += d;
@@ -132,28 +142,46 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_param_kernel(const flo
 
 using namespace glowtts;
 
-extern "C" int glowtts_chan_layernorm_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *y,
-                                          float *stats, int B, int C, int T, float eps, glowtts_stream_t stream) {
+// `_ex` forms: mask_x (B, T) multiplies x, (drop (B, C, T) keep bytes, drop_scale) apply dropout to res — each may be NULL;
+// the backward writes dx = dv * mask_x and, when dres != NULL, dres = dv * keep * drop_scale (else the gradient of res is dx)
+extern "C" int glowtts_chan_layernorm_fwd_ex(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                             float drop_scale, const float *gamma, const float *beta, float *y, float *stats,
+                                             int B, int C, int T, float eps, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && gamma && beta && y, "glowtts_chan_layernorm_fwd: null pointer");
-    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_chan_layernorm_fwd: bad shape");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && (!drop || res), "glowtts_chan_layernorm_fwd: bad shape");
     if ((long)B * T == 0) return 0;
-    hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((T + kLnCols - 1) / kLnCols, B), dim3(256), 0, (hipStream_t)stream, x, res,
+    LnIn in{x, res, mask_x, drop, drop_scale};
+    hipLaunchKernelGGL(chan_layernorm_fwd_kernel, dim3((T + kLnCols - 1) / kLnCols, B), dim3(256), 0, (hipStream_t)stream, in,
                        gamma, beta, y, stats, C, T, eps);
     GLOWTTS_LAUNCH_CHECK("glowtts_chan_layernorm_fwd");
+}
+
+extern "C" int glowtts_chan_layernorm_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *y,
+                                          float *stats, int B, int C, int T, float eps, glowtts_stream_t stream) {
+    return glowtts_chan_layernorm_fwd_ex(x, res, nullptr, nullptr, 1.f, gamma, beta, y, stats, B, C, T, eps, stream);
+}
+
+extern "C" int glowtts_chan_layernorm_bwd_ex(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                             float drop_scale, const float *gamma, const float *stats, const float *dy,
+                                             float *dx, float *dres, float *dgamma, float *dbeta, int B, int C, int T,
+                                             glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(x && gamma && stats && dy && dx && dgamma && dbeta, "glowtts_chan_layernorm_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && (!drop || (res && dres)), "glowtts_chan_layernorm_bwd: bad shape");
+    if ((long)B * T == 0) return 0;
+    LnIn in{x, res, mask_x, drop, drop_scale};
+    hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((T + kLnCols - 1) / kLnCols, B), dim3(256), 0, (hipStream_t)stream, in,
+                       gamma, stats, dy, dx, dres, C, T);
+    int slabs = (1024 + C - 1) / C;
+    if (slabs > B) slabs = B;
+    const int nb = (B + slabs - 1) / slabs;
+    hipLaunchKernelGGL(chan_layernorm_bwd_param_kernel, dim3(C, (B + nb - 1) / nb), dim3(256), 0, (hipStream_t)stream, in, stats,
+                       dy, dgamma, dbeta, B, C, T, nb);
+    GLOWTTS_LAUNCH_CHECK("glowtts_chan_layernorm_bwd");
 }
 
 extern "C" int glowtts_chan_layernorm_bwd(const float *x, const float *res, const float *gamma, const float *stats,
                                           const float *dy, float *dx, float *dgamma, float *dbeta, int B, int C, int T,
                                           glowtts_stream_t stream) {
-    GLOWTTS_CHECK_ARG(x && gamma && stats && dy && dx && dgamma && dbeta, "glowtts_chan_layernorm_bwd: null pointer");
-    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0, "glowtts_chan_layernorm_bwd: bad shape");
-    if ((long)B * T == 0) return 0;
-    hipLaunchKernelGGL(chan_layernorm_bwd_kernel, dim3((T + kLnCols - 1) / kLnCols, B), dim3(256), 0, (hipStream_t)stream, x, res,
-                       gamma, stats, dy, dx, C, T);
-    int slabs = (1024 + C - 1) / C;
-    if (slabs > B) slabs = B;
-    const int nb = (B + slabs - 1) / slabs;
-    hipLaunchKernelGGL(chan_layernorm_bwd_param_kernel, dim3(C, (B + nb - 1) / nb), dim3(256), 0, (hipStream_t)stream, x, res, stats,
-                       dy, dgamma, dbeta, B, C, T, nb);
-    GLOWTTS_LAUNCH_CHECK("glowtts_chan_layernorm_bwd");
+    return glowtts_chan_layernorm_bwd_ex(x, res, nullptr, nullptr, 1.f, gamma, stats, dy, dx, nullptr, dgamma, dbeta, B, C, T,
+                                         stream);
 }

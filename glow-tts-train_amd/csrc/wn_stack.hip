@@ -331,3 +331,101 @@ extern "C" int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float
                                      dskip, d_rs, d_xin, dx_wn, dx, B, C, H, T, taps, dil_rate, n_split, sigmoid_scale, two_source,
                                      0, wgrad_stream, stream);
 }
+
+
+// ---- a whole transformer layer of the text encoder per call --------------------------------------------------------------
+// attentions.py:63-73: x = x * mask ; y = attn(x) ; x = LN1(x + drop(y)) ; y = ffn(x) ; x = LN2(x + drop(y)), with
+// attn = conv_o(rel_attention(conv_q(x), conv_k(x), conv_v(x))) (attentions.py:204-211) and ffn = conv_2(drop(relu(conv_1(x * mask)))
+// * mask) * mask (attentions.py:373-381).  The per-operator path was ~16 autograd nodes and ~8 torch elementwise launches per
+// layer each way; here the elementwise neighbours ride in kernel epilogues (x * mask as mask_in of the q / k / v convs and as
+// mask_x of LN1; both dropouts of the residual branches inside the LayerNorm kernels; ReLU + dropout as the epilogue of
+// conv_1 and as the gate of conv_2's backward-data) and the sequence is one host call each way.
+extern "C" int glowtts_encoder_layer_fwd(const glowtts_enc_layer *L, const float *x, const float *mask,
+                                         const unsigned char *drop_a, const unsigned char *drop_o, const unsigned char *drop_h,
+                                         const unsigned char *drop_2, float drop_scale, float *q, float *k, float *v,
+                                         float *p_attn, float *y_att, float *o, float *x1, float *stats1, float *h, float *y2,
+                                         float *x2, float *stats2, int B, int H, int F, int T, int heads, int taps, int window,
+                                         int heads_share, int block_len, float eps, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(L && x && mask && q && k && v && p_attn && y_att && o && x1 && stats1 && h && y2 && x2 && stats2,
+                      "glowtts_encoder_layer_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(heads > 0 && H % heads == 0 && (taps & 1), "glowtts_encoder_layer_fwd: bad shape");
+    const long HT = (long)H * T, FT = (long)F * T;
+    const int pad = (taps - 1) / 2, dk = H / heads;
+    if (L->pack_desc)
+        WN_TRY(glowtts_pack_weight_multi(L->pack_desc, L->pack_prefix, L->n_conv, L->total_rows, stream));
+    // q, k, v = 1x1 convs of x * mask
+    WN_TRY(glowtts_conv_fwd(x, HT, L->wf_q, L->b_q, mask, nullptr, 0, q, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
+    WN_TRY(glowtts_conv_fwd(x, HT, L->wf_k, L->b_k, mask, nullptr, 0, k, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
+    WN_TRY(glowtts_conv_fwd(x, HT, L->wf_v, L->b_v, mask, nullptr, 0, v, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
+    WN_TRY(glowtts_rel_attn_fwd(q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, y_att, B, heads, T, dk, window,
+                                heads_share, block_len, stream));
+    WN_TRY(glowtts_conv_fwd(y_att, HT, L->wf_o, L->b_o, nullptr, nullptr, 0, o, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
+    // x1 = LN1(x * mask + dropout(o))
+    WN_TRY(glowtts_chan_layernorm_fwd_ex(x, o, mask, drop_o, drop_scale, L->gamma1, L->beta1, x1, stats1, B, H, T, eps, stream));
+    // h = dropout(relu(conv_1(x1 * mask))) ; y2 = conv_2(h * mask) * mask
+    WN_TRY(glowtts_conv_fwd_act(x1, HT, L->wf_1, L->b_1, mask, nullptr, 0, h, FT, B, H, F, T, taps, 1, pad, 1, 0, 0, 1, drop_h,
+                                drop_scale, nullptr, 1.f, stream));
+    WN_TRY(glowtts_conv_fwd(h, FT, L->wf_2, L->b_2, mask, nullptr, 0, y2, HT, B, F, H, T, taps, 1, pad, 1, 1, 0, stream));
+    // x2 = LN2(x1 + dropout(y2))
+    return glowtts_chan_layernorm_fwd_ex(x1, y2, nullptr, drop_2, drop_scale, L->gamma2, L->beta2, x2, stats2, B, H, T, eps, stream);
+}
+
+extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const float *mask,
+                                         const unsigned char *drop_a, const unsigned char *drop_o, const unsigned char *drop_h,
+                                         const unsigned char *drop_2, float drop_scale, const float *q, const float *k,
+                                         const float *v, const float *p_attn, const float *y_att, const float *o, const float *x1,
+                                         const float *stats1, const float *h, const float *y2, const float *stats2,
+                                         const float *dx2, float *dx1a, float *dy2, float *d_pre1, float *dx1, float *dxa,
+                                         float *d_o, float *dy_att, float *ds, float *dq, float *dkk, float *dv, float *dx, int B,
+                                         int H, int F, int T, int heads, int taps, int window, int heads_share, int block_len,
+                                         glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(L && x && mask && q && k && v && p_attn && y_att && o && x1 && stats1 && h && y2 && stats2 && dx2 && dx1a &&
+                      dy2 && d_pre1 && dx1 && dxa && d_o && dy_att && ds && dq && dkk && dv && dx,
+                      "glowtts_encoder_layer_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(L->unpack_desc && L->pack_prefix && L->dwp_all, "glowtts_encoder_layer_bwd: incomplete layer table");
+    hipStream_t ms = (hipStream_t)stream;
+    hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
+    glowtts_stream_t wss = (glowtts_stream_t)ws;
+    const long HT = (long)H * T, FT = (long)F * T;
+    const int pad = (taps - 1) / 2, dk = H / heads;
+    hipError_t e = hipMemsetAsync(L->dwp_all, 0, (size_t)L->dwp_floats * sizeof(float), ms);
+    if (e != hipSuccess) { set_error("glowtts_encoder_layer_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
+    // LN2 backwards: dx1a = d(x1) through the residual path, dy2 = d(y2) through the dropout
+    WN_TRY(glowtts_chan_layernorm_bwd_ex(x1, y2, nullptr, drop_2, drop_scale, L->gamma2, stats2, dx2, dx1a, drop_2 ? dy2 : nullptr,
+                                         L->dgamma2, L->dbeta2, B, H, T, stream));
+    const float *g2 = drop_2 ? dy2 : dx1a;
+    // conv_2 (y2 = conv(h * mask) * mask): weight gradient aside; input gradient gated by ReLU' and conv_1's dropout in one test
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(h, FT, g2, HT, mask, mask, L->dwp_2, L->db_2, B, F, H, T, taps, 1, pad, wss));
+    WN_TRY(glowtts_conv_fwd_act(g2, HT, L->wb_2, nullptr, mask, nullptr, 0, d_pre1, FT, B, H, F, T, taps, 1, (taps - 1) - pad, 1, 1, 0,
+                                0, nullptr, 1.f, h, drop_h ? drop_scale : 1.f, stream));
+    // conv_1 (pre = conv(x1 * mask)): dx1 = dx1a + mask * (W1^T d_pre1) = mask * (dx1a + W1^T d_pre1): dx1a vanishes beyond the
+    // utterance, because the gradient arriving at a layer's output does (every consumer of it multiplies by the mask first)
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(x1, HT, d_pre1, FT, nullptr, mask, L->dwp_1, L->db_1, B, H, F, T, taps, 1, pad, wss));
+    WN_TRY(glowtts_conv_fwd(d_pre1, FT, L->wb_1, nullptr, mask, dx1a, HT, dx1, HT, B, F, H, T, taps, 1, (taps - 1) - pad, 0, 1, 0,
+                            stream));
+    // LN1 backwards: dxa = d(x) through the residual path (times mask), d_o through the dropout
+    WN_TRY(glowtts_chan_layernorm_bwd_ex(x, o, mask, drop_o, drop_scale, L->gamma1, stats1, dx1, dxa, drop_o ? d_o : nullptr,
+                                         L->dgamma1, L->dbeta1, B, H, T, stream));
+    const float *go = drop_o ? d_o : dxa;
+    // conv_o
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(y_att, HT, go, HT, nullptr, nullptr, L->dwp_o, L->db_o, B, H, H, T, 1, 1, 0, wss));
+    WN_TRY(glowtts_conv_fwd(go, HT, L->wb_o, nullptr, nullptr, nullptr, 0, dy_att, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
+    // attention
+    WN_TRY(glowtts_rel_attn_bwd(dy_att, q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, ds, dq, dkk, dv, L->demb_k,
+                                L->demb_v, B, heads, T, dk, window, heads_share, block_len, stream));
+    // q, k, v convs of x * mask: dx = dxa + mask * (Wq^T dq + Wk^T dk + Wv^T dv)
+    WN_TRY(order_after(ms, ws));
+    WN_TRY(glowtts_conv_wrw(x, HT, dq, HT, nullptr, mask, L->dwp_q, L->db_q, B, H, H, T, 1, 1, 0, wss));
+    WN_TRY(glowtts_conv_wrw(x, HT, dkk, HT, nullptr, mask, L->dwp_k, L->db_k, B, H, H, T, 1, 1, 0, wss));
+    WN_TRY(glowtts_conv_wrw(x, HT, dv, HT, nullptr, mask, L->dwp_v, L->db_v, B, H, H, T, 1, 1, 0, wss));
+    // dxa is masked already and mask * mask = mask, so dxa + mask * S = mask * (dxa + S): the chain starts from dxa and the
+    // last convolution masks the sum
+    WN_TRY(glowtts_conv_fwd(dq, HT, L->wb_q, nullptr, nullptr, dxa, HT, dx, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
+    WN_TRY(glowtts_conv_fwd(dkk, HT, L->wb_k, nullptr, nullptr, dx, HT, dx, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
+    WN_TRY(glowtts_conv_fwd(dv, HT, L->wb_v, nullptr, mask, dx, HT, dx, HT, B, H, H, T, 1, 1, 0, 0, 1, 0, stream));
+    WN_TRY(order_after(ms, ws));
+    return glowtts_unpack_weight_grad_multi(L->unpack_desc, L->pack_prefix, L->n_conv, L->total_rows, wss);
+}

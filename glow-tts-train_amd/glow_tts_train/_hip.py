@@ -76,6 +76,12 @@ _SIGNATURES = {
     # a whole flow block per call (csrc/wn_stack.hip); the first argument is a HOST struct glowtts_flow_block
     "glowtts_flow_block_fwd": [_P, _P, _P, _P, _P, _F] + [_P] * 9 + [_I] * 8,
     "glowtts_flow_block_bwd": [_P, _P, _P, _P, _P, _F] + [_P] * 16 + [_I] * 9 + [_P],
+    # text-encoder neighbours in kernel epilogues and a whole transformer layer per call
+    "glowtts_conv_fwd_act": [_P, _L, _P, _P, _P, _P, _L, _P, _L] + [_I] * 11 + [_P, _F, _P, _F],
+    "glowtts_chan_layernorm_fwd_ex": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _F],
+    "glowtts_chan_layernorm_bwd_ex": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_encoder_layer_fwd": [_P] * 7 + [_F] + [_P] * 12 + [_I] * 9 + [_F],
+    "glowtts_encoder_layer_bwd": [_P] * 7 + [_F] + [_P] * 24 + [_I] * 9 + [_P],
     # `_io` forms (bf16 activation tensors in HBM: BASELINE configs[2]); the trailing int before the stream(s) is the io flag
     "glowtts_flow_block_fwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 10 + [_I] * 9,
     "glowtts_flow_block_bwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 17 + [_I] * 10 + [_P],
@@ -109,6 +115,16 @@ class FlowBlock(ctypes.Structure):
         "pack_prefix", "dwp_all")]
                 + [("dwp_floats", ctypes.c_longlong), ("n_layers", ctypes.c_int), ("n_conv", ctypes.c_int),
                    ("total_rows", ctypes.c_int), ("reserved", ctypes.c_int)])
+
+
+class EncLayer(ctypes.Structure):
+    """struct glowtts_enc_layer (include/glowtts_hip.h): one transformer layer's device pointers."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in (
+        "wf_q", "wb_q", "b_q", "wf_k", "wb_k", "b_k", "wf_v", "wb_v", "b_v", "wf_o", "wb_o", "b_o",
+        "wf_1", "wb_1", "b_1", "wf_2", "wb_2", "b_2", "emb_k", "emb_v", "gamma1", "beta1", "gamma2", "beta2",
+        "dwp_q", "dwp_k", "dwp_v", "dwp_o", "dwp_1", "dwp_2", "db_q", "db_k", "db_v", "db_o", "db_1", "db_2",
+        "demb_k", "demb_v", "dgamma1", "dbeta1", "dgamma2", "dbeta2", "pack_desc", "unpack_desc", "pack_prefix", "dwp_all")]
+                + [("dwp_floats", ctypes.c_longlong), ("n_conv", ctypes.c_int), ("total_rows", ctypes.c_int)])
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",

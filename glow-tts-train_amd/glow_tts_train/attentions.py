@@ -16,6 +16,7 @@ from .layers import WN, LayerNorm
 
 _coupling_apply = direct_apply(ops.CouplingFn)
 _rel_attn_apply = direct_apply(ops.RelAttnFn)
+_enc_layer_apply = direct_apply(convops.EncoderLayerFn)
 
 
 class Encoder(nn.Module):
@@ -38,7 +39,42 @@ class Encoder(nn.Module):
             for _ in range(n_layers))
         self.norm_layers_2 = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(n_layers))
 
+    def _native_layers(self, x):
+        """[(ConvGroup, attn, ffn, norm1, norm2), ...] when EVERY layer can run as one native call each way, else None."""
+        layers = []
+        for attn, norm1, ffn, norm2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
+            group = getattr(attn.conv_q, "_glowtts_group", (None, 0))[0]
+            if group is None or not convops.encoder_layer_eligible(group, attn, ffn, norm1, norm2, x):
+                return None
+            layers.append((group, attn, ffn, norm1, norm2))
+        return layers
+
     def forward(self, x, x_mask):
+        layers = self._native_layers(x) if x.is_cuda else None
+        if layers:
+            # one autograd node per layer, one native call each way (csrc/wn_stack.hip); the keep-masks of all four dropouts of
+            # all layers come from ONE generator launch
+            m2 = ops.mask2d(x_mask)
+            b, hch, t = x.shape
+            nh, p = self.n_heads, float(self.p_dropout) if self.training else 0.0
+            sizes = [b * nh * t * t, b * hch * t, b * self.filter_channels * t, b * hch * t]
+            keep = None
+            if p > 0.0:
+                keep = torch.empty(len(layers) * sum(sizes), device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p)
+            pos = 0
+            for group, attn, ffn, norm1, norm2 in layers:
+                drops = None
+                if keep is not None:
+                    drops = []
+                    for n in sizes:
+                        drops.append(keep[pos: pos + n])
+                        pos += n
+                    drops = tuple(drops)
+                cfg = (nh, ffn.kernel_size, -1 if attn.window_size is None else attn.window_size, int(attn.heads_share),
+                       -1 if attn.block_length is None else attn.block_length, norm1.eps, p)
+                _, live = convops._enc_layer_table(group, attn, ffn, norm1, norm2)
+                x = _enc_layer_apply(x, m2, drops, cfg, (group, attn, ffn, norm1, norm2), *live)
+            return x * x_mask
         pair_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
         for attn, norm1, ffn, norm2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
             x = x * x_mask

@@ -995,3 +995,142 @@ class FlowBlockFn(Function):
         else:
             _notify(live)
         return (dx, None, None, None, None, None) + (None,) * len(params)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+_ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
+
+
+def _enc_layer_table(group, attn, ffn, norm1, norm2):
+    """Host-side `glowtts_enc_layer` of one transformer layer, cached on the layer's ConvGroup (whose plan owns the packed
+    weights of conv_q, conv_k, conv_v, conv_o, conv_1, conv_2 in that order)."""
+    plan = group.plan
+    convs = [attn.conv_q, attn.conv_k, attn.conv_v, attn.conv_o, ffn.conv_1, ffn.conv_2]
+    others = [attn.emb_rel_k, attn.emb_rel_v] if attn.window_size is not None else [None, None]
+    others += [norm1.gamma, norm1.beta, norm2.gamma, norm2.beta]
+    live = [c.weight for c in convs] + [c.bias for c in convs] + [p for p in others if p is not None]
+    key = (plan.version, tuple(p.data_ptr() for p in live), tuple(p.grad.data_ptr() for p in live))
+    if getattr(group, "_enc_key", None) != key:
+        t = _hip.EncLayer()
+        gdesc, prefix = plan.unpack_tables(group._params())
+        for i, (name, c) in enumerate(zip("qkvo12", convs)):
+            wf, wb = plan.convs[i][2], plan.convs[i][3]
+            setattr(t, "wf_" + name, wf.data_ptr())
+            setattr(t, "wb_" + name, wb.data_ptr())
+            setattr(t, "b_" + name, c.bias.data_ptr())
+            setattr(t, "dwp_" + name, plan.dwp_view(i).data_ptr())
+            setattr(t, "db_" + name, c.bias.grad.data_ptr())
+        ek, ev = others[0], others[1]
+        t.emb_k, t.emb_v = (None, None) if ek is None else (ek.data_ptr(), ev.data_ptr())
+        t.demb_k, t.demb_v = (None, None) if ek is None else (ek.grad.data_ptr(), ev.grad.data_ptr())
+        t.gamma1, t.beta1, t.gamma2, t.beta2 = (p.data_ptr() for p in others[2:])
+        t.dgamma1, t.dbeta1, t.dgamma2, t.dbeta2 = (p.grad.data_ptr() for p in others[2:])
+        t.pack_desc = None                       # ConvGroup.begin() has packed this layer's weights already
+        t.unpack_desc, t.pack_prefix = gdesc.data_ptr(), prefix.data_ptr()
+        t.dwp_all, t.dwp_floats = plan.dwp.data_ptr(), plan.dwp.numel()
+        t.n_conv, t.total_rows = len(plan.convs), plan.total_rows
+        group._enc_tab, group._enc_key, group._enc_live = t, key, live
+    return group._enc_tab, group._enc_live
+
+
+def encoder_layer_eligible(group, attn, ffn, norm1, norm2, x) -> bool:
+    """Can this transformer layer run as ONE native call each way (EncoderLayerFn)?  Training step on the GPU with every
+    gradient buffer allocated and written in place, the attention kernel's envelope, ReLU FFN, biased convolutions."""
+    if not (x.is_cuda and torch.is_grad_enabled() and _hip.timing_off() and _WN_NATIVE == "both" and direct_grads_enabled()):
+        return False
+    if not group.active or group.modules != [attn.conv_q, attn.conv_k, attn.conv_v, attn.conv_o, ffn.conv_1, ffn.conv_2]:
+        return False
+    t = x.size(2)
+    if not (t <= 256 and attn.k_channels % 16 == 0 and attn.k_channels <= 128 and (attn.window_size is None or attn.window_size <= 7)
+            and not attn.proximal_bias and ffn.activation is None and ffn.kernel_size % 2 == 1):
+        return False
+    if attn.conv_o.weight.shape[0] != attn.channels or any(c.bias is None for c in group.modules):
+        return False
+    params = [attn.emb_rel_k, attn.emb_rel_v] if attn.window_size is not None else []
+    params += [norm1.gamma, norm1.beta, norm2.gamma, norm2.beta] + [c.bias for c in group.modules]
+    return all(p.requires_grad and p.grad is not None and p.grad.is_contiguous() for p in params)
+
+
+class EncoderLayerFn(Function):
+    """One post-LN transformer layer of the text encoder (reference attentions.py:63-73, 204-264, 373-381) as ONE autograd
+    node: forward and backward are one native call each (csrc/wn_stack.hip: glowtts_encoder_layer_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, m2, drops, cfg, mods, *params):
+        import ctypes
+        heads, taps, window, share, blk, eps, p_drop = cfg
+        group, attn, ffn, norm1, norm2 = mods
+        x = f32(x.contiguous())
+        B, H, T = x.shape
+        F_ = ffn.filter_channels
+        dev = x.device
+        tab, live = _enc_layer_table(group, attn, ffn, norm1, norm2)
+        n_ht, n_ft, n_tt = B * H * T, B * F_ * T, B * heads * T * T
+        buf = torch.empty(8 * n_ht + n_ft + n_tt + 4 * B * T, device=dev, dtype=torch.float32)
+        off = [0]
+
+        def take(n, *shape):
+            v = buf[off[0]: off[0] + n].view(*shape)
+            off[0] += n
+            return v
+        q, k, v, y_att, o, x1, y2, x2 = (take(n_ht, B, H, T) for _ in range(8))
+        h = take(n_ft, B, F_, T)
+        p_attn = take(n_tt, B, heads, T, T)
+        stats1, stats2 = take(2 * B * T, B, 2, T), take(2 * B * T, B, 2, T)
+        da, do_, dh, d2 = drops if drops is not None else (None, None, None, None)
+        scale = 1.0 / (1.0 - p_drop) if drops is not None else 1.0
+        call("glowtts_encoder_layer_fwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), scale,
+             ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(x2), ptr(stats2),
+             B, H, F_, T, heads, taps, window, share, blk, float(eps))
+        attn.attn = p_attn.detach()
+        ctx.save_for_backward(x, m2, buf, *([] if drops is None else drops))
+        ctx.cfg, ctx.mods, ctx.dims, ctx.scale, ctx.live = cfg, mods, (B, H, F_, T), scale, live
+        return x2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx2):
+        import ctypes
+        heads, taps, window, share, blk, eps, p_drop = ctx.cfg
+        group, attn, ffn, norm1, norm2 = ctx.mods
+        B, H, F_, T = ctx.dims
+        sv = ctx.saved_tensors
+        x, m2, buf = sv[:3]
+        da, do_, dh, d2 = sv[3:7] if len(sv) > 3 else (None, None, None, None)
+        dev = x.device
+        n_ht, n_ft, n_tt = B * H * T, B * F_ * T, B * heads * T * T
+        off = [0]
+
+        def take(src, n, *shape):
+            v = src[off[0]: off[0] + n].view(*shape)
+            off[0] += n
+            return v
+        q, k, v, y_att, o, x1, y2, _x2 = (take(buf, n_ht, B, H, T) for _ in range(8))
+        h = take(buf, n_ft, B, F_, T)
+        p_attn = take(buf, n_tt, B, heads, T, T)
+        stats1, stats2 = take(buf, 2 * B * T, B, 2, T), take(buf, 2 * B * T, B, 2, T)
+        ws = torch.empty(10 * n_ht + n_ft + n_tt, device=dev, dtype=torch.float32)
+        off[0] = 0
+        dx1a, dy2, dx1, dxa, d_o, dy_att, dq, dk_, dv, dx = (take(ws, n_ht, B, H, T) for _ in range(10))
+        d_pre1 = take(ws, n_ft, B, F_, T)
+        ds = take(ws, n_tt, B, heads, T, T)
+        dx2 = f32(dx2.contiguous())
+        tab, live = _enc_layer_table(group, attn, ffn, norm1, norm2)
+        # The layer's weight-gradient kernels stay on the stream this backward runs on (the text encoder's own side stream,
+        # which has ~10 ms of decoder backward to hide ~3 ms of work): sent to the decoder's weight-gradient stream they queue
+        # behind its 5-tap kernels and lengthen the tail every step ends with (A/B: +0.4 ms per step).
+        wgrad = _WgradStream(dev)
+        wgrad.enabled = wgrad.enabled and _ENC_WGRAD
+        call("glowtts_encoder_layer_bwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), ctx.scale,
+             ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(stats2), ptr(dx2),
+             ptr(dx1a), ptr(dy2), ptr(d_pre1), ptr(dx1), ptr(dxa), ptr(d_o), ptr(dy_att), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dx),
+             B, H, F_, T, heads, taps, window, share, blk, wgrad.side.cuda_stream if wgrad.enabled else None)
+        _mark_direct(live, True)
+        if wgrad.enabled:
+            for t in (x, buf, ws, dx2):                  # read by the second stream after this returns
+                t.record_stream(wgrad.side)
+            with torch.cuda.stream(wgrad.side):
+                _notify(live)
+        else:
+            _notify(live)
+        return (dx, None, None, None, None) + (None,) * len(live)

@@ -299,6 +299,63 @@ int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float *x, const 
                            float *dx_wn, float *dx, int B, int C, int H, int T, int taps, int dil_rate, int n_split,
                            int sigmoid_scale, int two_source, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 
+/* ---- text-encoder neighbours folded into kernels, and a whole transformer layer per call -------------------------------
+ * conv_fwd_act : conv_fwd (fp32 tensors) with the elementwise ops around the encoder's convolutions in the epilogue:
+ *   y = dropout(relu((conv(x) [gated] [+ addend]) [* mask]))  — relu flag; drop = keep bytes (B, M, T) or NULL with drop_scale;
+ *   gate_pos (B, M, T) or NULL: the conv result is multiplied by gate_scale where gate_pos > 0 and zeroed elsewhere, BEFORE
+ *   the addend — the backward of "ReLU then dropout" in one test when gate_pos is that layer's output
+ *   (reference attentions.py:373-381, layers.py:73-80).
+ * chan_layernorm_{fwd,bwd}_ex : the value normalised is x * mask_x[b, t] + res * keep * drop_scale (mask_x, drop may be NULL):
+ *   the `x * x_mask` that opens a transformer layer and the dropout on the branch that is added back (attentions.py:64-72)
+ *   never reach HBM; bwd: dx = dv * mask_x and, if dres != NULL, dres = dv * keep * drop_scale.
+ * encoder_layer_{fwd,bwd} (csrc/wn_stack.hip): one post-LN transformer layer of attentions.Encoder (attentions.py:63-73 with
+ *   MultiHeadAttention :204-264 and FFN :373-381) as ONE host call each way.  `L` is a HOST struct of DEVICE pointers (packed
+ *   weights as for conv_fwd: q, k, v, o are 1x1, the FFN convs `taps` wide with 'same' padding, F = filter channels).
+ *   fwd writes the slabs the backward reads: q, k, v, y_att, o, x1, h, y2, x2 (B, ., T), p_attn (B, heads, T, T), stats1/2
+ *   (B, 2, T); drop_a (B, heads, T, T), drop_o / drop_2 (B, H, T), drop_h (B, F, T) are keep bytes (all NULL = no dropout).
+ *   bwd: dx2 must vanish beyond each utterance (it does inside Encoder: every consumer of a layer's output masks it first);
+ *   workspaces dx1a, dy2, dx1, dxa, d_o, dy_att, dq, dkk, dv (B, H, T), d_pre1 (B, F, T), ds (B, heads, T, T); dx (B, H, T) out.
+ *   Parameter gradients: packed weight gradients accumulate in L->dwp_all (cleared here) and are un-packed by unpack_desc on
+ *   wgrad_stream; biases, embeddings and LayerNorm parameters are ACCUMULATED into db_*, demb_*, dgamma*, dbeta*. */
+int glowtts_conv_fwd_act(const float *x, long x_bs, const float *wp, const float *bias, const float *mask,
+                         const float *addend, long addend_bs, float *y, long y_bs, int B, int Cin, int M, int T, int taps,
+                         int dil, int pad, int mask_in, int mask_out, int mask_add, int relu, const unsigned char *drop,
+                         float drop_scale, const float *gate_pos, float gate_scale, glowtts_stream_t stream);
+int glowtts_chan_layernorm_fwd_ex(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                  float drop_scale, const float *gamma, const float *beta, float *y, float *stats, int B,
+                                  int C, int T, float eps, glowtts_stream_t stream);
+int glowtts_chan_layernorm_bwd_ex(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                  float drop_scale, const float *gamma, const float *stats, const float *dy, float *dx,
+                                  float *dres, float *dgamma, float *dbeta, int B, int C, int T, glowtts_stream_t stream);
+typedef struct glowtts_enc_layer {
+    const float *wf_q, *wb_q, *b_q, *wf_k, *wb_k, *b_k, *wf_v, *wb_v, *b_v, *wf_o, *wb_o, *b_o;   /* attention 1x1 convs */
+    const float *wf_1, *wb_1, *b_1, *wf_2, *wb_2, *b_2;                                           /* FFN convs */
+    const float *emb_k, *emb_v;                       /* relative-position embeddings (1 or heads, 2w+1, dk) or NULL */
+    const float *gamma1, *beta1, *gamma2, *beta2;     /* the two LayerNorms */
+    float *dwp_q, *dwp_k, *dwp_v, *dwp_o, *dwp_1, *dwp_2;
+    float *db_q, *db_k, *db_v, *db_o, *db_1, *db_2;
+    float *demb_k, *demb_v, *dgamma1, *dbeta1, *dgamma2, *dbeta2;
+    const long long *pack_desc, *unpack_desc;         /* device tables (6 rows) or pack_desc = NULL: already packed */
+    const int *pack_prefix;
+    float *dwp_all;
+    long long dwp_floats;
+    int n_conv, total_rows;
+} glowtts_enc_layer;
+int glowtts_encoder_layer_fwd(const glowtts_enc_layer *L, const float *x, const float *mask, const unsigned char *drop_a,
+                              const unsigned char *drop_o, const unsigned char *drop_h, const unsigned char *drop_2,
+                              float drop_scale, float *q, float *k, float *v, float *p_attn, float *y_att, float *o, float *x1,
+                              float *stats1, float *h, float *y2, float *x2, float *stats2, int B, int H, int F, int T,
+                              int heads, int taps, int window, int heads_share, int block_len, float eps,
+                              glowtts_stream_t stream);
+int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const float *mask, const unsigned char *drop_a,
+                              const unsigned char *drop_o, const unsigned char *drop_h, const unsigned char *drop_2,
+                              float drop_scale, const float *q, const float *k, const float *v, const float *p_attn,
+                              const float *y_att, const float *o, const float *x1, const float *stats1, const float *h,
+                              const float *y2, const float *stats2, const float *dx2, float *dx1a, float *dy2, float *d_pre1,
+                              float *dx1, float *dxa, float *d_o, float *dy_att, float *ds, float *dq, float *dkk, float *dv,
+                              float *dx, int B, int H, int F, int T, int heads, int taps, int window, int heads_share,
+                              int block_len, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
+
 /* ---- bf16 tensors in HBM (BASELINE configs[2]): the `_io` forms ---------------------------------------------------------
  * Same operators, same shapes and element indexing; `io` (or io_x / io_y) = 1 declares the ACTIVATION tensors bf16 in HBM
  * (void pointers), 0 = fp32 (then each is exactly the function without the suffix).  What stays fp32 in either case:

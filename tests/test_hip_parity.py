@@ -1032,6 +1032,110 @@ def test_wn_native_executor_matches_layer_by_layer_path(G):
             assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
+def _torch_encoder(enc, x, x_mask, keep, p):
+    """attentions.Encoder.forward in plain torch ops with the dropout keep-masks given (reference attentions.py:63-73,
+    204-264, 373-381; relative attention through the package's index-based general path)."""
+    import torch.nn.functional as F
+
+    b, hch, t = x.shape
+    nh = enc.n_heads
+    sizes = [b * nh * t * t, b * hch * t, b * enc.filter_channels * t, b * hch * t]
+    scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    pos = 0
+    pair = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
+    ln = lambda v, n: F.layer_norm(v.transpose(1, 2), (hch,), n.gamma, n.beta, n.eps).transpose(1, 2)      # noqa: E731
+    for attn, n1, ffn, n2 in zip(enc.attn_layers, enc.norm_layers_1, enc.ffn_layers, enc.norm_layers_2):
+        ks = []
+        for n, shape in zip(sizes, [(b, nh, t, t), (b, hch, t), (b, enc.filter_channels, t), (b, hch, t)]):
+            ks.append(None if keep is None else keep[pos: pos + n].view(shape).float() * scale)
+            pos += n
+        x = x * x_mask
+        q, k, v = (F.conv1d(x, c.weight, c.bias) for c in (attn.conv_q, attn.conv_k, attn.conv_v))
+        class _Keep(torch.nn.Module):
+            def forward(self, pr, _k=ks[0]):
+                return pr if _k is None else pr * _k
+
+        old = attn.drop
+        attn.drop = _Keep()
+        try:
+            y, _ = attn._attention_general(q, k, v, pair)
+        finally:
+            attn.drop = old
+        y = F.conv1d(y, attn.conv_o.weight, attn.conv_o.bias)
+        x = ln(x + (y if ks[1] is None else y * ks[1]), n1)
+        pad = ffn.kernel_size // 2
+        hh = torch.relu(F.conv1d(x * x_mask, ffn.conv_1.weight, ffn.conv_1.bias, padding=pad))
+        hh = hh if ks[2] is None else hh * ks[2]
+        y = F.conv1d(hh * x_mask, ffn.conv_2.weight, ffn.conv_2.bias, padding=pad) * x_mask
+        x = ln(x + (y if ks[3] is None else y * ks[3]), n2)
+    return x * x_mask
+
+
+@pytest.mark.parametrize("b,hch,fch,t,nl,win,p", [(3, 32, 64, 37, 2, 4, 0.0), (2, 192, 768, 160, 2, 4, 0.1), (2, 64, 128, 256, 1, None, 0.1)])
+def test_encoder_layer_executor_vs_torch_and_per_op_path(G, b, hch, fch, t, nl, win, p):
+    """convops.EncoderLayerFn (a whole transformer layer queued from C: q/k/v with the mask folded in, attention, both
+    dropouts of the residual branches inside the LayerNorm kernels, ReLU + dropout as conv epilogue / backward gate) against
+    a plain-torch statement of attentions.Encoder with the SAME keep-masks, and (p = 0) against the per-operator path."""
+    from glow_tts_train import convops, optimize
+
+    torch.manual_seed(13)
+    enc = G.attentions.Encoder(hch, fch, 2, nl, kernel_size=3, p_dropout=p, window_size=win).cuda().train()
+    groups = [convops.ConvGroup([a.conv_q, a.conv_k, a.conv_v, a.conv_o, f.conv_1, f.conv_2])
+              for a, f in zip(enc.attn_layers, enc.ffn_layers)]
+    opt = optimize.Adam(enc.parameters(), scheduler="noam", dim_model=hch)     # flat gradient buffers: in-place gradients
+    x0 = torch.randn(b, hch, t, device="cuda")
+    lens = torch.tensor([t, max(1, t - 9), max(1, t // 2)][:b], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
+    r = torch.randn(b, hch, t, device="cuda")
+
+    def run(native):
+        convops._WN_NATIVE = "both" if native else "fwd"
+        opt.zero_grad()
+        for g in groups:
+            g.begin()
+        torch.manual_seed(99)
+        x = x0.clone().requires_grad_(True)
+        y = enc(x, mask)
+        (y * r).sum().backward()
+        convops.flush_groups()
+        torch.cuda.synchronize()
+        convops._WN_NATIVE = "both"
+        return y.detach().clone(), x.grad.clone(), {k_: p_.grad.clone() for k_, p_ in enc.named_parameters()}
+
+    calls = []
+    orig = convops.EncoderLayerFn.forward
+    convops.EncoderLayerFn.forward = staticmethod(lambda *a, _o=orig: (calls.append(1), _o(*a))[1])
+    try:
+        y1, dx1, g1 = run(True)
+    finally:
+        convops.EncoderLayerFn.forward = orig
+    assert len(calls) == nl, "the layer executor did not run"
+    # plain torch with the same keep-masks (the executor draws them in ONE generator call at the top of Encoder.forward)
+    keep = None
+    if p > 0:
+        torch.manual_seed(99)
+        n_keep = nl * (b * 2 * t * t + 2 * b * hch * t + b * fch * t)
+        keep = torch.empty(n_keep, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p)
+    for p_ in enc.parameters():
+        p_.grad = None
+    xr = x0.clone().requires_grad_(True)
+    yr = _torch_encoder(enc, xr, mask, keep, p)
+    (yr * r).sum().backward()
+    assert_close(y1, yr, what="y", rtol=2e-4, atol=2e-4)
+    assert_close(dx1, xr.grad, what="dx", rtol=2e-3, atol=2e-4 * float(xr.grad.abs().max()))
+    gmax = max(float(p_.grad.abs().max()) for p_ in enc.parameters())
+    for k_, p_ in enc.named_parameters():
+        want = p_.grad       # (floor at 1e-5 of the model's largest gradient: the key bias's gradient is mathematically zero)
+        assert_close(g1[k_], want, what=f"grad {k_}", rtol=2e-3, atol=3e-4 * float(want.abs().max()) + 1e-5 * gmax)
+    opt._optim.zero_grad()                                   # (re-attach the flat gradient views for the next run)
+    if p == 0.0:
+        y0, dx0, g0 = run(False)
+        assert_close(y1, y0, what="y vs per-op", rtol=1e-5, atol=1e-5)
+        assert_close(dx1, dx0, what="dx vs per-op", rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
+        for k_ in g0:
+            assert_close(g1[k_], g0[k_], what=f"grad {k_} vs per-op", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k_].abs().max())))
+
+
 @pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("b,h,t,blocks,p_drop,sig", [(3, 192, 100, 2, 0.0, False), (2, 192, 64, 2, 0.05, False),
                                                        (2, 48, 37, 3, 0.0, True)])

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B of host-side switches in ONE process (boxes differ by several percent): alternating blocks of training steps.
+Usage: python tools/ab_flags.py NAME=VALUE_A,VALUE_B [steps_per_block] [blocks]
+  NAME in: enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
+  whole-layer executors vs the per-operator path), io (fp32|all|hidden)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "glow-tts-train_amd")]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from glow_tts_train import convops  # noqa: E402
+from glow_tts_train.train import train_batch  # noqa: E402
+
+name, _, vals = sys.argv[1].partition("=")
+vals = vals.split(",")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+sys.argv = [sys.argv[0]]
+args = bench.parse()
+model, opt, batch, cfg = bench.build_workload(args, torch.device("cuda:0"), 0)
+
+
+def apply(v):
+    if name == "enc_wgrad":
+        convops._ENC_WGRAD = v == "1"
+    elif name == "native":
+        convops._WN_NATIVE = v
+    elif name == "io":
+        model.decoder.io_bf16 = False if v == "fp32" else v
+    else:
+        raise SystemExit("unknown switch " + name)
+
+
+for _ in range(8):
+    train_batch(model, opt, batch, cfg.grad_clip, None)
+res = {v: [] for v in vals}
+for blk in range(2 * blocks):
+    v = vals[blk % len(vals)]
+    apply(v)
+    for _ in range(3):
+        train_batch(model, opt, batch, cfg.grad_clip, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        train_batch(model, opt, batch, cfg.grad_clip, None)
+    torch.cuda.synchronize()
+    res[v].append(1e3 * (time.perf_counter() - t0) / n)
+for v in vals:
+    print(f"{name}={v:8s}: " + "  ".join(f"{t:.2f}" for t in res[v]) + f"   mean {sum(res[v]) / len(res[v]):.2f} ms/step")
