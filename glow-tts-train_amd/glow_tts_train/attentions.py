@@ -182,6 +182,13 @@ class MultiHeadAttention(nn.Module):
             ev = self.emb_rel_v if self.window_size is not None else None
             return _rel_attn_apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
                                        self.block_length, p_drop)
+        if query.is_cuda and not getattr(MultiHeadAttention, "_warned_general", False):
+            MultiHeadAttention._warned_general = True
+            import logging
+            logging.getLogger("glow_tts_train.attentions").warning(
+                "MultiHeadAttention: shape outside the MFMA kernel's envelope (T=%d > 256, d_k=%d, window=%s, cross-attention "
+                "or proximal bias): using the composition of PyTorch ops (slower; still on the GPU)", key.size(2),
+                self.k_channels, self.window_size)
         return self._attention_general(query, key, value, mask)
 
     def _attention_general(self, query, key, value, mask=None):

@@ -245,3 +245,42 @@ def test_fp16_run_selects_bf16_tensors_and_trains(G):
     # the scaler only rescales: same parameters as the unscaled bf16 run up to the round-off of bf16 gradients times 1024
     d = (results["bf16+scaler"][1] - results["bf16"][1]).abs().max()
     assert float(d) < 2e-2, float(d)
+
+
+@pytest.mark.parametrize("mode", [False, "all", "hidden"])
+def test_training_reduces_the_loss(G, mode):
+    """60 updates on one fixed batch (a model this size can fit it): the loss must fall clearly in every tensor mode, and
+    the bf16-tensor runs must follow the fp32 run — the optimiser sees usable gradients, not just finite ones."""
+    from glow_tts_train import config
+    from glow_tts_train.train import train_batch
+
+    cfg = config.TrainingConfig()
+    cfg.model.num_symbols = 60
+    cfg.model.n_blocks_dec = 3
+    cfg.model.n_layers_enc = 2
+    cfg.warmup_steps = 20
+    torch.manual_seed(1234)
+    model, opt = G.models.setup_model(cfg, use_cuda=True)
+    model.train()
+    g = torch.Generator().manual_seed(9)
+    xl = torch.tensor([24, 20, 18, 13])
+    yl = torch.tensor([120, 104, 88, 64])
+    x = (torch.randint(1, 60, (4, 24), generator=g) * (torch.arange(24)[None] < xl[:, None])).cuda()
+    y = (torch.randn(4, 80, 120, generator=g) * (torch.arange(120)[None, None] < yl[:, None, None])).cuda()
+    batch = (x, xl.cuda(), y, yl.cuda(), None)
+    for f in model.decoder.flows:                       # data-dependent ActNorm initialisation, as ddi.py does
+        if hasattr(f, "set_ddi"):
+            f.set_ddi(True)
+    with torch.no_grad():
+        model(*batch[:4])
+    model.decoder.io_bf16 = mode
+    losses = [float(train_batch(model, opt, batch, cfg.grad_clip)) for _ in range(60)]
+    model.decoder.io_bf16 = False
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0] - 0.3, (mode, losses[0], losses[-1])
+    assert np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.3
+    test_training_reduces_the_loss.seen = getattr(test_training_reduces_the_loss, "seen", {})
+    test_training_reduces_the_loss.seen[mode] = losses
+    ref = test_training_reduces_the_loss.seen.get(False)
+    if mode and ref is not None:                        # same weights, same batch, same dropout seeds: the curves stay close
+        assert abs(losses[-1] - ref[-1]) < 0.15 * abs(ref[0] - ref[-1]) + 0.05, (mode, losses[-1], ref[-1])
