@@ -846,7 +846,7 @@ template <int RTW, int NCT, int EPI, int TAPS>
 static int launch_convgemm_wd(ConvGemmParams &p, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;
     constexpr size_t lds_pipe = ((size_t)6 * (NT + 16) * 20 + (NT + 16)) * sizeof(float);
-    constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
+    constexpr size_t lds_epi = ((size_t)WGR * (NT + 4) + (EPI == EPI_GATEBWD ? 2 * WGR : 0)) * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&
@@ -1054,15 +1054,15 @@ extern "C" int glowtts_conv_res_skip_fwd(const float *acts, const float *wp, con
 }
 
 extern "C" int glowtts_conv_gate_bwd_io(const void *d_rs, const void *d_rs2, const float *wp_b, const void *ts,
-                                        const unsigned char *drop, float drop_scale, void *d_pre, int B, int M_rs, int H,
-                                        int T, int io, glowtts_stream_t stream) {
+                                        const unsigned char *drop, float drop_scale, void *d_pre, float *dcond, int B,
+                                        int M_rs, int H, int T, int io, glowtts_stream_t stream) {
     if (int rc = check_conv_common("glowtts_conv_gate_bwd", d_rs, wp_b, B, M_rs, H, T, 1, 1, 0)) return rc;
     GLOWTTS_CHECK_ARG(ts && d_pre, "glowtts_conv_gate_bwd: null pointer");
     GLOWTTS_CHECK_ARG(H % 4 == 0, "glowtts_conv_gate_bwd: hidden width %d must be a multiple of 4", H);
     if ((long)B * T == 0) return 0;
     ConvGemmParams p{};
     p.x = static_cast<const float *>(d_rs); p.wp = wp_b; p.r0 = static_cast<const float *>(ts); p.drop = drop;
-    p.drop_scale = drop_scale; p.y0 = static_cast<float *>(d_pre); p.xb = io; p.yb = io;
+    p.drop_scale = drop_scale; p.y0 = static_cast<float *>(d_pre); p.xb = io; p.yb = io; p.dcond = dcond;
     p.x_bs = (long)M_rs * T; p.B = B; p.Cin = M_rs; p.M = H; p.H = H; p.T = T; p.taps = 1; p.dil = 1; p.pad = 0;
     if (d_rs2) {    // d_rs = rows [0, H) as (B,H,T), d_rs2 = rows [H, 2H) as (B,H,T): never concatenated in memory
         GLOWTTS_CHECK_ARG(M_rs == 2 * H && H % 96 == 0 && T % 4 == 0 && aligned16(d_rs) && aligned16(d_rs2),
@@ -1075,7 +1075,7 @@ extern "C" int glowtts_conv_gate_bwd_io(const void *d_rs, const void *d_rs2, con
 extern "C" int glowtts_conv_gate_bwd(const float *d_rs, const float *d_rs2, const float *wp_b, const float *ts,
                                      const unsigned char *drop, float drop_scale, float *d_pre, int B, int M_rs, int H,
                                      int T, glowtts_stream_t stream) {
-    return glowtts_conv_gate_bwd_io(d_rs, d_rs2, wp_b, ts, drop, drop_scale, d_pre, B, M_rs, H, T, 0, stream);
+    return glowtts_conv_gate_bwd_io(d_rs, d_rs2, wp_b, ts, drop, drop_scale, d_pre, nullptr, B, M_rs, H, T, 0, stream);
 }
 
 extern "C" int glowtts_conv_wrw2(const float *x, long x_bs, const float *d, long d_bs, const float *d2, long d2_bs,

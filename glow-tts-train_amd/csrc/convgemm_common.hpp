@@ -43,6 +43,8 @@ struct ConvGemmParams {
     int mask_add;            // ADD: multiply the addend by mask
     int vec_epilogue;        // pipelined kernel: 16-byte epilogue through LDS (all epilogue tensors 16-byte aligned)
     float drop_scale;        // 1 / (1 - p)
+    float *dcond;            // EPI_GATEBWD: (B, 2H) accumulated row sums over t of the UN-dropped pre-activation gradient — the
+                             //   gradient of the speaker conditioning row added before the gate (layers.py:150-153) — or null
     int relu;                // PLAIN / ADD: y = max(y, 0) after bias (and mask_out), before the dropout below
     const float *gate_pos;   // PLAIN / ADD (backward-data of a conv that follows ReLU [+ dropout]): (B, M, T) tensor g; the
     float gate_scale;        //   conv result is multiplied by gate_scale where g > 0 and zeroed elsewhere, before the addend.
@@ -158,6 +160,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams &p, f32x4 (&a
                     const long ot = ((long)b * 2 * p.H + row) * p.T + t, os = ot + (long)p.H * p.T;
                     const float th = E::ld1(p.r0, ot), sg = E::ld1(p.r0, os);
                     float dt = v * sg * (1.0f - th * th), ds = v * th * sg * (1.0f - sg);
+                    if (p.dcond) {           // (rare path: rows not 16-byte aligned) one atomic per element
+                        atomicAdd(p.dcond + (long)b * 2 * p.H + row, dt);
+                        atomicAdd(p.dcond + (long)b * 2 * p.H + p.H + row, ds);
+                    }
                     if (p.drop) {
                         dt = p.drop[ot] ? dt * p.drop_scale : 0.f;
                         ds = p.drop[os] ? ds * p.drop_scale : 0.f;
@@ -275,6 +281,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Ls[(ltile(r) * 16 + lk * 4 + reg) * LP + c * 16 + lrow] = acc[r][c][reg];
+    float *rsum = Ls + WGR * LP;                         // EPI_GATEBWD with dcond: [2][WGR] row sums (the launch reserves them)
+    if (EPI == EPI_GATEBWD && p.dcond != nullptr)
+        for (int i = threadIdx.x; i < 2 * WGR; i += 256) rsum[i] = 0.f;
     __syncthreads();
     const int tid = threadIdx.x;
     const float *mk = p.mask ? p.mask + (long)b * p.T : nullptr;
@@ -420,6 +429,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
             for (int jj = 0; jj < 4; ++jj) {
                 dt[jj] = go[jj] * sg[jj] * (1.0f - th[jj] * th[jj]);
                 ds[jj] = go[jj] * th[jj] * sg[jj] * (1.0f - sg[jj]);
+            }
+            if (p.dcond != nullptr) {                     // conditioning is added AFTER the dropout: its gradient is un-dropped
+                atomicAdd(rsum + lr, (dt[0] + dt[1]) + (dt[2] + dt[3]));
+                atomicAdd(rsum + WGR + lr, (ds[0] + ds[1]) + (ds[2] + ds[3]));
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
                 if (p.drop) {
                     dt[jj] = ((ka[i] >> (8 * jj)) & 0xffu) ? dt[jj] * p.drop_scale : 0.f;
                     ds[jj] = ((kb[i] >> (8 * jj)) & 0xffu) ? ds[jj] * p.drop_scale : 0.f;
@@ -427,6 +443,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams &p, f32x4
             }
             E::st4(p.y0, ot, make_float4(dt[0], dt[1], dt[2], dt[3]));
             E::st4(p.y0, os, make_float4(ds[0], ds[1], ds[2], ds[3]));
+        }
+    }
+    if (EPI == EPI_GATEBWD && p.dcond != nullptr) {       // one global atomic per (row, half) and workgroup
+        __syncthreads();
+        for (int i = tid; i < 2 * WGR; i += 256) {
+            const int half = i / WGR, lr = i - half * WGR, row = tile_m * WGR + lr;
+            if (row < p.M) atomicAdd(p.dcond + (long)b * 2 * p.H + half * p.H + row, rsum[i]);
         }
     }
 }

@@ -650,7 +650,7 @@ template <int NS, int RTW, int NCT, int EPI, int TAPS, int IOB = 0, int NSA = NS
 static int launch_split(ConvGemmParams &p, const unsigned short *planes, long stride, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;
     constexpr size_t lds_pipe = (size_t)NS * 3 * (NT + 16) * 80 + (size_t)(NT + 16) * sizeof(float);
-    constexpr size_t lds_epi = (size_t)WGR * (NT + 4) * sizeof(float);
+    constexpr size_t lds_epi = ((size_t)WGR * (NT + 4) + (EPI == EPI_GATEBWD ? 2 * WGR : 0)) * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     p.vec_epilogue = aligned16(p.y0) && aligned16(p.y1) && aligned16(p.r0) && aligned16(p.r1) && aligned16(p.mask) &&

@@ -73,8 +73,9 @@ static int wrw_any(const void *x, long x_bs, const void *d, long d_bs, const flo
 }
 
 extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
-                                 const unsigned char *drop, float drop_scale, void *xs, void *acts, void *ts, void *skip,
-                                 int B, int H, int T, int taps, int dil_rate, int io, glowtts_stream_t stream) {
+                                 const float *cond, const unsigned char *drop, float drop_scale, void *xs, void *acts,
+                                 void *ts, void *skip, int B, int H, int T, int taps, int dil_rate, int io,
+                                 glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(layers && x && mask && acts && ts && skip, "glowtts_wn_fwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_fwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_fwd: bad shape");
@@ -85,7 +86,8 @@ extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, c
         const bool last = i == n_layers - 1;
         const void *x_i = i == 0 ? x : at((const void *)xs, (long)(i - 1) * BHT, io);
         const int pad = (int)((taps * dil - dil) / 2);
-        WN_TRY(glowtts_conv_gate_fwd_io(x_i, L.wf_in, L.b_in, nullptr, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale,
+        WN_TRY(glowtts_conv_gate_fwd_io(x_i, L.wf_in, L.b_in, cond ? cond + (long)i * B * 2 * H : nullptr,
+                                        drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale,
                                         at(acts, (long)i * BHT, io), at(ts, (long)i * 2 * BHT, io), B, H, T, taps, (int)dil, pad,
                                         io, stream));
         // x_{i+1} = (x_i + rs[:H]) mask ; skip += rs[H:]   (skip accumulates in place: same thread reads and writes an element)
@@ -99,12 +101,13 @@ extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, c
 extern "C" int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask,
                               const unsigned char *drop, float drop_scale, float *xs, float *acts, float *ts, float *skip,
                               int B, int H, int T, int taps, int dil_rate, glowtts_stream_t stream) {
-    return glowtts_wn_fwd_io(layers, n_layers, x, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate, 0, stream);
+    return glowtts_wn_fwd_io(layers, n_layers, x, mask, nullptr, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate, 0,
+                             stream);
 }
 
 extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const void *xs,
                                  const void *acts, const void *ts, const float *mask, const unsigned char *drop,
-                                 float drop_scale, const void *dskip, void *d_rs, void *d_xin, void *dx,
+                                 float drop_scale, const void *dskip, void *d_rs, void *d_xin, void *dx, float *dcond,
                                  const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
                                  int H, int T, int taps, int dil_rate, int two_source, int mask_input_grad, int io,
                                  glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
@@ -144,12 +147,14 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
                 WN_TRY(order_after(ms, ws));
                 WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, d_rsf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
                                         1, 0, (glowtts_stream_t)ws));
-                WN_TRY(glowtts_conv_gate_bwd(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, H, H, T, stream));
+                WN_TRY(glowtts_conv_gate_bwd_io(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                                                dcond ? dcond + (long)i * B * 2 * H : nullptr, B, H, H, T, 0, stream));
             } else {
                 WN_TRY(order_after(ms, ws));
                 WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dskf, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
                                          T, 1, 1, 0, (glowtts_stream_t)ws));
-                WN_TRY(glowtts_conv_gate_bwd(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i, B, 2 * H, H, T, stream));
+                WN_TRY(glowtts_conv_gate_bwd_io(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                                                dcond ? dcond + (long)i * B * 2 * H : nullptr, B, 2 * H, H, T, 0, stream));
             }
             WN_TRY(order_after(ms, ws));
             WN_TRY(glowtts_conv_wrw(x_i, (long)H * T, dxin_i, (long)2 * H * T, nullptr, nullptr, L.dwp_in, L.db_in, B, H, 2 * H, T,
@@ -175,8 +180,8 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
                                        last ? 1 : 0, io, stream));
         if (last) dsk = drs_i;
         // d(pre-activation) = gate'(stored tanh / sigmoid) * (W_rs^T d_rs)
-        WN_TRY(glowtts_conv_gate_bwd_io(drs_i, nullptr, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i, B,
-                                        m_rs, H, T, io, stream));
+        WN_TRY(glowtts_conv_gate_bwd_io(drs_i, nullptr, L.wb_rs, ts_i, drop ? drop + (long)i * 2 * BHT : nullptr, drop_scale, dxin_i,
+                                        dcond ? dcond + (long)i * B * 2 * H : nullptr, B, m_rs, H, T, io, stream));
         // dx_i = (residual path) d_rs[:H] + (conv path) W_in^T (*) d_xin ; the last layer has no residual path
         const bool m_out = i == 0 && mask_input_grad;
         WN_TRY(glowtts_conv_fwd_io(dxin_i, (long)2 * H * T, L.wb_in, nullptr, m_out ? mask : nullptr, last ? nullptr : drs_i,
@@ -213,7 +218,7 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
                               const long long *unpack_desc, const int *unpack_prefix, int n_conv, int total_rows, int B,
                               int H, int T, int taps, int dil_rate, int two_source, glowtts_stream_t wgrad_stream,
                               glowtts_stream_t stream) {
-    return glowtts_wn_bwd_io(layers, n_layers, x, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx, unpack_desc,
+    return glowtts_wn_bwd_io(layers, n_layers, x, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx, nullptr, unpack_desc,
                              unpack_prefix, n_conv, total_rows, B, H, T, taps, dil_rate, two_source, 0, 0, wgrad_stream, stream);
 }
 
@@ -228,7 +233,7 @@ extern "C" int glowtts_wn_bwd(const glowtts_wn_layer *layers, int n_layers, cons
 // accumulates in fp32.  With io == 1 the start conv reads y0h, a bf16 copy (B, C/2, T) of y's first half written by the
 // fused ActNorm + InvConv kernel (unused otherwise, may be NULL).
 extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
-                                         const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs,
+                                         const float *cond, const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs,
                                          void *acts, void *ts, void *skip, float *out, void *z, float *logdet, int B, int C,
                                          int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int io,
                                          glowtts_stream_t stream) {
@@ -255,7 +260,7 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     // flow 3i+2: h = start(y[:, :C/2]) mask  ->  WN  ->  out = end(h)  ->  z = [y0 ; (m + e^logs y1) mask], logdet += sum logs mask
     WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1,
                                0, io_h, io_h, stream));
-    WN_TRY(glowtts_wn_fwd_io(blk->layers, blk->n_layers, h0, mask, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
+    WN_TRY(glowtts_wn_fwd_io(blk->layers, blk->n_layers, h0, mask, cond, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
                              io_h, stream));
     WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
                                stream));
@@ -267,15 +272,15 @@ extern "C" int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float
                                       float *acts, float *ts, float *skip, float *out, float *z, float *logdet, int B, int C,
                                       int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
                                       glowtts_stream_t stream) {
-    return glowtts_flow_block_fwd_io(blk, x, mask, x_len, drop, drop_scale, y, nullptr, h0, xs, acts, ts, skip, out, z, logdet, B, C,
-                                     H, T, taps, dil_rate, n_split, sigmoid_scale, 0, stream);
+    return glowtts_flow_block_fwd_io(blk, x, mask, x_len, nullptr, drop, drop_scale, y, nullptr, h0, xs, acts, ts, skip, out, z, logdet,
+                                     B, C, H, T, taps, dil_rate, n_split, sigmoid_scale, 0, stream);
 }
 
 extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
                                          const unsigned char *drop, float drop_scale, const void *y, const void *y0h, const void *h0,
                                          const void *xs, const void *acts, const void *ts, const void *skip, const float *out,
                                          const void *dz, const float *dlogdet, void *dy, void *dout, void *dskip, void *d_rs,
-                                         void *d_xin, void *dx_wn, void *dx, int B, int C, int H, int T, int taps, int dil_rate,
+                                         void *d_xin, void *dx_wn, void *dx, float *dcond, int B, int C, int H, int T, int taps, int dil_rate,
                                          int n_split, int sigmoid_scale, int two_source, int io, glowtts_stream_t wgrad_stream,
                                          glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(blk && x && mask && x_len && y && h0 && acts && ts && skip && out && dz && dy && dout && dskip && d_rs &&
@@ -303,8 +308,8 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
                                stream));
     // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block).
     // With bf16 tensors the stack masks its own input gradient: the start conv's weight gradient then needs no mask.
-    WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, nullptr,
-                             nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, io_h, io_h, wgrad_stream, stream));
+    WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, dcond,
+                             nullptr, nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, io_h, io_h, wgrad_stream, stream));
     // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
     WN_TRY(order_after(ms, ws));
     WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,
@@ -328,8 +333,8 @@ extern "C" int glowtts_flow_block_bwd(const glowtts_flow_block *blk, const float
                                       int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int two_source,
                                       glowtts_stream_t wgrad_stream, glowtts_stream_t stream) {
     return glowtts_flow_block_bwd_io(blk, x, mask, x_len, drop, drop_scale, y, nullptr, h0, xs, acts, ts, skip, out, dz, dlogdet, dy, dout,
-                                     dskip, d_rs, d_xin, dx_wn, dx, B, C, H, T, taps, dil_rate, n_split, sigmoid_scale, two_source,
-                                     0, wgrad_stream, stream);
+                                     dskip, d_rs, d_xin, dx_wn, dx, nullptr, B, C, H, T, taps, dil_rate, n_split, sigmoid_scale,
+                                     two_source, 0, wgrad_stream, stream);
 }
 
 

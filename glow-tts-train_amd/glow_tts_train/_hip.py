@@ -83,21 +83,21 @@ _SIGNATURES = {
     "glowtts_encoder_layer_fwd": [_P] * 7 + [_F] + [_P] * 12 + [_I] * 9 + [_F],
     "glowtts_encoder_layer_bwd": [_P] * 7 + [_F] + [_P] * 24 + [_I] * 9 + [_P],
     # `_io` forms (bf16 activation tensors in HBM: BASELINE configs[2]); the trailing int before the stream(s) is the io flag
-    "glowtts_flow_block_fwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 10 + [_I] * 9,
-    "glowtts_flow_block_bwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 17 + [_I] * 10 + [_P],
+    "glowtts_flow_block_fwd_io": [_P, _P, _P, _P, _P, _P, _F] + [_P] * 10 + [_I] * 9,
+    "glowtts_flow_block_bwd_io": [_P, _P, _P, _P, _P, _F] + [_P] * 18 + [_I] * 10 + [_P],
     "glowtts_squeeze_io": [_P, _P, _P, _P, _I, _I, _I, _I, _I],
     "glowtts_unsqueeze_io": [_P, _P, _P, _P, _I, _I, _I, _I, _I],
     "glowtts_conv_fwd_io": [_P, _L, _P, _P, _P, _P, _L, _P, _L] + [_I] * 12,
     "glowtts_conv_gate_fwd_io": [_P, _P, _P, _P, _P, _F, _P, _P] + [_I] * 7,
     "glowtts_conv_res_skip_fwd_io": [_P] * 8 + [_I] * 5,
-    "glowtts_conv_gate_bwd_io": [_P, _P, _P, _P, _P, _F, _P] + [_I] * 5,
+    "glowtts_conv_gate_bwd_io": [_P, _P, _P, _P, _P, _F, _P, _P] + [_I] * 5,
     "glowtts_res_skip_bwd_io": [_P] * 5 + [_I] * 5,
     "glowtts_actnorm_invconv_fwd_io": [_P] * 10 + [_I] * 5,
     "glowtts_actnorm_invconv_bwd_io": [_P] * 13 + [_I] * 5,
     "glowtts_coupling_fwd_io": [_P, _P, _P, _P, _P] + [_I] * 6,
     "glowtts_coupling_bwd_io": [_P] * 7 + [_I] * 6,
-    "glowtts_wn_fwd_io": [_P, _I, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 6,
-    "glowtts_wn_bwd_io": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "glowtts_wn_fwd_io": [_P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P] + [_I] * 6,
+    "glowtts_wn_bwd_io": [_P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
 }
 
 

@@ -858,9 +858,11 @@ class FlowBlockPlan:
 def flow_block_eligible(actnorm, invconv, coupling, x, g) -> bool:
     """Can [actnorm, invconv, coupling] run as ONE native call each way (FlowBlockFn)?  Training direction, no conditioning
     input, fused-flow sizes, every parameter gradient already allocated (the flat-buffer optimizer) and written in place."""
-    if g is not None or not x.is_cuda or not torch.is_grad_enabled() or not _hip.timing_off() or _WN_NATIVE != "both":
+    if not x.is_cuda or not torch.is_grad_enabled() or not _hip.timing_off() or _WN_NATIVE != "both":
         return False
-    if not actnorm.initialized or invconv.no_jacobian or invconv.n_split not in (2, 4) or coupling.gin_channels != 0:
+    if not actnorm.initialized or invconv.no_jacobian or invconv.n_split not in (2, 4):
+        return False
+    if (g is not None) != (coupling.gin_channels != 0):      # speaker conditioning: the block takes the cond rows as an input
         return False
     if not direct_grads_enabled():
         return False
@@ -898,7 +900,8 @@ class FlowBlockFn(Function):
     (csrc/wn_stack.hip: glowtts_flow_block_fwd / _bwd queue the block's whole launch sequence from C)."""
 
     @staticmethod
-    def forward(ctx, x, m2, x_len, drop, cfg, bplan, *params):
+    def forward(ctx, x, m2, x_len, drop, cfg, bplan, cond, *params):
+        # cond: None or the speaker conditioning rows (B, 2H * n_layers, 1) = wn.cond_layer(g) (reference layers.py:142-150)
         import ctypes
         n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
         # io (csrc: the `_io` entry points): 0 = fp32 tensors; 1 = the coupling network's hidden tensors bf16 in HBM, the
@@ -933,7 +936,10 @@ class FlowBlockFn(Function):
             tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
             taps = params[8].shape[2]
             scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-            call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), scale, ptr(y), ptr(y0h),
+            cond_l = None
+            if cond is not None:                         # layer-major rows (n_layers, B, 2H) for the gate kernels
+                cond_l = f32(cond.detach()).reshape(B, n_layers, 2 * H).permute(1, 0, 2).contiguous()
+            call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(cond_l), ptr(drop), scale, ptr(y), ptr(y0h),
                  ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(z), ptr(logdet), B, C, H, T, taps, dil_rate, n_split,
                  int(sigmoid_scale), int(io))
         finally:
@@ -941,6 +947,7 @@ class FlowBlockFn(Function):
         ctx.save_for_backward(x, m2, x_len, y, h0, acts, ts, skip, out, winv, *([] if xs is None else [xs]),
                               *([] if drop is None else [drop]), *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplan, ctx.params, ctx.taps, ctx.scale = cfg, bplan, params, taps, scale
+        ctx.cond_shape = None if cond is None else tuple(cond.shape)
         return z, logdet
 
     @staticmethod
@@ -976,11 +983,14 @@ class FlowBlockFn(Function):
         d_xin, dx_wn = new(n_layers, B, 2 * H, T), new(n_layers, B, H, T)
         tab = bplan.table(params, n_layers)
         tab.w_inv, tab.logdet_w = winv.data_ptr(), winv.data_ptr() + 4 * n_split * n_split
+        dcond_l = None
+        if ctx.cond_shape is not None:
+            dcond_l = scratch_zeros((n_layers, B, 2 * H), dev)
         bound = bplan.bind(io)
         try:
             call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(x_len), ptr(drop), ctx.scale, ptr(y),
                  ptr(y0h), ptr(h0), ptr(xs), ptr(acts), ptr(ts), ptr(skip), ptr(out), ptr(dz), ptr(dlogdet), ptr(dy), ptr(dout), ptr(dskip),
-                 ptr(d_rs), ptr(d_xin), ptr(dx_wn), ptr(dx), B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale),
+                 ptr(d_rs), ptr(d_xin), ptr(dx_wn), ptr(dx), ptr(dcond_l), B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale),
                  int(two_src), int(io), wgrad.side.cuda_stream if wgrad.enabled else None)
         finally:
             bplan.unbind(bound)
@@ -994,7 +1004,8 @@ class FlowBlockFn(Function):
                 _notify(live)
         else:
             _notify(live)
-        return (dx, None, None, None, None, None) + (None,) * len(params)
+        dcond = None if dcond_l is None else dcond_l.permute(1, 0, 2).reshape(ctx.cond_shape)
+        return (dx, None, None, None, None, None, dcond) + (None,) * len(params)
 
 
 # ----------------------------------------------------------------------------------------------------------------

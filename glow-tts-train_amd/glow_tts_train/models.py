@@ -200,7 +200,8 @@ class FlowSpecDecoder(nn.Module):
                     drop, wn._drop_pre = getattr(wn, "_drop_pre", None), None
                     cfg = (nxt.n_split, bool(cpl.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0,
                            wn.dilation_rate, wn.n_layers, wn.hidden_channels, io)
-                    x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan,
+                    cond = wn.cond_layer(g) if g is not None else None       # (B, 2H * n_layers, 1): tiny, left to torch
+                    x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan, cond,
                                                   *convops.flow_block_params(f, nxt, cpl))
                     i += 3
                 elif (isinstance(f, ActNorm) and f.initialized and isinstance(nxt, InvConvNear) and not nxt.no_jacobian

@@ -377,7 +377,10 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       bf16 copy (B, C/2, T) of z's first half for a bf16 start conv behind an fp32 flow tensor
  *   squeeze_io / unsqueeze_io : io = the SQUEEZED tensor only (mel frames / the latent handed to the loss stay fp32)
  *   wn_*_io : io = every slab; wn_bwd_io's mask_input_grad = 1 multiplies the stack's own input gradient by the mask
- *       (required with io = 1, where the two-source form is not available)
+ *       (required with io = 1, where the two-source form is not available).  Speaker conditioning (layers.py:142-153): cond
+ *       (n_layers, B, 2H) fp32 or NULL = the rows added to each layer's pre-activation AFTER its dropout; dcond (same shape,
+ *       ACCUMULATED, may be NULL) = their gradient, the row sums over t of the un-dropped pre-activation gradient, reduced
+ *       in the gate-backward kernel's epilogue (conv_gate_bwd_io's dcond: one layer's (B, 2H))
  *   flow_block_*_io : io bit 0 = the coupling network's hidden tensors (h0, xs, acts, ts, skip, their gradients, dout), bit 1
  *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
  *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads */
@@ -392,8 +395,8 @@ int glowtts_conv_res_skip_fwd_io(const void *acts, const float *wp, const float 
                                  const void *skip_in, void *x_out, void *skip_out, int B, int H, int T, int last, int io,
                                  glowtts_stream_t stream);
 int glowtts_conv_gate_bwd_io(const void *d_rs, const void *d_rs2, const float *wp_b, const void *ts,
-                             const unsigned char *drop, float drop_scale, void *d_pre, int B, int M_rs, int H, int T, int io,
-                             glowtts_stream_t stream);
+                             const unsigned char *drop, float drop_scale, void *d_pre, float *dcond, int B, int M_rs, int H,
+                             int T, int io, glowtts_stream_t stream);
 int glowtts_res_skip_bwd_io(const void *dx_out, const void *dskip, const float *mask, void *dx, void *drs, int B, int H,
                             int T, int last, int io, glowtts_stream_t stream);
 int glowtts_actnorm_invconv_fwd_io(const void *x, const float *mask, const float *logs, const float *bias, const float *w,
@@ -412,24 +415,24 @@ int glowtts_squeeze_io(const float *x, const float *mask, void *xs, float *ms, i
                        glowtts_stream_t stream);
 int glowtts_unsqueeze_io(const void *xs, const float *ms, float *x, float *mask_out, int B, int C, int Tsq, int n, int io,
                          glowtts_stream_t stream);
-int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
+int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask, const float *cond,
                       const unsigned char *drop, float drop_scale, void *xs, void *acts, void *ts, void *skip, int B, int H,
                       int T, int taps, int dil_rate, int io, glowtts_stream_t stream);
 int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const void *xs, const void *acts,
                       const void *ts, const float *mask, const unsigned char *drop, float drop_scale, const void *dskip,
-                      void *d_rs, void *d_xin, void *dx, const long long *unpack_desc, const int *unpack_prefix, int n_conv,
+                      void *d_rs, void *d_xin, void *dx, float *dcond, const long long *unpack_desc, const int *unpack_prefix, int n_conv,
                       int total_rows, int B, int H, int T, int taps, int dil_rate, int two_source, int mask_input_grad, int io,
                       glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
-                              const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs, void *acts, void *ts,
+                              const float *cond, const unsigned char *drop, float drop_scale, void *y, void *y0h, void *h0, void *xs, void *acts, void *ts,
                               void *skip, float *out, void *z, float *logdet, int B, int C, int H, int T, int taps,
                               int dil_rate, int n_split, int sigmoid_scale, int io, glowtts_stream_t stream);
 int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, const float *mask, const float *x_len,
                               const unsigned char *drop, float drop_scale, const void *y, const void *y0h, const void *h0, const void *xs,
                               const void *acts, const void *ts, const void *skip, const float *out, const void *dz,
                               const float *dlogdet, void *dy, void *dout, void *dskip, void *d_rs, void *d_xin, void *dx_wn,
-                              void *dx, int B, int C, int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale,
-                              int two_source, int io, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
+                              void *dx, float *dcond, int B, int C, int H, int T, int taps, int dil_rate, int n_split,
+                              int sigmoid_scale, int two_source, int io, glowtts_stream_t wgrad_stream, glowtts_stream_t stream);
 
 /* ---- relative-position multi-head self-attention (csrc/attention.hip) ------------------------------------------
  * replaces MultiHeadAttention.attention and its pad/reshape helpers (attentions.py:214-333).  q, k, v, out: (B, H*dk, T)

@@ -1137,9 +1137,10 @@ def test_encoder_layer_executor_vs_torch_and_per_op_path(G, b, hch, fch, t, nl, 
 
 
 @pytest.mark.usefixtures("conv_mode")
-@pytest.mark.parametrize("b,h,t,blocks,p_drop,sig", [(3, 192, 100, 2, 0.0, False), (2, 192, 64, 2, 0.05, False),
-                                                       (2, 48, 37, 3, 0.0, True)])
-def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig):
+@pytest.mark.parametrize("b,h,t,blocks,p_drop,sig,gin", [(3, 192, 100, 2, 0.0, False, 0), (2, 192, 64, 2, 0.05, False, 0),
+                                                           (2, 48, 37, 3, 0.0, True, 0), (3, 192, 80, 2, 0.05, False, 16),
+                                                           (2, 48, 37, 2, 0.0, True, 8)])
+def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig, gin):
     """convops.FlowBlockFn (a whole [ActNorm, InvConvNear, CouplingBlock] block queued from C, one autograd node) against
     the per-operator path (five nodes per block): same kernels in the same order, so outputs agree to rounding of the
     atomics; with dropout both draw the same keep-masks from the same generator state."""
@@ -1147,7 +1148,7 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
 
     torch.manual_seed(77)
     dec = G.models.FlowSpecDecoder(80, h, kernel_size=5, dilation_rate=1, n_blocks=blocks, n_layers=3, p_dropout=p_drop,
-                                   n_split=4, n_sqz=2, sigmoid_scale=sig).cuda().train()
+                                   n_split=4, n_sqz=2, sigmoid_scale=sig, gin_channels=gin).cuda().train()
     with torch.no_grad():
         for f in dec.flows:
             if hasattr(f, "end"):
@@ -1155,6 +1156,7 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
             if hasattr(f, "logs"):
                 f.logs.normal_(0, 0.1)
                 f.bias.normal_(0, 0.1)
+    g0 = torch.randn(b, gin, 1, device="cuda") if gin else None      # speaker embedding rows (models.py:320-323)
     y0 = torch.randn(b, 80, 2 * t, device="cuda")
     lens = torch.tensor([2 * t, 2 * t - 10, t][:b], device="cuda")
     mask = (torch.arange(2 * t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
@@ -1172,7 +1174,8 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
                 p.grad = torch.zeros_like(p)
             torch.manual_seed(5)
             y = (y0 * mask).clone().requires_grad_(True)
-            z, ld = dec(y, mask)
+            gg = None if g0 is None else g0.clone().requires_grad_(True)
+            z, ld = dec(y, mask, g=gg)
             ((z * r).sum() + (ld * s).sum()).backward()
             convops.flush_groups()
             torch.cuda.synchronize()
@@ -1180,7 +1183,10 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
             convops._WN_NATIVE = "both"
             convops.FlowBlockFn.forward = orig
         used[mode] = len(calls)
-        res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), {k: p.grad.clone() for k, p in dec.named_parameters()})
+        grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
+        if gg is not None:
+            grads["<speaker rows g>"] = gg.grad.clone()
+        res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), grads)
     assert used["both"] == blocks and used["fwd"] == 0, used
     z1, l1, dx1, g1 = res["both"]
     z0, l0, dx0, g0 = res["fwd"]
