@@ -400,8 +400,12 @@ def main():
 
     # ---- extra leg (not `value`): bf16 activation tensors in HBM for the flow decoder (decoder.io_bf16 = "all")
     if args.dtype == "bf16" and mode == "eager":
+        from glow_tts_train.attentions import MultiHeadAttention
         dec = model.decoder
         dec.io_bf16 = "all"
+        mhas = [m for m in model.modules() if isinstance(m, MultiHeadAttention)]
+        for m in mhas:
+            m.bf16_mma = True                          # encoder attention contractions on v_mfma_f32_16x16x16_bf16
         try:
             for _ in range(3):
                 step_fn()
@@ -419,13 +423,16 @@ def main():
                               "dtype": "bf16 tensors / fp32 accumulate", "loss_after_these_further_steps": float(loss),
                               "what": "flow decoder: squeezed flow tensor and every hidden tensor of the coupling networks bf16 in "
                                       "HBM, v_mfma_f32_16x16x32_bf16 with fp32 accumulation, fp32 parameters / (m, logs) / "
-                                      "log-determinants / parameter gradients; text encoder and losses as in `value`"}
+                                      "log-determinants / parameter gradients; text encoder: attention contractions on "
+                                      "v_mfma_f32_16x16x16_bf16 (fp32 softmax and tensors); losses as in `value`"}
             log(f"bf16-tensor leg: {out['bf16_io']['ms_per_step']:.2f} ms/step")
         except Exception as exc:
             log(f"bf16-tensor leg failed ({type(exc).__name__}: {exc}); reported as null")
             out["bf16_io"] = None
         finally:
             dec.io_bf16 = False
+            for m in mhas:
+                m.bf16_mma = False
 
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if reducer is not None:

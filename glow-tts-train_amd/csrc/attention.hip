@@ -38,6 +38,24 @@ struct AttnParams {
     int TP;                // LDS pitch of the probability strip
 };
 
+typedef short bf16x4_s __attribute__((ext_vector_type(4)));
+
+// BF = true: the contractions (Q K^T, Q E_k^T, P V, P_w E_v and their backward counterparts) run on the bf16 matrix pipe —
+// v_mfma_f32_16x16x16_bf16, fp32 accumulate; operands are rounded to bf16 (nearest even) in registers on their way from
+// the SAME fp32 LDS images the fp32 path uses (lane slot lk takes k = 4 lk .. 4 lk + 3 of a 16-deep step), scores, softmax
+// and every tensor in HBM stay fp32.  BASELINE configs[2]: "encoder MultiHeadAttention on MFMA" in the bf16 configuration.
+__device__ __forceinline__ bf16x4_s bf4(float a, float b, float c, float d) {
+    const unsigned lo = io_pack_bf16x2(a, b), hi = io_pack_bf16x2(c, d);
+    return bf16x4_s{(short)(lo & 0xffffu), (short)(lo >> 16), (short)(hi & 0xffffu), (short)(hi >> 16)};
+}
+__device__ __forceinline__ bf16x4_s bf4_strided(const float *p, int stride) {
+    return bf4(p[0], p[stride], p[2 * stride], p[3 * stride]);
+}
+__device__ __forceinline__ bf16x4_s bf4_row(const float *p) { return bf4(p[0], p[1], p[2], p[3]); }
+__device__ __forceinline__ f32x4 mma_bf16(bf16x4_s a, bf16x4_s b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
 constexpr int kAP = 80;    // LDS pitch of the [d][64 queries] A block          (== 16 mod 32)
 constexpr int kBP = 68;    // LDS pitch of the [d][64 keys] B tile              (==  4 mod 32)
 
@@ -101,7 +119,7 @@ __device__ unsigned long long g_attn_trace[1024 * 8];
 #define ATTN_TRACE(i) do { } while (0)
 #endif
 
-template <int MODE>
+template <int MODE, bool BF = false>
 __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     extern __shared__ __align__(16) float smem[];
     const int dk = p.dk, T = p.T, w = p.w, TP = p.TP;
@@ -160,12 +178,21 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             __syncthreads();
             stage_rows64(Bs, kBP, B1g, dk, T, jt * 64, tid);
             __syncthreads();
-            for (int kk = 0; kk < dk; kk += 4) {
-                const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
+            if constexpr (BF) {
+                for (int kk = 0; kk < dk; kk += 16) {
+                    const bf16x4_s av = bf4_strided(As + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    const float bv = Bs[(kk + lk) * kBP + ct * 16 + lcol];
-                    S[jt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, S[jt * 4 + ct], 0, 0, 0);
+                    for (int ct = 0; ct < 4; ++ct)
+                        S[jt * 4 + ct] = mma_bf16(av, bf4_strided(Bs + (kk + 4 * lk) * kBP + ct * 16 + lcol, kBP), S[jt * 4 + ct]);
+                }
+            } else {
+                for (int kk = 0; kk < dk; kk += 4) {
+                    const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const float bv = Bs[(kk + lk) * kBP + ct * 16 + lcol];
+                        S[jt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, S[jt * 4 + ct], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -174,10 +201,15 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     // ---- phase 1b: relative term R[i][r] = sum_d A[d][i] E1[r][d], added on the band j - i + w = r ----------------------
     if (rel) {
         f32x4 R = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kk = 0; kk < dk; kk += 4) {
-            const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
-            const float bv = E1s[lcol * EP + kk + lk];
-            R = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, R, 0, 0, 0);
+        if constexpr (BF) {
+            for (int kk = 0; kk < dk; kk += 16)
+                R = mma_bf16(bf4_strided(As + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP), bf4_row(E1s + lcol * EP + kk + 4 * lk), R);
+        } else {
+            for (int kk = 0; kk < dk; kk += 4) {
+                const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
+                const float bv = E1s[lcol * EP + kk + lk];
+                R = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, R, 0, 0, 0);
+            }
         }
         float *rw = Rs + wave * 16 * 17;
 #pragma unroll
@@ -297,28 +329,50 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         stage_rows64(Bs, kBP, B2g, dk, T, jt * 64, tid);
         __syncthreads();
         const int jmax = min(64, ((T - jt * 64 + 15) >> 4) << 4);     // keys of this tile that exist in the P strip
-        for (int kk = 0; kk < jmax; kk += 4) {
-            const float av = pw[lcol * TP + jt * 64 + kk + lk];
+        if constexpr (BF) {
+            for (int kk = 0; kk < jmax; kk += 16) {
+                const bf16x4_s av = bf4_row(pw + lcol * TP + jt * 64 + kk + 4 * lk);
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                if (dt < DT) {
-                    const float bv = Bs[(dt * 16 + lcol) * kBP + kk + lk];
-                    O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+                for (int dt = 0; dt < 8; ++dt)
+                    if (dt < DT) O[dt] = mma_bf16(av, bf4_row(Bs + (dt * 16 + lcol) * kBP + kk + 4 * lk), O[dt]);
+            }
+        } else {
+            for (int kk = 0; kk < jmax; kk += 4) {
+                const float av = pw[lcol * TP + jt * 64 + kk + lk];
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    if (dt < DT) {
+                        const float bv = Bs[(dt * 16 + lcol) * kBP + kk + lk];
+                        O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+                    }
                 }
             }
         }
     }
     if (rel) {
         const int iq = q0 + wave * 16 + lcol;                  // A operand row = query lcol of this wave
-        for (int kk = 0; kk < 2 * w + 1; kk += 4) {
-            const int r = kk + lk;
-            const int j = iq + r - w;
-            const float av = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+        if constexpr (BF) {                                    // one 16-deep step covers the 2w + 1 <= 15 offsets
+            float pv[4];
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                if (dt < DT) {
-                    const float bv = E2s[r * E2P + dt * 16 + lcol];
-                    O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = 4 * lk + jj, j = iq + r - w;
+                pv[jj] = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+            }
+            const bf16x4_s av = bf4(pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+                if (dt < DT) O[dt] = mma_bf16(av, bf4_strided(E2s + (4 * lk) * E2P + dt * 16 + lcol, E2P), O[dt]);
+        } else {
+            for (int kk = 0; kk < 2 * w + 1; kk += 4) {
+                const int r = kk + lk;
+                const int j = iq + r - w;
+                const float av = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    if (dt < DT) {
+                        const float bv = E2s[r * E2P + dt * 16 + lcol];
+                        O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -354,6 +408,7 @@ struct AttnDkvParams {
     float drop_scale;
 };
 
+template <bool BF = false>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
     extern __shared__ __align__(16) float smem[];
     const int dk = p.dk, T = p.T;
@@ -401,17 +456,32 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
             for (int idx = rows * 64 + tid; idx < 64 * 64; idx += 256) Dss[(idx >> 6) * kAP + (idx & 63)] = 0.f;
         }
         __syncthreads();
-        const int imax = min(64, ((T - i0 + 3) >> 2) << 2);
-        for (int kk = 0; kk < imax; kk += 4) {
-            const float bp = Pds[(kk + lk) * kAP + wave * 16 + lcol];      // B[k = query][col = key]
-            const float bd = Dss[(kk + lk) * kAP + wave * 16 + lcol];
+        if constexpr (BF) {
+            const int imax = min(64, ((T - i0 + 15) >> 4) << 4);               // (rows / columns beyond T are staged as zeros)
+            for (int kk = 0; kk < imax; kk += 16) {
+                const bf16x4_s bp = bf4_strided(Pds + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
+                const bf16x4_s bd = bf4_strided(Dss + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                if (dt < DT) {
-                    const float ao = Dos[(dt * 16 + lcol) * kBP + kk + lk];   // A[row = d][k = query]
-                    const float aq = Qs[(dt * 16 + lcol) * kBP + kk + lk];
-                    aV[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bp, aV[dt], 0, 0, 0);
-                    aK[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bd, aK[dt], 0, 0, 0);
+                for (int dt = 0; dt < 8; ++dt) {
+                    if (dt < DT) {
+                        aV[dt] = mma_bf16(bf4_row(Dos + (dt * 16 + lcol) * kBP + kk + 4 * lk), bp, aV[dt]);
+                        aK[dt] = mma_bf16(bf4_row(Qs + (dt * 16 + lcol) * kBP + kk + 4 * lk), bd, aK[dt]);
+                    }
+                }
+            }
+        } else {
+            const int imax = min(64, ((T - i0 + 3) >> 2) << 2);
+            for (int kk = 0; kk < imax; kk += 4) {
+                const float bp = Pds[(kk + lk) * kAP + wave * 16 + lcol];      // B[k = query][col = key]
+                const float bd = Dss[(kk + lk) * kAP + wave * 16 + lcol];
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    if (dt < DT) {
+                        const float ao = Dos[(dt * 16 + lcol) * kBP + kk + lk];   // A[row = d][k = query]
+                        const float aq = Qs[(dt * 16 + lcol) * kBP + kk + lk];
+                        aV[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bp, aV[dt], 0, 0, 0);
+                        aK[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, bd, aK[dt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -511,15 +581,15 @@ static size_t attn_lds(int dk, int TP) {
            sizeof(float);
 }
 
-template <int MODE>
+template <int MODE, bool BF>
 static int attn_launch(AttnParams &p, hipStream_t s) {
     p.TP = ((p.T + 15) / 16) * 16 + 4;
     const size_t lds = attn_lds(p.dk, p.TP);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE>), lds, "glowtts_rel_attn")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE, BF>), lds, "glowtts_rel_attn")) return rc_;
     dim3 grid((p.T + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL((attn_qblock_kernel<MODE>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_qblock_kernel<MODE, BF>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
 }
 
@@ -527,10 +597,10 @@ static int attn_launch(AttnParams &p, hipStream_t s) {
 
 using namespace glowtts;
 
-extern "C" int glowtts_rel_attn_fwd(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
-                                    const float *mask, const unsigned char *drop, float drop_scale, float *p_attn,
-                                    float *out, int B, int H, int T, int dk, int window, int heads_share, int block_len,
-                                    glowtts_stream_t stream) {
+extern "C" int glowtts_rel_attn_fwd_ex(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                                       const float *mask, const unsigned char *drop, float drop_scale, float *p_attn,
+                                       float *out, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                                       int bf16_mma, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(q && k && v && mask && p_attn && out, "glowtts_rel_attn_fwd: null pointer");
     if (int rc = attn_check("glowtts_rel_attn_fwd", B, H, T, dk, window)) return rc;
     if ((long)B * T == 0) return 0;
@@ -539,14 +609,22 @@ extern "C" int glowtts_rel_attn_fwd(const float *q, const float *k, const float 
     p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
     p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
     p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
-    return attn_launch<0>(p, (hipStream_t)stream);
+    return bf16_mma ? attn_launch<0, true>(p, (hipStream_t)stream) : attn_launch<0, false>(p, (hipStream_t)stream);
 }
 
-extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
-                                    const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
-                                    const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
-                                    float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+extern "C" int glowtts_rel_attn_fwd(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                                    const float *mask, const unsigned char *drop, float drop_scale, float *p_attn,
+                                    float *out, int B, int H, int T, int dk, int window, int heads_share, int block_len,
                                     glowtts_stream_t stream) {
+    return glowtts_rel_attn_fwd_ex(q, k, v, emb_k, emb_v, mask, drop, drop_scale, p_attn, out, B, H, T, dk, window, heads_share,
+                                   block_len, 0, stream);
+}
+
+extern "C" int glowtts_rel_attn_bwd_ex(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
+                                       const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
+                                       const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
+                                       float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                                       int bf16_mma, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(dout && q && k && v && mask && p_attn && ds && dq && dk_out && dv, "glowtts_rel_attn_bwd: null pointer");
     GLOWTTS_CHECK_ARG(!emb_k || (emb_v && demb_k && demb_v), "glowtts_rel_attn_bwd: relative embeddings need their gradients");
     if (int rc = attn_check("glowtts_rel_attn_bwd", B, H, T, dk, window)) return rc;
@@ -558,14 +636,20 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
     p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
     p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
     p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
-    if (int rc = attn_launch<1>(p, s)) return rc;
+    if (int rc = bf16_mma ? attn_launch<1, true>(p, s) : attn_launch<1, false>(p, s)) return rc;
     AttnDkvParams d{};
     d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
     d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
     const size_t lds = ((size_t)2 * dk * kBP + (size_t)2 * 64 * kAP) * sizeof(float);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel), lds, "glowtts_rel_attn_bwd")) return rc_;
-    hipLaunchKernelGGL(attn_dkv_kernel, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
+    if (bf16_mma) {
+        static LdsLimit attr_max_b;
+        if (int rc_ = attr_max_b.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel<true>), lds, "glowtts_rel_attn_bwd")) return rc_;
+        hipLaunchKernelGGL(attn_dkv_kernel<true>, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
+    } else {
+        if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel<false>), lds, "glowtts_rel_attn_bwd")) return rc_;
+        hipLaunchKernelGGL(attn_dkv_kernel<false>, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
+    }
     if (emb_k) {
         const int nr = 2 * window + 1;
         int DC = (256 / nr) & ~7;                      // one (r, d) output per thread, slab rows a multiple of 8
@@ -577,6 +661,15 @@ extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const flo
                            drop_scale, dout, q, demb_k, demb_v, H, T, dk, window, p.e_hs, DC);
     }
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn_bwd");
+}
+
+extern "C" int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
+                                    const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
+                                    const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
+                                    float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                                    glowtts_stream_t stream) {
+    return glowtts_rel_attn_bwd_ex(dout, q, k, v, emb_k, emb_v, mask, drop, drop_scale, p_attn, ds, dq, dk_out, dv, demb_k, demb_v,
+                                   B, H, T, dk, window, heads_share, block_len, 0, stream);
 }
 
 #ifdef GLOWTTS_TRACE

@@ -362,8 +362,8 @@ extern "C" int glowtts_encoder_layer_fwd(const glowtts_enc_layer *L, const float
     WN_TRY(glowtts_conv_fwd(x, HT, L->wf_q, L->b_q, mask, nullptr, 0, q, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
     WN_TRY(glowtts_conv_fwd(x, HT, L->wf_k, L->b_k, mask, nullptr, 0, k, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
     WN_TRY(glowtts_conv_fwd(x, HT, L->wf_v, L->b_v, mask, nullptr, 0, v, HT, B, H, H, T, 1, 1, 0, 1, 0, 0, stream));
-    WN_TRY(glowtts_rel_attn_fwd(q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, y_att, B, heads, T, dk, window,
-                                heads_share, block_len, stream));
+    WN_TRY(glowtts_rel_attn_fwd_ex(q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, y_att, B, heads, T, dk, window,
+                                heads_share, block_len, L->attn_bf16, stream));
     WN_TRY(glowtts_conv_fwd(y_att, HT, L->wf_o, L->b_o, nullptr, nullptr, 0, o, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
     // x1 = LN1(x * mask + dropout(o))
     WN_TRY(glowtts_chan_layernorm_fwd_ex(x, o, mask, drop_o, drop_scale, L->gamma1, L->beta1, x1, stats1, B, H, T, eps, stream));
@@ -419,8 +419,8 @@ extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float
     WN_TRY(glowtts_conv_wrw(y_att, HT, go, HT, nullptr, nullptr, L->dwp_o, L->db_o, B, H, H, T, 1, 1, 0, wss));
     WN_TRY(glowtts_conv_fwd(go, HT, L->wb_o, nullptr, nullptr, nullptr, 0, dy_att, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
     // attention
-    WN_TRY(glowtts_rel_attn_bwd(dy_att, q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, ds, dq, dkk, dv, L->demb_k,
-                                L->demb_v, B, heads, T, dk, window, heads_share, block_len, stream));
+    WN_TRY(glowtts_rel_attn_bwd_ex(dy_att, q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, ds, dq, dkk, dv, L->demb_k,
+                                L->demb_v, B, heads, T, dk, window, heads_share, block_len, L->attn_bf16, stream));
     // q, k, v convs of x * mask: dx = dxa + mask * (Wq^T dq + Wk^T dk + Wv^T dv)
     WN_TRY(order_after(ms, ws));
     WN_TRY(glowtts_conv_wrw(x, HT, dq, HT, nullptr, mask, L->dwp_q, L->db_q, B, H, H, T, 1, 1, 0, wss));

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "glowtts_gate_bwd_ts": [_P, _P, _P, _F, _P, _I, _I, _I],
     "glowtts_rel_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_rel_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_rel_attn_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_rel_attn_bwd_ex": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_squeeze": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_unsqueeze": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_mle_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
@@ -124,7 +126,8 @@ class EncLayer(ctypes.Structure):
         "wf_1", "wb_1", "b_1", "wf_2", "wb_2", "b_2", "emb_k", "emb_v", "gamma1", "beta1", "gamma2", "beta2",
         "dwp_q", "dwp_k", "dwp_v", "dwp_o", "dwp_1", "dwp_2", "db_q", "db_k", "db_v", "db_o", "db_1", "db_2",
         "demb_k", "demb_v", "dgamma1", "dbeta1", "dgamma2", "dbeta2", "pack_desc", "unpack_desc", "pack_prefix", "dwp_all")]
-                + [("dwp_floats", ctypes.c_longlong), ("n_conv", ctypes.c_int), ("total_rows", ctypes.c_int)])
+                + [("dwp_floats", ctypes.c_longlong), ("n_conv", ctypes.c_int), ("total_rows", ctypes.c_int),
+                   ("attn_bf16", ctypes.c_int)])
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",

@@ -131,7 +131,12 @@ class MultiHeadAttention(nn.Module):
 
     The relative terms are stated by index: scores[i,j] += q_i . E_k[j-i+w] and out_i += p_ij E_v[j-i+w] for |j-i| <= w,
     instead of the reference's pad / reshape skewing of (T, 2T-1) matrices.
+
+    `bf16_mma` (module attribute; GLOWTTS_IO=bf16 or train.train_step(fp16_run=True) set it): the kernel's contractions run
+    on the bf16 matrix pipe with fp32 accumulation — the reference's autocast branch (train.py:116-121) computes these
+    matmuls in half precision; here q, k, v, the softmax and p_attn stay fp32.
     """
+    bf16_mma = __import__("os").environ.get("GLOWTTS_IO", "fp32") == "bf16"
 
     def __init__(self, channels: int, out_channels: int, n_heads: int, window_size: typing.Optional[int] = None,
                  heads_share: bool = True, p_dropout: float = 0.0, block_length: typing.Optional[int] = None,
@@ -181,7 +186,7 @@ class MultiHeadAttention(nn.Module):
             ek = self.emb_rel_k if self.window_size is not None else None
             ev = self.emb_rel_v if self.window_size is not None else None
             return _rel_attn_apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
-                                       self.block_length, p_drop)
+                                   self.block_length, p_drop, bool(self.bf16_mma))
         if query.is_cuda and not getattr(MultiHeadAttention, "_warned_general", False):
             MultiHeadAttention._warned_general = True
             import logging

@@ -1041,6 +1041,7 @@ def _enc_layer_table(group, attn, ffn, norm1, norm2):
         t.dwp_all, t.dwp_floats = plan.dwp.data_ptr(), plan.dwp.numel()
         t.n_conv, t.total_rows = len(plan.convs), plan.total_rows
         group._enc_tab, group._enc_key, group._enc_live = t, key, live
+    group._enc_tab.attn_bf16 = int(bool(getattr(attn, "bf16_mma", False)))
     return group._enc_tab, group._enc_live
 
 

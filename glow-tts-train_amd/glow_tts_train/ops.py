@@ -447,10 +447,11 @@ class AlignExpandFn(Function):
 
 class RelAttnFn(Function):
     """Windowed relative-position self-attention (attentions.py:214-264) on the MFMA kernels of csrc/attention.hip.
-    q, k, v: (B, H*dk, T); emb_k / emb_v: (1|H, 2w+1, dk) or None; m2: (B, T) sequence mask.  Returns (out, p_attn)."""
+    q, k, v: (B, H*dk, T); emb_k / emb_v: (1|H, 2w+1, dk) or None; m2: (B, T) sequence mask.  Returns (out, p_attn).
+    `bf16_mma`: the contractions on the bf16 matrix pipe with fp32 accumulation (tensors and softmax stay fp32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, emb_k, emb_v, m2, n_heads, window, block_length, p_drop):
+    def forward(ctx, q, k, v, emb_k, emb_v, m2, n_heads, window, block_length, p_drop, bf16_mma=False):
         q, k, v = f32(_c(q)), f32(_c(k)), f32(_c(v))
         B, C, T = q.shape
         dk = C // n_heads
@@ -464,10 +465,12 @@ class RelAttnFn(Function):
         p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-        call("glowtts_rel_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale, ptr(p_attn),
-             ptr(out), B, n_heads, T, dk, window if has_rel else 0, share, -1 if block_length is None else block_length)
+        call("glowtts_rel_attn_fwd_ex", ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale, ptr(p_attn),
+             ptr(out), B, n_heads, T, dk, window if has_rel else 0, share, -1 if block_length is None else block_length,
+             int(bool(bf16_mma)))
         ctx.save_for_backward(q, k, v, ek, ev, m2, drop, p_attn)
-        ctx.cfg = (n_heads, window if has_rel else 0, share, -1 if block_length is None else block_length, scale)
+        ctx.cfg = (n_heads, window if has_rel else 0, share, -1 if block_length is None else block_length, scale,
+                   int(bool(bf16_mma)))
         ctx.eshape = None if not has_rel else emb_k.shape
         ctx.mark_non_differentiable(p_attn)
         return out, p_attn
@@ -476,7 +479,7 @@ class RelAttnFn(Function):
     @once_differentiable
     def backward(ctx, dout, _dp):
         q, k, v, ek, ev, m2, drop, p_attn = ctx.saved_tensors
-        n_heads, window, share, blk, scale = ctx.cfg
+        n_heads, window, share, blk, scale, bf16_mma = ctx.cfg
         B, C, T = q.shape
         dk = C // n_heads
         dout = _c(dout)
@@ -485,9 +488,10 @@ class RelAttnFn(Function):
         dek = dev = None
         if ek is not None:
             dek, dev = torch.zeros_like(ek), torch.zeros_like(ev)
-        call("glowtts_rel_attn_bwd", ptr(dout), ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale,
-             ptr(p_attn), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dek), ptr(dev), B, n_heads, T, dk, window, share, blk)
-        return dq, dk_, dv, dek, dev, None, None, None, None, None
+        call("glowtts_rel_attn_bwd_ex", ptr(dout), ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale,
+             ptr(p_attn), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dek), ptr(dev), B, n_heads, T, dk, window, share, blk,
+             bf16_mma)
+        return dq, dk_, dv, dek, dev, None, None, None, None, None, None
 
 
 def library_loaded() -> bool:

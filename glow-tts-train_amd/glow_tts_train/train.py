@@ -125,7 +125,8 @@ def train_step(global_step: int, epoch: int, model, optimizer, config, train_loa
 
     `fp16_run` (reference train.py:116-121, 133-141: `autocast()` + GradScaler) selects the reduced-precision form of THIS
     build: the flow decoder keeps its activation tensors in HBM as bf16 (`decoder.io_bf16 = "all"`, models.FlowSpecDecoder)
-    with fp32 parameters, log-determinants and accumulation.  bf16 has fp32's exponent range, so no loss scaling is needed:
+    with fp32 parameters, log-determinants and accumulation, and the text encoder's attention contractions run on the bf16
+    matrix pipe (`MultiHeadAttention.bf16_mma`).  bf16 has fp32's exponent range, so no loss scaling is needed:
     `scaler` may be None; a GradScaler that is passed in is driven exactly as the reference drives it."""
     from .dataset import DeviceBatches
 
@@ -135,6 +136,11 @@ def train_step(global_step: int, epoch: int, model, optimizer, config, train_loa
     before = getattr(decoder, "io_bf16", False)
     if fp16_run and decoder is not None and not before:
         decoder.io_bf16 = "all"
+    from .attentions import MultiHeadAttention
+    mha = [m for m in bare.modules() if isinstance(m, MultiHeadAttention)] if fp16_run else []
+    mha_before = [m.bf16_mma for m in mha]
+    for m in mha:
+        m.bf16_mma = True
     losses = []
     device = next(model.parameters()).device
     try:
@@ -144,6 +150,8 @@ def train_step(global_step: int, epoch: int, model, optimizer, config, train_loa
     finally:
         if decoder is not None:
             decoder.io_bf16 = before
+        for m, b in zip(mha, mha_before):
+            m.bf16_mma = b
     if losses and on_loss is not None:
         on_loss(epoch, float(torch.stack(losses).mean()), global_step)   # ONE sync per epoch
     return global_step

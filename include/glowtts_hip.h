@@ -340,6 +340,7 @@ typedef struct glowtts_enc_layer {
     float *dwp_all;
     long long dwp_floats;
     int n_conv, total_rows;
+    int attn_bf16;                                    /* 1: the attention contractions on the bf16 MFMA (glowtts_rel_attn_*_ex) */
 } glowtts_enc_layer;
 int glowtts_encoder_layer_fwd(const glowtts_enc_layer *L, const float *x, const float *mask, const unsigned char *drop_a,
                               const unsigned char *drop_o, const unsigned char *drop_h, const unsigned char *drop_2,
@@ -442,7 +443,11 @@ int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, cons
  * drop_scale, or NULL.  p_attn (B, H, T, T) receives softmax(P) BEFORE dropout (saved for the backward).
  * fwd : scores = (q_i.k_j + q_i.emb_k[j-i+w]) / sqrt(dk) ; out_i = sum_j Pd_ij v_j + sum_r Pd[i][i+r-w] emb_v[r]
  * bwd : dq, dk, dv (B, H*dk, T) written; demb_k / demb_v accumulated; ds (B, H, T, T) is scratch (scaled score grads).
- * Limits: T <= 256, dk % 16 == 0, dk <= 128, window <= 7. */
+ * Limits: T <= 256, dk % 16 == 0, dk <= 128, window <= 7.
+ * The `_ex` forms take bf16_mma: 0 = exactly the functions above (v_mfma_f32_16x16x4_f32); 1 = the contractions
+ * (q k^T, q emb_k^T, P v, P_w emb_v, and dP, dq, dk, dv in the backward) on v_mfma_f32_16x16x16_bf16 with fp32
+ * accumulation — operands are rounded to bf16 (nearest even) in registers as they leave LDS; q, k, v, p_attn, the
+ * softmax, the relative-embedding gradients and every tensor in HBM stay fp32 (BASELINE configs[2], with bf16 tensors). */
 int glowtts_rel_attn_fwd(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
                          const float *mask, const unsigned char *drop, float drop_scale, float *p_attn, float *out,
                          int B, int H, int T, int dk, int window, int heads_share, int block_len,
@@ -452,6 +457,15 @@ int glowtts_rel_attn_bwd(const float *dout, const float *q, const float *k, cons
                          const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
                          float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
                          glowtts_stream_t stream);
+int glowtts_rel_attn_fwd_ex(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                            const float *mask, const unsigned char *drop, float drop_scale, float *p_attn, float *out,
+                            int B, int H, int T, int dk, int window, int heads_share, int block_len, int bf16_mma,
+                            glowtts_stream_t stream);
+int glowtts_rel_attn_bwd_ex(const float *dout, const float *q, const float *k, const float *v, const float *emb_k,
+                            const float *emb_v, const float *mask, const unsigned char *drop, float drop_scale,
+                            const float *p_attn, float *ds, float *dq, float *dk_out, float *dv, float *demb_k,
+                            float *demb_v, int B, int H, int T, int dk, int window, int heads_share, int block_len,
+                            int bf16_mma, glowtts_stream_t stream);
 
 /* ---- channel LayerNorm with fused residual (csrc/norm.hip) -----------------------------------------------------
  * replaces LayerNorm.forward (layers.py:19-28) and the `x + y` before it (attentions.py:68,72):

@@ -284,3 +284,93 @@ def test_training_reduces_the_loss(G, mode):
     ref = test_training_reduces_the_loss.seen.get(False)
     if mode and ref is not None:                        # same weights, same batch, same dropout seeds: the curves stay close
         assert abs(losses[-1] - ref[-1]) < 0.2 * abs(ref[0] - ref[-1]) + 0.05, (mode, losses[-1], ref[-1])
+
+
+# ------------------------------------------------------------------------------------ attention on the bf16 matrix pipe
+# BASELINE configs[2]: "encoder MultiHeadAttention on MFMA".  With `bf16_mma` the kernel's contractions round their operands
+# to bf16 (unit round-off 2^-9 = 2e-3) and accumulate in fp32; softmax, p_attn and every tensor in HBM stay fp32.  Stated
+# tolerance against the committed golden vectors of the REFERENCE's attention (fp32): every result within 1e-2 of its
+# tensor's largest element (measured: y 2-3e-3, p_attn 2e-3, gradients 3-6e-3).
+MHA_MFMA_CASES = ["mha_c32_t70_w4", "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4",
+                  "mha_c192_t240_w4", "mha_c64_t256_w4"]
+
+
+@pytest.mark.parametrize("name", MHA_MFMA_CASES)
+def test_attention_bf16_mma_vs_reference_golden(name):
+    from glow_tts_train import attentions
+    from helpers import load_golden, split_prefix
+
+    g = load_golden(name)
+    win, blk = int(g["window"]), int(g["block"])
+    ch = g["x"].shape[1]
+    f = attentions.MultiHeadAttention(ch, ch, 2, window_size=None if win < 0 else win, p_dropout=0.0,
+                                      block_length=None if blk < 0 else blk)
+    f.load_state_dict(split_prefix(g, "sd."))
+    f = f.cuda()
+    f.bf16_mma = True
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]).cuda()
+    pair = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    assert f._kernel_applicable(x, x, pair)
+    y = f(x, x, pair)
+    (y * torch.from_numpy(g["r"]).cuda()).sum().backward()
+    errs = {"y": rel_err(y, g["y"]), "p_attn": rel_err(f.attn, g["p_attn"]), "dx": rel_err(x.grad, g["dx"])}
+    named = dict(f.named_parameters())
+    grads = {k: torch.as_tensor(np.asarray(w)) for k, w in split_prefix(g, "grad.").items()}
+    gmax = max(float(w.abs().max()) for w in grads.values())
+    for k, want in grads.items():
+        if float(want.abs().max()) > 1e-4 * gmax:          # (the key bias's gradient is mathematically zero: softmax shift)
+            errs["grad " + k] = rel_err(named[k].grad, want)
+    assert max(errs.values()) < 1e-2, errs
+    # and it is NOT the fp32 kernel: the same call without the flag differs from this one in the low bits
+    f.bf16_mma = False
+    y32 = f(x, x, pair)
+    assert rel_err(y32, g["y"]) < 1e-4
+    assert rel_err(y, y32) > 1e-6, "bf16_mma did not change the arithmetic"
+
+
+def test_encoder_layer_executor_honours_bf16_mma(G):
+    """The whole-layer executor (glowtts_encoder_layer_fwd/_bwd) passes the layer's `bf16_mma` to the attention kernels:
+    its results move by bf16 round-off (not zero, not more than 1e-2 of scale) against the fp32 executor."""
+    from glow_tts_train import attentions, convops, optimize
+
+    torch.manual_seed(5)
+    b, hch, fch, t, nl = 3, 192, 768, 160, 2
+    enc = attentions.Encoder(hch, fch, 2, nl, kernel_size=3, p_dropout=0.0, window_size=4).cuda().train()
+    groups = [convops.ConvGroup([a.conv_q, a.conv_k, a.conv_v, a.conv_o, f.conv_1, f.conv_2])
+              for a, f in zip(enc.attn_layers, enc.ffn_layers)]
+    opt = optimize.Adam(enc.parameters(), scheduler="noam", dim_model=hch)     # flat gradient buffers: in-place gradients
+    x = torch.randn(b, hch, t, device="cuda")
+    lens = torch.tensor([t, 120, 77], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
+    r = torch.randn(b, hch, t, device="cuda")
+    out, calls = {}, []
+    orig = convops.EncoderLayerFn.forward
+    convops.EncoderLayerFn.forward = staticmethod(lambda *a, _o=orig: (calls.append(1), _o(*a))[1])
+    try:
+        for flag in (False, True):
+            for m in enc.attn_layers:
+                m.bf16_mma = flag
+            opt.zero_grad()
+            for g in groups:
+                g.begin()
+            xi = x.clone().requires_grad_(True)
+            y = enc(xi, mask)
+            (y * r).sum().backward()
+            convops.flush_groups()
+            torch.cuda.synchronize()
+            out[flag] = [y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+    finally:
+        convops.EncoderLayerFn.forward = orig
+    assert len(calls) == 2 * nl, "the layer executor did not run"
+    gmax = max(float(e.abs().max()) for e in out[False][2:])
+    names = ["y", "dx"] + [k for k, _ in enc.named_parameters()]
+    errs = {n: rel_err(a, e) for n, a, e in zip(names, out[True], out[False])
+            if float(e.abs().max()) > 1e-4 * gmax and not n.endswith("conv_k.bias")}   # (d key bias == 0 mathematically)
+    # conv_1's gradient passes the ReLU gate: a pre-activation within round-off of zero flips its gate and moves one whole
+    # term of a ~180-term sum (0.3 such terms per weight element here), so it is checked by direction instead
+    bad = {n: v for n, v in errs.items() if v >= 1e-2 and "conv_1" not in n}
+    assert not bad and max(errs.values()) > 1e-6, bad or errs
+    for n, a, e in zip(names, out[True], out[False]):
+        if "conv_1" in n:
+            assert _cos(a, e) > 0.995, (n, _cos(a, e))
