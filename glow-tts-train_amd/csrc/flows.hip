@@ -355,7 +355,33 @@ __global__ __launch_bounds__(256) void actnorm_invconv_fwd_kernel(const void *__
 }
 
 // grid (G, slabs): every thread of a workgroup works on the same channel group, so the 2N per-channel sums and the N*N
-// matrix sums reduce inside the workgroup and leave as one atomic each.
+// matrix sums reduce inside the workgroup and leave as one atomic each.  A workgroup takes `nb` consecutive items of the
+// flattened (b, t/V) axis (every thread busy whatever T is); the host sizes nb for ~200 workgroups: the N*N matrix sums of
+// ALL workgroups land on one cache line, where float atomics retire one instruction at a time (~7.5 ns: 640 workgroups were
+// 5 us of a 17 us kernel), while fewer, longer workgroups stream worse (no atomics at all: 6.0 us with 1 040 workgroups,
+// 8.4 us with 140).
+//
+// The NS = 2N + N*N per-thread partial sums are reduced through LDS: every thread deposits its NS values as one column of
+// part[NS][256]; then a lane owns (value v, segment seg), adds its share of row v with 16-byte reads, and the segments meet
+// in log2(nseg) shuffles.  (Butterflies on every value — NS * 6 ds_bpermute per wave — were 3.5 us of the kernel.)
+template <int NVAL>
+__device__ __forceinline__ float row_sum_256(const float *part, int pitch, int row0, int lane, int &v_out, bool &owner) {
+    constexpr int NSEG = 64 / NVAL;                 // lanes per value; each adds 256 / NSEG elements
+    const int v = lane % NVAL, seg = lane / NVAL;
+    const float *row = part + (row0 + v) * pitch;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64 / NSEG; ++i) {
+        const float4 p = *reinterpret_cast<const float4 *>(row + 4 * (seg + NSEG * i));
+        s += (p.x + p.y) + (p.z + p.w);
+    }
+#pragma unroll
+    for (int off = NVAL; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+    v_out = v;
+    owner = seg == 0;
+    return s;
+}
+
 template <int N, int V, bool B16 = false>
 __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const void *__restrict__ x, const float *__restrict__ mask,
                                                                   const float *__restrict__ logs, const float *__restrict__ bias,
@@ -367,7 +393,6 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const void *__
     using IO = VecIO<V, B16>;
     const int TV = T / V;
     const int g = blockIdx.x;
-    const int b0 = blockIdx.y * nb, b1 = min(B, b0 + nb);
     float wr[N * N], e[N], bi[N];
 #pragma unroll
     for (int q = 0; q < N * N; ++q) wr[q] = w[q];
@@ -382,19 +407,34 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const void *__
     for (int q = 0; q < N * N; ++q) aw[q] = 0.f;
 #pragma unroll
     for (int k = 0; k < N; ++k) { al[k] = 0.f; ab[k] = 0.f; }
-    const int items = (b1 - b0) * TV;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int b = b0 + it / TV, tv = it % TV;
-        Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
-        Vec<V> xv[N], gz[N];
+    // two items in flight per thread: the loads of item i + 1 are issued before item i is worked on (with ~1 workgroup per
+    // CU a wave has nobody to hide its memory latency behind)
+    const int i0 = blockIdx.y * nb, i1 = min(B * TV, i0 + nb);
+    Vec<V> mv, xv[N], gz[N];
+    long off_cur[N];
+    auto fetch = [&](int it, Vec<V> &m_, Vec<V> *x_, Vec<V> *g_, long *off_) {
+        const int b = it / TV, tv = it - b * TV;
+        m_ = Vec<V>::load(mask + (long)b * T + (long)tv * V);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const long off = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
-            xv[k] = IO::load(x, off);
-            gz[k] = IO::load(dz, off);
+            off_[k] = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
+            x_[k] = IO::load(x, off_[k]);
+            g_[k] = IO::load(dz, off_[k]);
+        }
+    };
+    int it = i0 + threadIdx.x;
+    bool have = it < i1;
+    if (have) fetch(it, mv, xv, gz, off_cur);
+    while (have) {
+        const int nx = it + 256;
+        const bool have_nx = nx < i1;
+        Vec<V> mv2, xv2[N], gz2[N];
+        long off_nx[N];
+        if (have_nx) fetch(nx, mv2, xv2, gz2, off_nx);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
 #pragma unroll
             for (int j = 0; j < V; ++j) gz[k][j] *= mv[j];
-        }
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             Vec<V> o;
@@ -412,41 +452,50 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(const void *__
                 al[k] += dym * e[k] * xv[k][j];
                 ab[k] += dym;
             }
-            IO::store(dx, ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V, o);
+            IO::store(dx, off_cur[k], o);
         }
+        if (have_nx) {
+            mv = mv2;
+#pragma unroll
+            for (int k = 0; k < N; ++k) { xv[k] = xv2[k]; gz[k] = gz2[k]; off_cur[k] = off_nx[k]; }
+        }
+        it = nx;
+        have = have_nx;
     }
     // one LDS round for all 2N + N*N sums, then ONE atomic instruction per output cache line: same-line float atomics
-    // retire serially in L2 (~13 ns each), so a workgroup must not send them one by one
+    // retire serially in L2, so a workgroup must not send them one by one
     constexpr int NS = 2 * N + N * N;
-    __shared__ float part[4][NS + 1];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float t = 0.f;                                  // sum_b dlogdet[b] * x_len[b]: feeds dlogs (every channel) and dW
-    if (dlogdet != nullptr && wave == 0)
-        for (int b = lane; b < B; b += 64) t += dlogdet[b] * x_len[b];
-    t = wave_sum(t);
+    constexpr int RP = 260;                         // row pitch (floats): 16-byte aligned rows, 4 banks apart
+    __shared__ __attribute__((aligned(16))) float part[NS * RP + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const float sl = wave_sum(al[k]), sb = wave_sum(ab[k]);
-        if (lane == 0) { part[wave][k] = sl; part[wave][N + k] = sb; }
-    }
+    for (int k = 0; k < N; ++k) { part[k * RP + tid] = al[k]; part[(N + k) * RP + tid] = ab[k]; }
 #pragma unroll
-    for (int q = 0; q < N * N; ++q) {
-        const float sw = wave_sum(aw[q]);
-        if (lane == 0) part[wave][2 * N + q] = sw;
+    for (int q = 0; q < N * N; ++q) part[(2 * N + q) * RP + tid] = aw[q];
+    if (wave == 3) {                                // sum_b dlogdet[b] * x_len[b]: feeds dlogs (every channel) and dW
+        float t = 0.f;
+        if (dlogdet != nullptr)
+            for (int b = lane; b < B; b += 64) t += dlogdet[b] * x_len[b];
+        t = wave_sum(t);
+        if (lane == 0) part[NS * RP] = t;
     }
-    if (threadIdx.x == 0) part[0][NS] = t;
     __syncthreads();
-    if (threadIdx.x < NS) {
-        const int q = threadIdx.x;
-        float v = part[0][q] + part[1][q] + part[2][q] + part[3][q];
-        const float tt = part[0][NS];
-        if (q < N) {
-            if (blockIdx.y == 0) v += tt;
-            atomicAdd(dlogs + invconv_channel<N>(q, g, C), v);
-        } else if (q < 2 * N) {
-            atomicAdd(dbias + invconv_channel<N>(q - N, g, C), v);
-        } else {
-            const int r = q - 2 * N;
+    const float tt = part[NS * RP];
+    if (wave == 0) {                                // rows [0, 2N): dlogs, dbias
+        int q; bool owner;
+        float v = row_sum_256<2 * N>(part, RP, 0, lane, q, owner);
+        if (owner) {
+            if (q < N) {
+                if (blockIdx.y == 0) v += tt;
+                atomicAdd(dlogs + invconv_channel<N>(q, g, C), v);
+            } else {
+                atomicAdd(dbias + invconv_channel<N>(q - N, g, C), v);
+            }
+        }
+    } else if (wave == 1) {                         // rows [2N, 2N + N*N): dW, one instruction for the whole matrix
+        int r; bool owner;
+        float v = row_sum_256<N * N>(part, RP, 2 * N, lane, r, owner);
+        if (owner) {
             if (g == 0 && blockIdx.y == 0 && dlogdet != nullptr) v += w_inv[(r % N) * N + r / N] * (float)(C / N) * tt;
             atomicAdd(dw + r, v);
         }
@@ -786,11 +835,13 @@ extern "C" int glowtts_actnorm_invconv_bwd_io(const void *x, const float *mask, 
     hipStream_t s = (hipStream_t)stream;
     const bool v4 = can_vec4(T, {x, mask, dz, dx});
     const int G = C / n_split;
-    int slabs = (640 + G - 1) / G;
-    if (slabs > B) slabs = B;
+    const long items = (long)B * (v4 ? T / 4 : T);                       // per channel group
+    long slabs = (200 + G - 1) / G;     // ~200 workgroups (see the kernel's comment; 80 / 120 / 160 / 200 / 288 / 400 / 520 at
+                                        // B=32, C=160, T=400: 10.9 / 9.5 / 9.1 / 8.9 / 9.6 / 10.6 / 11.7 us)
+    if (slabs > (items + 255) / 256) slabs = (items + 255) / 256;
     if (slabs < 1) slabs = 1;
-    const int nb = (B + slabs - 1) / slabs;
-    dim3 grid(G, (B + nb - 1) / nb);
+    const int nb = (int)((items + slabs - 1) / slabs);
+    dim3 grid(G, (unsigned)((items + nb - 1) / nb));
     FUSED_DISPATCH(actnorm_invconv_bwd_kernel, grid, x, mask, logs, bias, w, w_inv, dz, dlogdet, x_len, dx, dlogs, dbias, dw, B, C, T, nb);
     GLOWTTS_LAUNCH_CHECK("glowtts_actnorm_invconv_bwd");
 }

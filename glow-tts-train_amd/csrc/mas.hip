@@ -27,18 +27,20 @@ constexpr float kMasNeg = -1e9f;
 
 #ifdef GLOWTTS_TRACE   // tuning builds only: phase timestamps per utterance (100 MHz wall clock)
 __device__ unsigned long long g_mas_trace[1024 * 8];
-#define MAS_TRACE(i) do { if (threadIdx.x == 0) g_mas_trace[(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); } while (0)
+#define MAS_TRACE(i) do { if (threadIdx.x == 0) { g_mas_trace[(blockIdx.x & 1023) * 8 + (i)] = wall_clock64(); if ((i) < 2) g_mas_trace[(blockIdx.x & 1023) * 8 + 5 + (i)] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define MAS_TRACE(i) do { } while (0)
 #endif
 
 // v_mov_b32_dpp wave_shr:1 (control 0x138): lane i receives lane i-1's value, lane 0 keeps the `old` operand.
 
-template <int R>
+template <int R, bool GD>
 __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ value, float *__restrict__ path,
                                                   const int *__restrict__ t_xs, const int *__restrict__ t_ys,
-                                                  int Tx, int Ty, int log2tc, int nblk32, int gdirs,
+                                                  int Tx, int Ty, int log2tc, int nblk32,
                                                   int *__restrict__ first_out, int *__restrict__ tok_out) {
+    constexpr bool gdirs = GD;      // (a template parameter: one pointer that may be LDS or global turns every access into a
+                                    //  flat instruction, and those make each s_waitcnt in the DP loop wait for everything)
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ROWPAD = R * 64 + 1;
     const int TC = 1 << log2tc;
@@ -117,7 +119,11 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
             }
         }
     };
+#ifdef EXP_NOSTAGE
+    auto stage_any = [&](int k) { if (k < 0) stage(k); };
+#else
     auto stage_any = [&](int k) { if (vec_ok) stage4(k); else stage(k); };
+#endif
 
     MAS_TRACE(0);
     if (wave != 0 && ntiles > 0) stage_any(0);
@@ -140,38 +146,101 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
             // Only in-band cells are ever read back: an in-band (x, y) takes v[x][y-1] and v[x-1][y-1], both in band (or the
             // x == y / x == 0 sentinels), and the backtrack never leaves the band.  So rows outside the band may carry
             // garbage values and bits, and the loop needs no band test at all — 8 vector instructions per row and column.
-            float cnext[R];                              // next column's cells, fetched one column ahead of their use
-#pragma unroll
-            for (int r = 0; r < R; ++r) cnext[r] = tbase[r * 64 + lane];
+            // Four columns per half-trip, two register buffers: while one buffer's columns are worked on, the other is being
+            // filled from LDS (an LDS read is ~130 cycles and wave 0 has nobody to hide behind — one column of look-ahead
+            // left the wave waiting every column: 300 cycles per column, 117 us at Ty = 800).
+            // Per cell 6 vector instructions: diagonal compare + select, compare, select, add, and ONE add-with-carry that
+            // shifts the new direction bit into the row's word (newest column in bit 0; normalised by a shift + bit reverse
+            // when the word is stored every 32 columns).
+            constexpr int U = 4;
+            float bufa[U][R], bufb[U][R];
             const float *trow = tbase + lane;
-            for (int yl = 0; yl < ncols; ++yl) {
-                const int y = y0 + yl;
-                float cell[R];
+            auto fill = [&](float (&buf)[U][R], int yl) {          // columns yl .. yl + U - 1 of the tile
+                if (yl < TC) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) cell[r] = cnext[r];
-                if (yl + 1 < TC) trow += ROWPAD;
+                    for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int r = 0; r < R; ++r) cnext[r] = trow[r * 64];
+                        for (int r = 0; r < R; ++r) buf[u][r] = trow[(yl + u) * ROWPAD + r * 64];
+                }
+            };
+            // Scheduling (one wave, nobody to hide behind): nothing on the column-to-column chain goes through a scalar
+            // register written in the same column — the diagonal masks of a half-trip are computed ahead, the running value is
+            // select(diag) -> v_max -> add, and the `vprev > vcur` compare feeds only the add-with-carry that shifts the
+            // direction bit into the row's word.  (max(a, b) is the reference's `a > b ? a : b` for everything but the sign of a
+            // zero, which no later compare or sum can tell apart.)  The forced step on the diagonal (core.pyx:34, index == y)
+            // is OR-ed into a word when it is stored, not per cell.  The R rows of a lane are independent within a column:
+            // their instructions are issued stage by stage, not row by row; a half-trip that lies inside the utterance runs
+            // without per-column branches.
+            auto flush = [&](int y) {                             // after column y: store the rows' words of its 32-column block
+                const int sh = 31 - (y & 31), blk = y >> 5;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    uint32_t w = __brev(dw[r] << sh);             // column 32 blk + j of the word in bit j
+                    const int x = lane * R + r;
+                    if ((x >> 5) == blk) w |= 1u << (x & 31);     // x == y: the path must step (bits past y are never read)
+                    if (gdirs) gd[(r * nblk32 + blk) * 64 + lane] = w;
+                    else dirs[(r * nblk32 + blk) * 64 + lane] = w;
+                    dw[r] = 0u;
+                }
+            };
+            auto column = [&](const float (&cells)[R], unsigned long long (&dg)[R], int y) {
                 // v[x-1] of this lane's first row: ONE DPP; lane 0 (x = 0) receives the sentinel of core.pyx:24-27
                 const float edge = (y == 0) ? 0.0f : kMasNeg;
-                const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v[R - 1]),
-                                                                            0x138, 0xf, 0xf, false));
+                float vp[R], vc[R], best[R];
+                vp[0] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v[R - 1]),
+                                                                   0x138, 0xf, 0xf, false));
 #pragma unroll
-                for (int r = R - 1; r >= 0; --r) {
-                    const int x = lane * R + r;
-                    const float vprev = (r == 0) ? up : v[r > 0 ? r - 1 : 0];
-                    const float vcur = (x == y) ? kMasNeg : v[r];
-                    const bool take_prev = vprev > vcur;
-                    v[r] = (take_prev ? vprev : vcur) + cell[r];
-                    dw[r] |= ((x == y) || take_prev ? 1u : 0u) << (y & 31);
+                for (int r = 1; r < R; ++r) vp[r] = v[r - 1];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vc[r]) : "v"(v[r]), "v"(kMasNeg), "s"(dg[r]));
+                unsigned long long take[R];                       // (each compare well ahead of the add-with-carry that reads its mask)
+#pragma unroll
+                for (int r = 0; r < R; ++r) take[r] = __builtin_amdgcn_fcmpf(vp[r], vc[r], 2);      // vprev > vcur
+#pragma unroll
+                for (int r = 0; r < R; ++r) asm volatile("v_max_f32 %0, %1, %2" : "=v"(best[r]) : "v"(vp[r]), "v"(vc[r]));
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = best[r] + cells[r];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    unsigned long long carry_out;
+                    asm volatile("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(dw[r]), "=s"(carry_out) : "v"(dw[r]), "s"(take[r]));
                 }
-                if ((y & 31) == 31 || y == ty - 1) {
+            };
+            auto work = [&](const float (&buf)[U][R], int yl) {
+                unsigned long long dg[U][R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (gdirs) gd[(r * nblk32 + (y >> 5)) * 64 + lane] = dw[r];
-                        else dirs[(r * nblk32 + (y >> 5)) * 64 + lane] = dw[r];
-                        dw[r] = 0u;
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        dg[u][r] = __builtin_amdgcn_uicmp((unsigned)(lane * R + r), (unsigned)(y0 + yl + u), 32);   // x == y
+                const int ya = y0 + yl;
+                if (ya + U <= ty) {                               // the whole half-trip is inside the utterance
+#pragma unroll
+                    for (int u = 0; u < U; ++u) column(buf[u], dg[u], ya + u);
+                    const int y = ya + U - 1;                     // (ya is a multiple of 4: only the last column can end a block)
+                    if ((y & 31) == 31 || y == ty - 1) flush(y);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int y = ya + u;
+                        if (y < ty) {
+                            column(buf[u], dg[u], y);
+                            if ((y & 31) == 31 || y == ty - 1) flush(y);
+                        }
                     }
+                }
+            };
+            fill(bufa, 0);
+#ifdef EXP_NODP
+            if (ntiles < 0)
+#endif
+            for (int yl = 0; yl < ncols; yl += 2 * U) {
+                fill(bufb, yl + U);
+                work(bufa, yl);
+                if (yl + U < ncols) {
+                    fill(bufa, yl + 2 * U);
+                    work(bufb, yl + U);
                 }
             }
         }
@@ -186,12 +255,18 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     // word of the row below is fetched while the current row is walked.
     for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = x >= tx ? ty : 0;
     __syncthreads();
-    if (threadIdx.x == 0 && tx > 0 && ty > 0) {
+    // The walk runs on wave 0 with its state in SCALAR registers (a lone wave issues a vector instruction every ~10 cycles,
+    // a scalar one every cycle or two): all 64 lanes read the same word (an LDS broadcast), v_readfirstlane hands it to the
+    // scalar unit, and mask / clz / compare / address arithmetic are SALU work.
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && tx > 0 && ty > 0) {
         auto word_of = [&](int row, int blk) -> uint32_t {
             if (row <= 0) return 0u;
             const int at = ((row % R) * nblk32 + blk) * 64 + row / R;
-            return gdirs ? *reinterpret_cast<volatile uint32_t *>(gd + at) : dirs[at];
+            const uint32_t w = gdirs ? *reinterpret_cast<volatile uint32_t *>(gd + at) : dirs[at];
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         };
+        // (fetching two rows ahead so that the LDS latency passes under two steps was measured SLOWER, 39 us against 30: the
+        //  extra address arithmetic costs more vector issue slots than the latency it hides)
         int index = tx - 1, y = ty - 1, blk = y >> 5;
         uint32_t word = word_of(index, blk), below = word_of(index - 1, blk);
         while (index > 0 && y > 0) {
@@ -206,7 +281,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
                 continue;
             }
             y = (blk << 5) + (31 - __clz(m));             // frame at which the path leaves row `index` downwards
-            first[index] = y;
+            first[index] = y;                             // (every lane stores the same value)
             --index;
             --y;
             word = below;
@@ -282,10 +357,17 @@ static int launch_mas(const float *value, float *path, const int32_t *t_x, const
     const size_t bytes = fixed + tile_b(log2tc);
     GLOWTTS_CHECK_ARG(bytes <= 160 * 1024, "glowtts_mas_path: lattice %dx%d needs %zu B of LDS (> 160 KiB)", Tx, Ty,
                       bytes);
-    static LdsLimit limit;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = limit.ensure(reinterpret_cast<const void *>(&mas_kernel<R>), bytes, "glowtts_mas_path")) return rc_;
-    hipLaunchKernelGGL(mas_kernel<R>, dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
-                       nblk32, gdirs, first_out, tok_out);
+    if (gdirs) {
+        static LdsLimit limit_g;
+        if (int rc_ = limit_g.ensure(reinterpret_cast<const void *>(&mas_kernel<R, true>), bytes, "glowtts_mas_path")) return rc_;
+        hipLaunchKernelGGL((mas_kernel<R, true>), dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
+                           nblk32, first_out, tok_out);
+    } else {
+        static LdsLimit limit;   // per device: raised only when a launch needs more than any earlier one
+        if (int rc_ = limit.ensure(reinterpret_cast<const void *>(&mas_kernel<R, false>), bytes, "glowtts_mas_path")) return rc_;
+        hipLaunchKernelGGL((mas_kernel<R, false>), dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, log2tc,
+                           nblk32, first_out, tok_out);
+    }
     GLOWTTS_LAUNCH_CHECK("glowtts_mas_path");
 }
 

@@ -58,7 +58,7 @@ template <int V>
 __global__ __launch_bounds__(256) void mle_fwd_kernel(const float *__restrict__ z, const float *__restrict__ m,
                                                       const float *__restrict__ logs, const float *__restrict__ mask,
                                                       float *__restrict__ acc, long nv, long nmask) {
-    __shared__ float red[4];
+    __shared__ float red[4], red2[4];
     float s = 0.f;
     const long stride = (long)gridDim.x * 256;
     for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 2 * stride) {
@@ -81,13 +81,18 @@ __global__ __launch_bounds__(256) void mle_fwd_kernel(const float *__restrict__ 
             }
         }
     }
-    s = block_sum_256(s, red);
-    if (threadIdx.x == 0) atomicAdd(acc, s);
-    if (blockIdx.x == 0) {
-        float t = 0.f;
-        for (long i = threadIdx.x; i < nmask; i += 256) t += mask[i];
-        t = block_sum_256(t, red);
-        if (threadIdx.x == 0) atomicAdd(acc + 1, t);
+    // sum(mask) rides along: every workgroup adds its grid-stride share (one workgroup walking all B*T' mask values was
+    // 40 of this kernel's 49 us), and both sums leave in ONE atomic instruction (lanes 0 and 1, adjacent addresses)
+    float t = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nmask; i += stride) t += mask[i];
+    s = wave_sum(s);
+    t = wave_sum(t);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave] = s; red2[wave] = t; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float *r = threadIdx.x == 0 ? red : red2;
+        atomicAdd(acc + threadIdx.x, (r[0] + r[1]) + (r[2] + r[3]));
     }
 }
 

@@ -37,6 +37,22 @@ v_st = torch.randn(H, C // 2, 1, device=dev) * 0.1
 wf_st, wb_st, _ = convops.pack_weight(v_st, None)
 h = torch.empty(B, H, T, device=dev)
 
+# MB_MATH=bf16x6+wrw (the package default) runs the bf16-plane kernels: planes of every packed weight, all bound at once
+from glow_tts_train import _hip  # noqa: E402
+_math = os.environ.get("MB_MATH", "bf16x6+wrw")
+if _math != "fp32":
+    _hip.conv_math(_math)
+    _all = [wf_in, wb_in, wf_rs, wb_rs, wf_st, wb_st]
+    _flat = torch.cat([w.reshape(-1) for w in _all])
+    _views, _o = [], 0
+    for w in _all:
+        _views.append(_flat[_o: _o + w.numel()])
+        _o += w.numel()
+    wf_in, wb_in, wf_rs, wb_rs, wf_st, wb_st = (v.view_as(w) for v, w in zip(_views, _all))
+    _planes = torch.empty(3 * _flat.numel(), device=dev, dtype=torch.int16)
+    call("glowtts_conv_split_weights", ptr(_flat), _flat.numel(), ptr(_planes))
+    _hip.conv_bind_planes(_flat, _planes)
+
 
 def gate():
     call("glowtts_conv_gate_fwd", ptr(x), ptr(wf_in), ptr(b_in), None, None, 1.0, ptr(acts), ptr(ts), B, H, T, 5, 1, 2)

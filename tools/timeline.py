@@ -1,57 +1,58 @@
 #!/usr/bin/env python3
-"""Timeline summary of the last training step in a rocprofv3 (rocpd sqlite) kernel trace of bench.py: per-queue busy time,
-time with >= 1 kernel running, idle gaps, and the kernels that run while nothing else does (the critical path's makeup).
-Usage: python tools/timeline.py <results.db> [top]"""
-import collections
-import sqlite3
+"""Timeline of ONE training step from a rocprofv3 kernel trace (…_kernel_trace.csv): per-queue busy time, the union of busy
+intervals, and the idle gaps of the whole device with the kernels either side.  Steps are delimited by the optimizer kernel.
+Usage: python tools/timeline.py kernel_trace.csv [step_index_from_end=1] [min_gap_us=15]"""
+import csv
+import re
 import sys
+from collections import defaultdict
 
-db = sys.argv[1]
-top = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-c = sqlite3.connect(db)
-rows = c.execute("select name, start, end, queue_id from kernels order by start").fetchall()
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
-step = rows[adam[-2] + 1: adam[-1] + 1]
-t0, t1 = step[0][1], max(r[2] for r in step)
-print(f"last step: {len(step)} launches, wall {(t1 - t0) / 1e6:.3f} ms")
-per_q = collections.defaultdict(int)
-for n, s, e, q in step:
-    per_q[q] += e - s
-for q, v in per_q.items():
-    print(f"  queue {q}: busy {v / 1e6:.3f} ms, {sum(1 for r in step if r[3] == q)} launches")
-for q in per_q:
-    agg = collections.defaultdict(lambda: [0, 0])
-    for n, s_, e, qq in step:
-        if qq == q:
-            agg[n[:100]][0] += 1
-            agg[n[:100]][1] += e - s_
-    print(f"queue {q}: kernels by total time")
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
-        print(f"  {v[1] / 1e6:7.3f} ms  n={v[0]:4d}  avg {v[1] / v[0] / 1e3:7.1f} us  {k}")
-# sweep: coverage and exclusive time per kernel
-events = []
-for i, (n, s, e, q) in enumerate(step):
-    events.append((s, 1, i))
-    events.append((e, -1, i))
-events.sort()
-active = set()
-last = t0
-covered = 0
-excl = collections.defaultdict(int)       # time during which exactly one kernel runs, by kernel name
-shared = 0
-for t, kind, i in events:
-    if active:
-        covered += t - last
-        if len(active) == 1:
-            excl[step[next(iter(active))][0][:100]] += t - last
-        else:
-            shared += t - last
-    last = t
-    if kind == 1:
-        active.add(i)
-    else:
-        active.discard(i)
-print(f"  >=1 kernel running {covered / 1e6:.3f} ms, idle {(t1 - t0 - covered) / 1e6:.3f} ms, >=2 kernels running {shared / 1e6:.3f} ms")
-print("time with exactly ONE kernel running, by kernel:")
-for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:top]:
-    print(f"  {v / 1e6:7.3f} ms  {k}")
+rows = list(csv.DictReader(open(sys.argv[1])))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+min_gap = float(sys.argv[3]) if len(sys.argv) > 3 else 15.0
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows))
+marks = [e for e in ev if "adam_kernel" in e[3]]
+assert len(marks) > back, "not enough steps in the trace"
+t0, t1 = marks[-back - 1][1], marks[-back][1]
+step = [e for e in ev if t0 <= e[0] < t1]
+print(f"step of {(t1 - t0) / 1e3:.1f} us, {len(step)} kernels")
+
+
+def short(n):
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"glowtts::", "", n)
+    return n[:70]
+
+
+byq = defaultdict(list)
+for s, e, q, n in step:
+    byq[q].append((s, e, n))
+for q, v in sorted(byq.items()):
+    busy = sum(e - s for s, e, _ in v)
+    print(f"  queue {q}: {len(v):4d} kernels, busy {busy / 1e3:8.1f} us, from +{(v[0][0] - t0) / 1e3:8.1f} to +{(v[-1][1] - t0) / 1e3:8.1f}")
+# union + gaps
+cur_end, union, gaps, last_name = t0, 0, [], "(previous step's optimizer)"
+for s, e, q, n in step:
+    if s > cur_end:
+        gaps.append((s - cur_end, cur_end - t0, last_name, n))
+        union += e - s
+        cur_end, last_name = e, n
+    elif e > cur_end:
+        union += e - cur_end
+        cur_end, last_name = e, n
+print(f"  device busy (union) {union / 1e3:.1f} us, idle {(t1 - t0 - union) / 1e3:.1f} us in {len(gaps)} gaps")
+for g, at, a, b in sorted(gaps, reverse=True)[:25]:
+    if g / 1e3 >= min_gap:
+        print(f"    gap {g / 1e3:7.1f} us at +{at / 1e3:8.1f}: after {short(a)}  -> before {short(b)}")
+small = sum(g for g, *_ in gaps if g / 1e3 < min_gap)
+print(f"  gaps < {min_gap:.0f} us: {sum(1 for g, *_ in gaps if g / 1e3 < min_gap)} totalling {small / 1e3:.1f} us")
+# concurrency profile: time with exactly k queues busy
+pts = []
+for s, e, q, n in step:
+    pts += [(s, 1), (e, -1)]
+pts.sort()
+depth, last, hist = 0, t0, defaultdict(int)
+for t, d in pts:
+    hist[depth] += t - last
+    depth, last = depth + d, t
+print("  time by number of kernels in flight: " + ", ".join(f"{k}: {v / 1e3:.0f} us" for k, v in sorted(hist.items())))

@@ -28,3 +28,6 @@ t0 = tr[:, 0].min()
 names = ["start", "dp done (wave 0)", "all waves past dp", "backtrack done", "path written"]
 for i, n in enumerate(names):
     print(f"{n:22s} median {np.median((tr[:, i] - t0) / 100.0):7.1f} us   max {((tr[:, i] - t0) / 100.0).max():7.1f}")
+cyc = (tr[:, 6] - tr[:, 5]).astype(float)
+wall = (tr[:, 1] - tr[:, 0]) / 100.0
+print(f"shader clock over the DP phase: median {np.median(cyc / wall):.0f} cycles/us; {np.median(cyc) / Ty:.0f} cycles per column")
