@@ -9,7 +9,8 @@
 // in the native kernel.  Six bf16 MFMAs per 32-deep step cost 96 cycles where the fp32 path needs 256.
 //   NS = 3 ("bf16x6"): fp32-equivalent (measured: same error against an fp64 reference as the native kernel);
 //   NS = 2 ("bf16x3"): hh + hl + lh, products good to 2^-16;      NS = 1: plain bf16 operands (config 3's arithmetic).
-// Opt-in (glowtts_conv_math); the native fp32 kernels stay the default and the reference for parity.
+// Selected with glowtts_conv_math (the Python host's default is NS = 3 for forward-type and weight-gradient kernels alike;
+// the library itself starts in native fp32, which stays the reference for parity).
 //
 // Data flow (differences from convgemm_wd_kernel, whose tiling, staging map, ring and epilogues are kept):
 //   weights   : the packed fp32 buffer [tap][g][M][16] is split ONCE per step by split_weights_kernel into bf16 planes

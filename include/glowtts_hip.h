@@ -197,8 +197,9 @@ int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const
 int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
                         int taps, glowtts_stream_t stream);
 
-/* Opt-in arithmetic for the WN convolutions (convgemm_split.hip): fp32 operands split into bf16 planes, products on the
- * bf16 matrix pipe, fp32 accumulation.  mode 0 = native fp32 MFMA (default, the parity reference), 1 = bf16 operands,
+/* Arithmetic of the WN convolutions (convgemm_split.hip): fp32 operands split into bf16 planes, products on the
+ * bf16 matrix pipe, fp32 accumulation.  mode 0 = native fp32 MFMA (the LIBRARY's initial mode; the Python host selects
+ * 3 + 4 * 3, "bf16x6+wrw", at import — convops.DEFAULT_CONV_MATH), 1 = bf16 operands,
  * 2 = bf16x3 (products good to 2^-16), 3 = bf16x6 (fp32-equivalent: dropped terms <= 2^-24 |x w|); the weight-gradient
  * kernel has its own code in bits 2-3 (mode = forward_code + 4 * wrw_code).  A negative mode only returns the current one.
  *   glowtts_conv_split_weights: planes[pl * n + i] = plane pl of wp[i] (caller-owned, 3 * n uint16; call after every
