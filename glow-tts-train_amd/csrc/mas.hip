@@ -119,11 +119,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
             }
         }
     };
-#ifdef EXP_NOSTAGE
-    auto stage_any = [&](int k) { if (k < 0) stage(k); };
-#else
     auto stage_any = [&](int k) { if (vec_ok) stage4(k); else stage(k); };
-#endif
 
     MAS_TRACE(0);
     if (wave != 0 && ntiles > 0) stage_any(0);
@@ -232,9 +228,6 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
                 }
             };
             fill(bufa, 0);
-#ifdef EXP_NODP
-            if (ntiles < 0)
-#endif
             for (int yl = 0; yl < ncols; yl += 2 * U) {
                 fill(bufb, yl + U);
                 work(bufa, yl);

@@ -100,8 +100,12 @@ template <int V>
 __global__ __launch_bounds__(256) void mle_bwd_kernel(const float *__restrict__ z, const float *__restrict__ m,
                                                       const float *__restrict__ logs, const float *__restrict__ scale,
                                                       float *__restrict__ dz, float *__restrict__ dm,
-                                                      float *__restrict__ dlogs, long nv) {
-    const float sc = scale[0];
+                                                      float *__restrict__ dlogs, long nv,
+                                                      const float *__restrict__ denom = nullptr,
+                                                      float *__restrict__ dlogdet = nullptr, int B = 0) {
+    const float sc = denom ? scale[0] / denom[0] : scale[0];
+    if (dlogdet != nullptr && blockIdx.x == 0)
+        for (int b = threadIdx.x; b < B; b += 256) dlogdet[b] = -sc;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         Vec<V> zv = Vec<V>::load(z + i * V);
         Vec<V> mv = Vec<V>::load(m + i * V);
@@ -123,6 +127,61 @@ __global__ __launch_bounds__(256) void mle_bwd_kernel(const float *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------------------
 // clip + Adam/Noam on flat buffers
+// The scalar tails of the losses as kernels of their own (each was 5-8 one-element torch launches on the critical path
+// between the decoder's forward and its backward).
+//   mle_finish : out[0] = (acc[0] - sum_b logdet[b]) / (acc[1] * C) + 0.5 log(2 pi) ; out[1] = acc[1] * C     (utils.py:17-22)
+//   dur_fwd    : out[0] = sum (logw - logw_)^2 / sum_b lengths[b] ; out[1] = sum_b lengths[b]                  (utils.py:26-28)
+//   dur_bwd    : dlogw = 2 (logw - logw_) dloss / out[1]
+//   span_logw  : logw_[b][x] = log(1e-8 + first[b][x+1] - first[b][x]) for x < t_x[b], else 0                 (models.py:392)
+__global__ __launch_bounds__(256) void mle_finish_kernel(const float *__restrict__ acc, const float *__restrict__ logdet, int B,
+                                                         int C, float *__restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) s += logdet[b];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+        const float denom = acc[1] * (float)C;
+        out[0] = (acc[0] - s) / denom + 0.91893853320467274178f;
+        out[1] = denom;
+    }
+}
+
+__global__ __launch_bounds__(256) void dur_fwd_kernel(const float *__restrict__ logw, const float *__restrict__ logw_,
+                                                      const long long *__restrict__ lengths, int B, long n,
+                                                      float *__restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f, l = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float d = logw[i] - logw_[i];
+        s += d * d;
+    }
+    for (int b = threadIdx.x; b < B; b += 256) l += (float)lengths[b];
+    s = block_sum_256(s, red);
+    __syncthreads();
+    l = block_sum_256(l, red);
+    if (threadIdx.x == 0) {
+        out[0] = s / l;
+        out[1] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void dur_bwd_kernel(const float *__restrict__ logw, const float *__restrict__ logw_,
+                                                      const float *__restrict__ dloss, const float *__restrict__ denom,
+                                                      float *__restrict__ dlogw, long n) {
+    const float sc = 2.0f * dloss[0] / denom[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dlogw[i] = sc * (logw[i] - logw_[i]);
+}
+
+__global__ __launch_bounds__(256) void span_logw_kernel(const int *__restrict__ first, const int *__restrict__ t_x, int B, int Tx,
+                                                        float *__restrict__ out) {
+    const long n = (long)B * Tx;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / Tx), x = (int)(i - (long)b * Tx);
+        const int *f = first + (long)b * (Tx + 1);
+        out[i] = x < t_x[b] ? logf(1e-8f + (float)(f[x + 1] - f[x])) : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Reducing kernels end in one same-address atomic per workgroup, and those retire serially in L2 (~13 ns each): they
 // run on a small grid (reduce_grid) and get their memory-level parallelism from 4 independent vector loads per thread.
@@ -275,6 +334,54 @@ extern "C" int glowtts_mle_bwd(const float *z, const float *m, const float *logs
     else
         hipLaunchKernelGGL((mle_bwd_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, z, m, logs, scale, dz, dm, dlogs, (long)n);
     GLOWTTS_LAUNCH_CHECK("glowtts_mle_bwd");
+}
+
+extern "C" int glowtts_mle_loss_fwd(const float *z, const float *m, const float *logs, const float *mask, const float *logdet,
+                                    float *acc, float *out, int B, int C, int T, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(logdet && out, "glowtts_mle_loss_fwd: null pointer");
+    if (int rc = glowtts_mle_fwd(z, m, logs, mask, acc, B, C, T, stream)) return rc;
+    if ((long)B * C * T == 0) return 0;
+    hipLaunchKernelGGL(mle_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc, logdet, B, C, out);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mle_loss_fwd");
+}
+
+extern "C" int glowtts_mle_loss_bwd(const float *z, const float *m, const float *logs, const float *dloss, const float *denom,
+                                    float *dz, float *dm, float *dlogs, float *dlogdet, int B, int64_t n,
+                                    glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(z && m && logs && dloss && denom && dz && dm && dlogs && dlogdet, "glowtts_mle_loss_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 0 && B >= 0, "glowtts_mle_loss_bwd: negative size");
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((n & 3) == 0 && aligned16(z) && aligned16(m) && aligned16(logs) && aligned16(dz) && aligned16(dm) && aligned16(dlogs))
+        hipLaunchKernelGGL((mle_bwd_kernel<4>), dim3(stream_grid(n / 4)), dim3(256), 0, s, z, m, logs, dloss, dz, dm, dlogs, (long)(n / 4), denom, dlogdet, B);
+    else
+        hipLaunchKernelGGL((mle_bwd_kernel<1>), dim3(stream_grid(n)), dim3(256), 0, s, z, m, logs, dloss, dz, dm, dlogs, (long)n, denom, dlogdet, B);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mle_loss_bwd");
+}
+
+extern "C" int glowtts_duration_loss_fwd(const float *logw, const float *logw_, const long long *lengths, float *out, int B,
+                                         int64_t n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(logw && logw_ && lengths && out, "glowtts_duration_loss_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && n >= 0, "glowtts_duration_loss_fwd: negative size");
+    hipLaunchKernelGGL(dur_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logw, logw_, lengths, B, (long)n, out);
+    GLOWTTS_LAUNCH_CHECK("glowtts_duration_loss_fwd");
+}
+
+extern "C" int glowtts_duration_loss_bwd(const float *logw, const float *logw_, const float *dloss, const float *denom,
+                                         float *dlogw, int64_t n, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(logw && logw_ && dloss && denom && dlogw, "glowtts_duration_loss_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n >= 0, "glowtts_duration_loss_bwd: negative size");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dur_bwd_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, logw, logw_, dloss, denom, dlogw, (long)n);
+    GLOWTTS_LAUNCH_CHECK("glowtts_duration_loss_bwd");
+}
+
+extern "C" int glowtts_span_logw(const int32_t *first, const int32_t *t_x, float *logw_, int B, int Tx, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(first && t_x && logw_, "glowtts_span_logw: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && Tx >= 0, "glowtts_span_logw: negative size");
+    if ((long)B * Tx == 0) return 0;
+    hipLaunchKernelGGL(span_logw_kernel, dim3(stream_grid((long)B * Tx)), dim3(256), 0, (hipStream_t)stream, first, t_x, B, Tx, logw_);
+    GLOWTTS_LAUNCH_CHECK("glowtts_span_logw");
 }
 
 extern "C" int glowtts_clip_grad_value(float *g, int64_t n, float clip, float *sumsq, glowtts_stream_t stream) {

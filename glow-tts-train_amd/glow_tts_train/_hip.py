@@ -69,6 +69,11 @@ _SIGNATURES = {
     "glowtts_unsqueeze": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_mle_fwd": [_P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_mle_bwd": [_P, _P, _P, _P, _P, _P, _P, _L],
+    "glowtts_mle_loss_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_mle_loss_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L],
+    "glowtts_duration_loss_fwd": [_P, _P, _P, _P, _I, _L],
+    "glowtts_duration_loss_bwd": [_P, _P, _P, _P, _P, _L],
+    "glowtts_span_logw": [_P, _P, _P, _I, _I],
     "glowtts_clip_grad_value": [_P, _L, _F, _P],
     "glowtts_adam_noam": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F],
     "glowtts_adam_advance": [_P, _F, _F, _F],

@@ -330,8 +330,7 @@ class FlowGenerator(nn.Module):
             attn = path.unsqueeze(1)
             z_m = _align_expand_apply(x_m, tok, first)
             z_logs = torch.zeros_like(z_m) if mean_only else _align_expand_apply(x_logs, tok, first)
-            counts = (first[:, 1:] - first[:, :-1]).to(x_mask.dtype).unsqueeze(1)          # = sum(attn, -1)
-            logw_ = torch.log(1e-8 + counts) * x_mask
+            logw_ = ops.span_logw(first, x_lengths).to(x_mask.dtype)    # = log(1e-8 + sum(attn, -1)) * x_mask
             return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
         attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
         with torch.no_grad():

@@ -358,28 +358,61 @@ _HALF_LOG_2PI = 0.5 * math.log(2 * math.pi)
 
 
 class MleLossFn(Function):
-    """utils.py:14-23 as one streaming reduction (+ a handful of scalar ops) instead of ~10 full-tensor passes."""
+    """utils.py:14-23 as one streaming reduction and a one-workgroup finish (no one-element torch launches)."""
 
     @staticmethod
     def forward(ctx, z, m, logs, logdet, m2):
         z, m, logs = f32(_c(z)), f32(_c(m)), f32(_c(logs))
         B, C, T = z.shape
         acc = _hip.scratch_zeros((2,), z.device)
-        call("glowtts_mle_fwd", ptr(z), ptr(m), ptr(logs), ptr(m2), ptr(acc), B, C, T)
-        denom = acc[1] * C
-        loss = (acc[0] - logdet.sum()) / denom + _HALF_LOG_2PI
-        ctx.save_for_backward(z, m, logs, denom)
+        out = torch.empty(2, device=z.device, dtype=torch.float32)          # loss, denominator
+        call("glowtts_mle_loss_fwd", ptr(z), ptr(m), ptr(logs), ptr(m2), ptr(f32(_c(logdet))), ptr(acc), ptr(out), B, C, T)
+        ctx.save_for_backward(z, m, logs, out)
         ctx.B = B
-        return loss
+        return out[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dloss):
-        z, m, logs, denom = ctx.saved_tensors
-        scale = (dloss / denom).reshape(1).contiguous()
+        z, m, logs, out = ctx.saved_tensors
+        dloss = f32(_c(dloss)).reshape(1)
         dz, dm, dlogs = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
-        call("glowtts_mle_bwd", ptr(z), ptr(m), ptr(logs), ptr(scale), ptr(dz), ptr(dm), ptr(dlogs), z.numel())
-        return dz, dm, dlogs, (-scale).expand(ctx.B), None
+        dlogdet = torch.empty(ctx.B, device=z.device, dtype=torch.float32)
+        call("glowtts_mle_loss_bwd", ptr(z), ptr(m), ptr(logs), ptr(dloss), ptr(out[1:]), ptr(dz), ptr(dm), ptr(dlogs),
+             ptr(dlogdet), ctx.B, z.numel())
+        return dz, dm, dlogs, dlogdet, None
+
+
+class DurationLossFn(Function):
+    """utils.py:26-28: sum((logw - logw_)^2) / sum(lengths), one launch each way.  logw_ carries no gradient (the alignment
+    is a constant of the step, models.py:383-392)."""
+
+    @staticmethod
+    def forward(ctx, logw, logw_, lengths):
+        logw, logw_ = f32(_c(logw)), f32(_c(logw_.detach()))
+        lengths = _c(lengths.to(device=logw.device, dtype=torch.int64))
+        out = torch.empty(2, device=logw.device, dtype=torch.float32)       # loss, denominator
+        call("glowtts_duration_loss_fwd", ptr(logw), ptr(logw_), ptr(lengths), ptr(out), lengths.numel(), logw.numel())
+        ctx.save_for_backward(logw, logw_, out)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        logw, logw_, out = ctx.saved_tensors
+        dloss = f32(_c(dloss)).reshape(1)
+        dlogw = torch.empty_like(logw)
+        call("glowtts_duration_loss_bwd", ptr(logw), ptr(logw_), ptr(dloss), ptr(out[1:]), ptr(dlogw), logw.numel())
+        return dlogw, None, None
+
+
+def span_logw(first: torch.Tensor, t_x: torch.Tensor) -> torch.Tensor:
+    """log(1e-8 + frames per token) * x_mask from the span table of mas_path_spans: (B, 1, Tx) fp32 (models.py:392)."""
+    B, tx1 = first.shape
+    out = torch.empty(B, 1, tx1 - 1, device=first.device, dtype=torch.float32)
+    t_x = t_x.to(device=first.device, dtype=torch.int32).contiguous()
+    call("glowtts_span_logw", ptr(first), ptr(t_x), ptr(out), B, tx1 - 1)
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -495,6 +495,24 @@ int glowtts_mle_fwd(const float *z, const float *m, const float *logs, const flo
                     int C, int T, glowtts_stream_t stream);
 int glowtts_mle_bwd(const float *z, const float *m, const float *logs, const float *scale, float *dz, float *dm,
                     float *dlogs, int64_t n, glowtts_stream_t stream);
+/* The same losses with their scalar tails on the device (one autograd node, no one-element torch launches):
+ *   mle_loss_fwd : acc (2, zero-filled) as glowtts_mle_fwd; out[0] = (acc[0] - sum logdet) / (acc[1] C) + 0.5 log(2 pi),
+ *                  out[1] = acc[1] C (utils.py:14-23);  mle_loss_bwd : dz, dm, dlogs as glowtts_mle_bwd with
+ *                  scale = dloss[0] / denom[0], and dlogdet[b] = -scale
+ *   duration_loss_fwd : out[0] = sum (logw - logw_)^2 / sum lengths, out[1] = sum lengths (utils.py:26-28; lengths int64);
+ *   duration_loss_bwd : dlogw = 2 (logw - logw_) dloss[0] / denom[0]
+ *   span_logw : logw_[b][x] = log(1e-8 + first[b][x+1] - first[b][x]) for x < t_x[b], else 0 — the reference's
+ *               log(1e-8 + sum(attn, -1)) * x_mask (models.py:392) from the span table of glowtts_mas_path_spans */
+int glowtts_mle_loss_fwd(const float *z, const float *m, const float *logs, const float *mask, const float *logdet, float *acc,
+                         float *out, int B, int C, int T, glowtts_stream_t stream);
+int glowtts_mle_loss_bwd(const float *z, const float *m, const float *logs, const float *dloss, const float *denom, float *dz,
+                         float *dm, float *dlogs, float *dlogdet, int B, int64_t n, glowtts_stream_t stream);
+int glowtts_duration_loss_fwd(const float *logw, const float *logw_, const long long *lengths, float *out, int B, int64_t n,
+                              glowtts_stream_t stream);
+int glowtts_duration_loss_bwd(const float *logw, const float *logw_, const float *dloss, const float *denom, float *dlogw,
+                              int64_t n, glowtts_stream_t stream);
+int glowtts_span_logw(const int32_t *first, const int32_t *t_x, float *logw_, int B, int Tx, glowtts_stream_t stream);
+
 
 /* ---- clip_grad_value_ (utils.py:118-132) and Adam + Noam (optimize.py:8-64) over FLAT buffers ---------------
  * clip : sumsq[0] += sum g^2 (pre-clamp, as the reference's norm) ; g = clamp(g, -clip, clip)

@@ -1319,3 +1319,45 @@ def test_graphed_train_step_matches_eager(G):
     for a, e in zip(losses["graph"][2:], losses["eager"][2:]):
         assert abs(a - e) <= 2e-4 * abs(e), (losses)
     # (the graph variant made one extra eager step above; compare the trajectories, not the end state)
+
+
+def test_actnorm_invconv_bwd_is_stable_next_to_the_weight_gradient_kernel(G):
+    """Regression (DESIGN.md lesson 12): the fused ActNorm + InvConv backward run NEXT TO the bf16-plane 5-tap weight-gradient
+    kernel (second stream, co-resident on the CUs) returned wrong matrix-gradient partials in a few percent of its launches
+    while its accumulators were packed-fp32 register pairs; alone it never did.  The library is built without packed-fp32 VALU
+    math since; results must repeat to the rounding of the atomics (shape with a partially filled last wave, the worst case)."""
+    from glow_tts_train import _hip
+    from glow_tts_train._hip import call, ptr
+
+    B, C, T, H = 8, 160, 64, 192
+    torch.manual_seed(0)
+    x, dz = torch.randn(B, C, T, device="cuda"), torch.randn(B, C, T, device="cuda")
+    m = torch.ones(B, T, device="cuda")
+    logs, bias = torch.randn(C, device="cuda") * 0.1, torch.randn(C, device="cuda") * 0.1
+    w = torch.linalg.qr(torch.randn(4, 4))[0].cuda().contiguous()
+    winv = torch.linalg.inv(w).contiguous()
+    xlen, dld = m.sum(1), torch.randn(B, device="cuda")
+    dx = torch.empty_like(x)
+    xw, d2 = torch.randn(B, H, 120, device="cuda"), torch.randn(B, 2 * H, 120, device="cuda")
+    dwp5 = torch.zeros(5, H, 2 * H, device="cuda")
+    side = torch.cuda.Stream()
+    before = _hip.conv_math("bf16x6+wrw")
+    try:
+        ref, worst = None, 0.0
+        for _ in range(120):
+            dlogs, dbias, dw = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(16, device="cuda")
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    call("glowtts_conv_wrw", ptr(xw), xw.stride(0), ptr(d2), d2.stride(0), None, None, ptr(dwp5), None, B, H, 2 * H,
+                         120, 5, 1, 2)
+            call("glowtts_actnorm_invconv_bwd", ptr(x), ptr(m), ptr(logs), ptr(bias), ptr(w), ptr(winv), ptr(dz), ptr(dld), ptr(xlen),
+                 ptr(dx), ptr(dlogs), ptr(dbias), ptr(dw), B, C, T, 4)
+            torch.cuda.synchronize()
+            got = torch.cat([dw, dlogs, dbias])
+            if ref is None:
+                ref = got.clone()
+            worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+    finally:
+        _hip.conv_math(before)
+    assert worst < 5e-6, worst
