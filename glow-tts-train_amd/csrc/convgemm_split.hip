@@ -356,7 +356,14 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xreg[PRE ? 1 : NX], dreg[PRE ? 1 : ND], mreg;
+    // AG (1x1 convolutions): a wave's 16 x rows are used by that wave alone, so they skip LDS — each lane loads the 8 frames of
+    // its MFMA slot straight from global memory (two 16-byte loads per 32-frame step, the next chunk's while this one is
+    // multiplied) and splits them in registers.  LDS then carries the d rows only: a third fewer ds_read_b128 per MFMA in a loop
+    // that was bound by them (4 waves x 18 reads per step against 24 MFMAs), and half the ds_write traffic of the staging.
+    constexpr bool AG = (TAPS == 1) && !PRE;
+    f32x4 xreg[(PRE || AG) ? 1 : NX], dreg[PRE ? 1 : ND], mreg;
+    f32x4 araw[AG ? NSTEP : 1][2];                     // next chunk's x values of this lane's slots (fp32, as loaded)
+    int apl[AG ? NSTEP : 1][NS][4];                    // this chunk's A operands: [step][plane] = 8 bf16
     i32x2 xpr[PRE ? NX : 1][NS], dpr[PRE ? ND : 1][NS];
     float bsum[ND];
 #pragma unroll
@@ -431,11 +438,22 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
             }
             return;
         }
+        if constexpr (AG) {
+            const int row = k0 + wave * 16 + lrow;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int t = ts + xq[i];
-            const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
-            xreg[i] = ld16(xrs, ok ? (xb + xrow[i] + t) * 4 : kOOB);
+            for (int g = 0; g < NSTEP; ++g) {
+                const int t = tc + g * 32 + lk * 8;      // (frames past the chunk meet zero d rows; past T the loads return zeros)
+                const bool ok = row < p.Cin;
+                araw[g][0] = ld16(xrs, (ok && t < p.T) ? (xb + row * p.T + t) * 4 : kOOB);
+                araw[g][1] = ld16(xrs, (ok && t + 4 < p.T) ? (xb + row * p.T + t + 4) * 4 : kOOB);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int t = ts + xq[i];
+                const bool ok = xrow[i] >= 0 && t >= 0 && t < p.T;
+                xreg[i] = ld16(xrs, ok ? (xb + xrow[i] + t) * 4 : kOOB);
+            }
         }
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
@@ -485,19 +503,35 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
             if (md_thread) *reinterpret_cast<f32x4 *>(Md + (tid - 64) * 4) = mreg;
             __syncthreads();
         }
+        if constexpr (AG) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            const int q = idx % (XWL / 4), r = idx / (XWL / 4);
-            if (idx < X4) {
-                f32x4 v = xreg[i];
-                if (p.mask_x) v *= *reinterpret_cast<const f32x4 *>(Mx + q * 4);
-                unsigned o01[NS], o23[NS];
-                split_planes2<NS>(v[0], v[1], o01);
-                split_planes2<NS>(v[2], v[3], o23);
+            for (int g = 0; g < NSTEP; ++g)
 #pragma unroll
-                for (int pl = 0; pl < NS; ++pl)
-                    *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 v = araw[g][h];
+                    const int f0 = g * 32 + lk * 8 + h * 4;                    // first of the four frames, inside the chunk's window
+                    if (p.mask_x && f0 + 4 <= XWL) v *= *reinterpret_cast<const f32x4 *>(Mx + f0);
+                    unsigned o01[NS], o23[NS];
+                    split_planes2<NS>(v[0], v[1], o01);
+                    split_planes2<NS>(v[2], v[3], o23);
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) { apl[g][pl][2 * h] = (int)o01[pl]; apl[g][pl][2 * h + 1] = (int)o23[pl]; }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int idx = tid + i * 256;
+                const int q = idx % (XWL / 4), r = idx / (XWL / 4);
+                if (idx < X4) {
+                    f32x4 v = xreg[i];
+                    if (p.mask_x) v *= *reinterpret_cast<const f32x4 *>(Mx + q * 4);
+                    unsigned o01[NS], o23[NS];
+                    split_planes2<NS>(v[0], v[1], o01);
+                    split_planes2<NS>(v[2], v[3], o23);
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl)
+                        *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
+                }
             }
         }
 #pragma unroll
@@ -520,15 +554,17 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     const unsigned short *xa = Xh + (wave * 16 + lrow) * XP16 + lk * 8;
     const unsigned short *db_ = Dh + lrow * DP16 + lk * 8;
     auto compute = [&]() {
-        int aw[2][NS][8];
+        int aw[AG ? 1 : 2][NS][8];
         i32x4 bv[2][MT][NS];
         auto fetch = [&](int g, int sl) {
+            if constexpr (!AG) {
 #pragma unroll
-            for (int pl = 0; pl < NS; ++pl) {
-                const i32x4 lo = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32);
-                const i32x4 hi = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32 + 8);
+                for (int pl = 0; pl < NS; ++pl) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32);
+                    const i32x4 hi = *reinterpret_cast<const i32x4 *>(xa + pl * XPLANE + g * 32 + 8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { aw[sl][pl][e] = lo[e]; aw[sl][pl][4 + e] = hi[e]; }
+                    for (int e = 0; e < 4; ++e) { aw[sl][pl][e] = lo[e]; aw[sl][pl][4 + e] = hi[e]; }
+                }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -549,10 +585,14 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        av[pl][e] = (sh & 1) ? (int)__builtin_amdgcn_alignbit((unsigned)aw[sl][pl][(sh >> 1) + e + 1],
-                                                                             (unsigned)aw[sl][pl][(sh >> 1) + e], 16)
-                                             : aw[sl][pl][(sh >> 1) + e];
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (AG)
+                            av[pl][e] = apl[g][pl][e];
+                        else
+                            av[pl][e] = (sh & 1) ? (int)__builtin_amdgcn_alignbit((unsigned)aw[sl][pl][(sh >> 1) + e + 1],
+                                                                                 (unsigned)aw[sl][pl][(sh >> 1) + e], 16)
+                                                 : aw[sl][pl][(sh >> 1) + e];
+                    }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
