@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import typing
 import weakref
+from operator import is_ as _is
 
 import numpy as np
 import torch
@@ -94,7 +95,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def grads_in_place(self) -> bool:
         views = self._grad_views()
-        return all(p.grad is v for p, v in zip(self._params, views))
+        return all(map(_is, [p.grad for p in self._params], views))        # (C-level loops: called twice per step)
 
     def clip_grad_value_(self, clip_value: float):
         """utils.clip_grad_value_ over the whole flat gradient buffer in one launch; None if a gradient has been replaced by
