@@ -115,6 +115,12 @@ def ptr_rows(t: torch.Tensor):
     return t.data_ptr()
 
 
+# The weight-gradient stream is the one every backward ends with (its queue drains ~1.3 ms after the dx chain's at config 2):
+# a high-priority HIP stream lets its kernels win the CUs when both streams have work (17.60 -> 17.47 ms per step, A/B in
+# separate processes on one box).  GLOWTTS_WGRAD_PRIO=0 restores a normal-priority stream.
+_WGRAD_PRIO = int(os.environ.get("GLOWTTS_WGRAD_PRIO", "-1"))
+
+
 class _WgradStream:
     """Weight-gradient launches of a backward pass go to a second HIP stream: they read tensors that already exist (layer
     input, output gradient) and nothing on the dx chain waits for them, so their workgroups fill the prologue / epilogue /
@@ -125,7 +131,7 @@ class _WgradStream:
         self.enabled = _hip.side_stream_enabled()
         if self.enabled:
             self.main = torch.cuda.current_stream(device)
-            self.side = _hip.side_stream(device, "wgrad")
+            self.side = _hip.side_stream(device, "wgrad", priority=_WGRAD_PRIO)
 
     def run(self, fn, *reads):
         if not self.enabled:
