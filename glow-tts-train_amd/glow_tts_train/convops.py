@@ -119,6 +119,9 @@ def ptr_rows(t: torch.Tensor):
 # a high-priority HIP stream lets its kernels win the CUs when both streams have work (17.60 -> 17.47 ms per step, A/B in
 # separate processes on one box).  GLOWTTS_WGRAD_PRIO=0 restores a normal-priority stream.
 _WGRAD_PRIO = int(os.environ.get("GLOWTTS_WGRAD_PRIO", "-1"))
+# ... and the LAST block of the backward (the decoder's first) keeps its weight gradients on the chain's stream: by then the
+# weight-gradient stream has a backlog and the chain nothing else to do (0 / 1 / 2 blocks: 17.68 / 17.40 / 17.60 ms per step).
+_WGRAD_MAIN_BLOCKS = int(os.environ.get("GLOWTTS_WGRAD_MAIN_BLOCKS", "1"))
 
 
 class _WgradStream:
@@ -950,7 +953,7 @@ class FlowBlockFn(Function):
     def forward(ctx, x, m2, x_len, drop, cfg, bplan, cond, *params):
         # cond: None or the speaker conditioning rows (B, 2H * n_layers, 1) = wn.cond_layer(g) (reference layers.py:142-150)
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg[:7]
         # io (csrc: the `_io` entry points): 0 = fp32 tensors; 1 = the coupling network's hidden tensors bf16 in HBM, the
         # flow tensor fp32; 3 = the flow tensor bf16 as well
         fdt = torch.bfloat16 if io & 2 else torch.float32
@@ -1001,7 +1004,8 @@ class FlowBlockFn(Function):
     @once_differentiable
     def backward(ctx, dz, dlogdet):
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = ctx.cfg
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = ctx.cfg[:7]
+        block_index = ctx.cfg[7] if len(ctx.cfg) > 7 else 1 << 30
         fdt = torch.bfloat16 if io & 2 else torch.float32
         adt = torch.bfloat16 if io & 1 else torch.float32
         sv = list(ctx.saved_tensors)
@@ -1023,6 +1027,8 @@ class FlowBlockFn(Function):
             dz = dz.to(fdt)
         dlogdet = dlogdet.contiguous().float() if dlogdet is not None else torch.zeros(B, device=dev)
         wgrad = _WgradStream(dev)
+        if block_index < _WGRAD_MAIN_BLOCKS:
+            wgrad.enabled = False                    # the backward's last blocks: their weight gradients stay on the chain's stream
         two_src = (not io) and wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
         dy, dout, dx = flow(B, C, T), new(B, C, T), flow(B, C, T)
         dskip = new(B, H, T)

@@ -106,7 +106,7 @@ def test_flow_stack_bf16_tensors_track_fp32(G, mode, b, t, blocks, p_drop):
     used, calls_io = [], []
     orig = G.convops.FlowBlockFn.forward
     G.convops.FlowBlockFn.forward = staticmethod(
-        lambda ctx, x, m2, xl, drop, cfg, *a, _o=orig: (used.append(x.dtype), calls_io.append(cfg[-1]), _o(ctx, x, m2, xl, drop, cfg, *a))[2])
+        lambda ctx, x, m2, xl, drop, cfg, *a, _o=orig: (used.append(x.dtype), calls_io.append(cfg[6]), _o(ctx, x, m2, xl, drop, cfg, *a))[2])
     try:
         z1, l1, dx1, g1 = _run(dec, y0, mask, r, s, mode)
         want = torch.bfloat16 if mode == "all" else torch.float32
