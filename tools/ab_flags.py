@@ -31,8 +31,26 @@ def apply(v):
         convops._WN_NATIVE = v
     elif name == "io":
         model.decoder.io_bf16 = False if v == "fp32" else v
+    elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
+        global CHAIN
+        CHAIN = v == "1"
     else:
         raise SystemExit("unknown switch " + name)
+
+
+CHAIN = False
+_chain_stream = torch.cuda.Stream(priority=-1)
+_tb = train_batch
+
+
+def train_batch(*a):                                         # noqa: F811
+    if not CHAIN:
+        return _tb(*a)
+    _chain_stream.wait_stream(torch.cuda.default_stream())
+    with torch.cuda.stream(_chain_stream):
+        out = _tb(*a)
+    torch.cuda.default_stream().wait_stream(_chain_stream)
+    return out
 
 
 for _ in range(8):
