@@ -324,7 +324,7 @@ def join_side_streams() -> None:
 
 def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda.Stream":
     """One extra stream per (device, role): "encoder" (the text-encoder branch), "wgrad" (weight-gradient kernels) and
-    "chain" (high priority: the decoder's dependency chain, see train.train_batch)."""
+    "comm" (the DP reducer's collectives)."""
     key = (torch.device(device).index, role)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device, priority=priority)
