@@ -115,10 +115,11 @@ def ptr_rows(t: torch.Tensor):
     return t.data_ptr()
 
 
-# The weight-gradient stream is the one every backward ends with (its queue drains ~1.3 ms after the dx chain's at config 2):
-# a high-priority HIP stream lets its kernels win the CUs when both streams have work (17.60 -> 17.47 ms per step, A/B in
-# separate processes on one box).  GLOWTTS_WGRAD_PRIO=0 restores a normal-priority stream.
-_WGRAD_PRIO = int(os.environ.get("GLOWTTS_WGRAD_PRIO", "-1"))
+# Tuning knob, OFF by default: GLOWTTS_WGRAD_PRIO=-1 makes the weight-gradient stream a high-priority HIP stream.  On one
+# GPU without collectives it shortens the step a little (17.60 -> 17.47 ms: its queue is the one every backward ends with), but
+# with RCCL collectives on another stream ANY high-priority stream in the process nearly doubles the step (bench.py
+# --rccl-self: 18.2 -> 32 ms, whichever of the weight-gradient and communication streams has the priority).
+_WGRAD_PRIO = int(os.environ.get("GLOWTTS_WGRAD_PRIO", "0"))
 # ... and the LAST block of the backward (the decoder's first) keeps its weight gradients on the chain's stream: by then the
 # weight-gradient stream has a backlog and the chain nothing else to do (0 / 1 / 2 blocks: 17.68 / 17.40 / 17.60 ms per step).
 _WGRAD_MAIN_BLOCKS = int(os.environ.get("GLOWTTS_WGRAD_MAIN_BLOCKS", "1"))
