@@ -437,6 +437,9 @@ def main():
     # ---- roofline leg: HIP events around every hand-written kernel launch, instrumented pass after the timed region
     if reducer is not None:
         reducer.remove_hooks()                           # the legs below run rank-local steps without collectives
+        # ... on the SAME operator path as `value`: with the listener gone and a process group still alive, "auto" would send
+        # every parameter gradient back through autograd (no whole-block executors) — pin in-place gradients instead
+        convops.set_direct_grads(True)
     if rank == 0 and not args.no_roofline:
         import re
 

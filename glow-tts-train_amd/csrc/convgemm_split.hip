@@ -713,6 +713,10 @@ static int dispatch_bf16_io(ConvGemmParams &p, int epi, bool big, bool n5, const
     if (epi == E && (R == 2) == big && p.taps == TP)                                   \
         return n5 ? launch_split<1, R, 5, E, TP, IOB, (IOB == 2 ? 3 : 1)>(p, pl, st, s)  \
                   : launch_split<1, R, 4, E, TP, IOB, (IOB == 2 ? 3 : 1)>(p, pl, st, s);
+    // the 1x1 PLAIN / ADD convolutions (start, end, start's input gradient) exist with 64-row workgroups only, which serve
+    // any M: dispatch_convgemm's 128-row preference (M % 128 == 0 or M > 192: squeezed C = 128 / 256) must not leave them
+    // without a kernel
+    if (p.taps == 1 && (epi == EPI_PLAIN || epi == EPI_ADD)) big = false;
     GLOWTTS_BF16_CASE(EPI_PLAIN, 1, 1)       // fp32 results (IOB == 2): exact weights, three planes
     GLOWTTS_BF16_CASE(EPI_ADD, 1, 1)         // ... and the start conv's input gradient added into an fp32 flow gradient
     if constexpr (IOB == 1) {

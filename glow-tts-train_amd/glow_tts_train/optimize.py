@@ -143,7 +143,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, d):
         """Like torch.optim.Optimizer.load_state_dict: a state whose parameter count or moment shapes differ from this
-        optimizer's raises ValueError; an EMPTY state (a file saved before the first update) is accepted."""
+        optimizer's raises ValueError; an EMPTY state (a file saved before the first update) is accepted, and so is a
+        state without an entry for some parameter — torch.optim.Adam only creates a parameter's state at its first
+        gradient, so a reference checkpoint of a model with a frozen / never-used parameter has none: zero moments here,
+        with a warning."""
         st = d.get("state", {})
         saved_groups = d.get("param_groups", [])
         if saved_groups and "params" in saved_groups[0]:
@@ -152,14 +155,19 @@ class FlatAdam(torch.optim.Optimizer):
                 raise ValueError(f"loaded state dict has {n_saved} parameters, the optimizer has {len(self._params)}")
         missing = [i for i in range(len(self._params)) if st and i not in st and str(i) not in st]
         if missing:
-            raise ValueError(f"optimizer state lacks entries for parameters {missing[:8]}{'...' if len(missing) > 8 else ''}")
+            import warnings
+            warnings.warn(f"FlatAdam.load_state_dict: no state for parameters {missing[:8]}{'...' if len(missing) > 8 else ''} "
+                          "(never updated when the file was written): their moments start at zero")
         steps = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self._params, self.offsets)):
                 s = st.get(i, st.get(str(i)))
-                if s is None:
-                    continue
                 n = p.numel()
+                if s is None:
+                    if st:
+                        self.flat_m[o:o + n].zero_()
+                        self.flat_v[o:o + n].zero_()
+                    continue
                 for name in ("exp_avg", "exp_avg_sq"):
                     if tuple(s[name].shape) != tuple(p.shape):
                         raise ValueError(f"optimizer state {name}[{i}] has shape {tuple(s[name].shape)}, "

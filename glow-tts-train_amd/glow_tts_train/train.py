@@ -77,10 +77,18 @@ def train_batch(model, optimizer, batch, grad_clip: float, reducer=None, scaler=
     else:
         # train.py:140: scaler.step(optimizer._optim).  The reference's wrapper never sees that call, so its Noam counter
         # stands still in fp16 runs; here the schedule lives on the device inside FlatAdam.step and advances
-        # with every update that is actually applied — the host mirror follows it.
-        scaler.step(flat)
+        # with every update that is actually applied — the host mirror follows it: GradScaler.step calls flat.step only
+        # when the un-scaled gradients are finite, so the mirror advances exactly when that call happened (a skipped update
+        # must not move step_num / cur_lr, which checkpoints save and load_state_dict re-imposes).
+        applied = []
+        inner_step = flat.step
+        flat.step = lambda *a, **k: (applied.append(1), inner_step(*a, **k))[1]
+        try:
+            scaler.step(flat)
+        finally:
+            del flat.step                   # drop the instance attribute: the class's method is visible again
         scaler.update()
-        if hasattr(optimizer, "_update_learning_rate"):
+        if applied and hasattr(optimizer, "_update_learning_rate"):
             optimizer._update_learning_rate()
     return loss
 

@@ -40,9 +40,9 @@ def G():
     return ns
 
 
-def _decoder(G, blocks, seed=3, p_drop=0.0, end_std=0.02):
+def _decoder(G, blocks, seed=3, p_drop=0.0, end_std=0.02, mels=80):
     torch.manual_seed(seed)
-    dec = G.models.FlowSpecDecoder(80, 192, kernel_size=5, dilation_rate=1, n_blocks=blocks, n_layers=4, p_dropout=p_drop,
+    dec = G.models.FlowSpecDecoder(mels, 192, kernel_size=5, dilation_rate=1, n_blocks=blocks, n_layers=4, p_dropout=p_drop,
                                    n_split=4, n_sqz=2).cuda().train()
     with torch.no_grad():
         for f in dec.flows:
@@ -127,6 +127,37 @@ def test_flow_stack_bf16_tensors_track_fp32(G, mode, b, t, blocks, p_drop):
             continue
         assert _cos(g1[k], g0[k]) > 0.999, (k, _cos(g1[k], g0[k]))
         assert rel_err(g1[k], g0[k]) < 6e-2, (k, rel_err(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mels", [64, 128])
+def test_flow_stack_bf16_other_mel_widths(G, mode, mels):
+    """Squeezed C = 128 / 256 (64 / 128 mels): the end conv (M = C) and the start conv's input gradient (M = C/2) fall on
+    dispatch_convgemm's 128-row preference, for which the 1x1 bf16-tensor kernels are not instantiated: they
+    must run on the 64-row form — the block runs with bf16 tensors and tracks the fp32 path, no 'no kernel for epilogue'."""
+    b, t, blocks = 2, 96, 2
+    dec = _decoder(G, blocks, mels=mels)
+    y0 = torch.randn(b, mels, t, device="cuda")
+    lens = torch.tensor([t, t - 24], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
+    y0 = y0 * mask
+    r = torch.randn(b, mels, t, device="cuda")
+    s = torch.randn(b, device="cuda")
+    calls_io = []
+    orig = G.convops.FlowBlockFn.forward
+    G.convops.FlowBlockFn.forward = staticmethod(
+        lambda ctx, x, m2, xl, drop, cfg, *a, _o=orig: (calls_io.append(cfg[6]), _o(ctx, x, m2, xl, drop, cfg, *a))[1])
+    try:
+        z1, l1, dx1, g1 = _run(dec, y0, mask, r, s, mode)
+        assert calls_io == [3 if mode == "all" else 1] * blocks, calls_io
+        z0, l0, dx0, g0 = _run(dec, y0, mask, r, s, False)
+    finally:
+        G.convops.FlowBlockFn.forward = orig
+    assert rel_err(z1, z0) < 3e-2 and rel_err(l1, l0) < 2e-3, (rel_err(z1, z0), rel_err(l1, l0))
+    assert _cos(dx1, dx0) > 0.999
+    for k in g0:
+        if float(g0[k].abs().max()) >= 1e-6:
+            assert _cos(g1[k], g0[k]) > 0.999, (k, _cos(g1[k], g0[k]))
 
 
 @pytest.mark.parametrize("mode", MODES)

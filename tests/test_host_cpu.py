@@ -389,8 +389,12 @@ def test_flat_adam_load_state_dict_rejects_mismatched_state():
     opt.load_state_dict({"state": {}, "param_groups": sd["param_groups"]})      # saved before the first update: fine
     broken = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
     del broken["state"][3]
-    with pytest.raises(ValueError, match="lacks entries"):
+    # torch.optim.Adam has no state for a parameter that never received a gradient: accepted (zero moments) with a warning
+    opt._optim.flat_m.fill_(1.0)
+    with pytest.warns(UserWarning, match="no state for parameters"):
         opt.load_state_dict(broken)
+    o3, n3 = opt._optim.offsets[3], opt._optim._params[3].numel()
+    assert float(opt._optim.flat_m[o3:o3 + n3].abs().max()) == 0.0
     broken = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
     broken["state"][0] = dict(broken["state"][0], exp_avg=torch.zeros(5))
     with pytest.raises(ValueError, match="shape"):

@@ -11,10 +11,12 @@ base=${f%.hip}
 mkdir -p build/exp ../lib/exp
 rm -f ../lib/exp/*.so
 OTHERS=$(ls build/*.o | grep -v "build/$base.o")
+# compiler, architecture and flags are the production ones (the Makefile's: incl. -fno-slp-vectorize, DESIGN.md lesson 12)
+HIPCC=$(make -s print-HIPCC); ARCH=$(make -s print-ARCH); CXXFLAGS=$(make -s print-CXXFLAGS)
 for v in "$@"; do
   n=${v%%:*}; fl=${v#*:}
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$ROOT/include" -I. -ffp-contract=off -munsafe-fp-atomics $fl -c $f -o build/exp/${base}_$n.o \
-    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/exp/lib_$n.so $OTHERS build/exp/${base}_$n.o ) &
+  ( $HIPCC $CXXFLAGS $fl -c $f -o build/exp/${base}_$n.o \
+    && $HIPCC -shared -fPIC --offload-arch=$ARCH -o ../lib/exp/lib_$n.so $OTHERS build/exp/${base}_$n.o ) &
 done
 wait
 ls ../lib/exp
