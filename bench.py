@@ -12,14 +12,23 @@ T_text=160, T_mel=800, 80 mels, 12 flow blocks, n_split=4, fp32, ModelConfig def
 random-init weights, data-dependent ActNorm init done before timing.  Weak scaling: every rank gets its own B=32.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  "roofline"     : the dominant hand-written HIP kernel of the step (the one with the largest total time): an fp32-MFMA
-                   implicit-GEMM convolution, so bound = "mfma": algorithmic FLOPs per launch (2*M*K*taps*columns,
-                   DESIGN.md 4a) / its mean launch duration, measured with HIP events on the launch stream in an
-                   instrumented pass after the timed region, against the 157.3 TFLOP/s dense fp32 MFMA peak;
-                   "traffic" = HBM-side bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json);
-                   plus every MFMA kernel's TFLOP/s, every streaming kernel's GB/s against 8 TB/s, and the
-                   SURVEY.md 8d(i) invertible-subset fraction;
-  "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) timed on this host's cores on a bounded sample.
+  "roofline"     : the dominant hand-written HIP kernel of the step (largest total time): the weight gradient of the WN stack's
+                   5-tap convolutions, bound = "mfma".  Its mean launch duration is measured with HIP events on the launch
+                   stream in an instrumented pass after the timed region.  In the default arithmetic ("bf16x6+wrw": each fp32
+                   operand as three bf16 planes, six products per fp32 product on v_mfma_f32_16x16x32_bf16) the line carries
+                   THREE fractions and says which is which:
+                     frac_algorithmic = algorithmic FLOPs (2*M*K*taps*columns) / t / 2.5 PFLOP/s dense bf16 peak,
+                     frac_pipe        = 6 x that (the MFMA work the pipe really does) = `frac`,
+                     mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed PMC
+                                        pass (profiles/r03_pmc.json), null when no pass exists for the kernel;
+                   with GLOWTTS_CONV_MATH=fp32 the peak is the 157.3 TFLOP/s dense fp32 MFMA figure and all three coincide.
+                   "traffic" = HBM-side bytes per launch from the PMC passes.  Every MFMA kernel is listed with its
+                   algorithmic bytes and FLOPs, its time at each roof and `bound: hbm|mfma` (the 1x1 convolutions are
+                   byte-bound: they are reported against 8 TB/s, not as TFLOP/s alone); every streaming kernel with GB/s against
+                   8 TB/s; plus the SURVEY.md 8d(i) invertible-subset fraction and the decoder alone (8d(ii));
+  "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) on this host's cores as BASELINE.md section 3 prescribes:
+                   3 warm-up + 10 timed full steps, median, all usable cores, plus a 1-thread run on a shorter sample; the
+                   CPU model is stated.
 """
 from __future__ import annotations
 
@@ -57,7 +66,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split-math", action="store_true",
                     help="skip the extra leg that times the same step with the WN convolutions in bf16x6 split arithmetic")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps on all cores (BASELINE.md section 3: 10)")
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-steps-1thread", type=int, default=2, help="timed CPU-oracle steps of the 1-thread run (0 = skip)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: add a leg (`bf16_io`, beside `value`, never instead of it) that times the same step with the flow "
                          "decoder's activation tensors kept in HBM as bf16 (BASELINE configs[2]'s arithmetic; use with --batch 64 "
@@ -108,29 +119,60 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
 
 # bench tag -> (HIP kernel, grid size) of the committed counter passes, per arithmetic of the WN convolutions
 _PMC_KERNEL = {
-    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_split_kernel<3,5,5,2,false> grid=129024",
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,2> grid=129024",
     ("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32"): "convwrw_fp_kernel<5,5,2> grid=196608",
     ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
     ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
 }
 
 
-def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
-    """HBM-side bytes per launch of `kernel_tag` from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be
-    collected from inside this process): profiles/r02_pmc.json — tools/pmc_passes.sh over this same bench command, one counter
-    group per run, combined per kernel and grid size by tools/pmc_combine.py as MI355X_MICROARCH.md prescribes (FETCH_SIZE
-    doubled on gfx950); round 1's table (native kernels, profiles/r01_pmc_traffic.json) as the fallback.  None when no
-    measurement exists."""
+def pmc_entry(kernel_tag, math="bf16x6+wrw"):
+    """The committed rocprofv3 PMC record of `kernel_tag` (FETCH_SIZE / WRITE_SIZE / MFMA-busy cannot be collected from inside
+    this process): profiles/r03_pmc.json, else r02 — tools/pmc_passes.sh over this same bench command, one counter group per
+    run, combined per kernel (matched by name; the grid size is part of the key) by tools/pmc_combine.py as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950).  {} when no measurement exists."""
     here = os.path.dirname(os.path.abspath(__file__))
-    try:
-        key = _PMC_KERNEL.get((kernel_tag, math if math.startswith("bf16x6") else "fp32"))
-        if key is not None and math.startswith("bf16x6"):
-            table = json.load(open(os.path.join(here, "profiles", "r02_pmc.json")))
-            return table[key]["traffic_bytes"]
-        table = json.load(open(os.path.join(here, "profiles", "r01_pmc_traffic.json")))
-        return table[kernel_tag]["traffic_bytes"]
+    key = _PMC_KERNEL.get((kernel_tag, math if math.startswith("bf16x6") else "fp32"))
+    if key is None:
+        return {}
+    name = key.split(" grid=")[0]
+    for fn in ("r03_pmc.json", "r02_pmc.json"):
+        try:
+            table = json.load(open(os.path.join(here, "profiles", fn)))
+        except Exception:
+            continue
+        if key in table:
+            return dict(table[key], source="profiles/" + fn)
+        same = [k for k in table if k.split(" grid=")[0] == name]
+        if same:                                   # same kernel, another grid size: the largest (the config-2 shape)
+            k = max(same, key=lambda k_: int(k_.split("grid=")[1]))
+            return dict(table[k], source="profiles/" + fn)
+    return {}
+
+
+def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
+    e = pmc_entry(kernel_tag, math)
+    if "traffic_bytes" in e:
+        return e["traffic_bytes"]
+    try:                                           # round 1's table (native kernels)
+        here = os.path.dirname(os.path.abspath(__file__))
+        return json.load(open(os.path.join(here, "profiles", "r01_pmc_traffic.json")))[kernel_tag]["traffic_bytes"]
     except Exception:
         return None
+
+
+def conv_algorithmic_bytes(name, M, K, taps, cols, H):
+    """Ideal-fusion HBM bytes of one launch of a convolution kernel (fp32 tensors; weights included): every operand read
+    once, every result written once.  cols = B x T columns."""
+    e = 4
+    w = M * K * taps * e
+    per_col = {
+        "glowtts_conv_gate_fwd": K + H + 2 * H,            # x in; acts out; tanh / sigmoid kept for the backward
+        "glowtts_conv_res_skip_fwd": K + (4 * H if M == 2 * H else 2 * H),   # acts, x, skip in; x, skip out (last layer: skip only)
+        "glowtts_conv_gate_bwd": K + 2 * H + 2 * H,        # d_rs (two sources); tanh / sigmoid; d(pre-activation) out
+        "glowtts_conv_wrw": K + M, "glowtts_conv_wrw2": K + M,
+    }.get(name, K + M + (M if name == "glowtts_conv_fwd" and taps == 5 and M == H else 0))   # 5-tap backward-data adds a tensor
+    return per_col * cols * e + w
 
 
 def decoder_alone(model, batch, cfg, n_iter=5):
@@ -462,8 +504,12 @@ def main():
                    "total_ms_per_step": round(sum(ms) / n_inst, 3)}
             m = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", name)
             if m:       # dense contraction on the MFMA: algorithmic (fp32) FLOPs = 2 * M * K * taps * columns
-                flops = 2.0 * int(m.group(2)) * int(m.group(3)) * int(m.group(4)) * int(m.group(5)) * int(m.group(6))
-                row.update(alg_GFLOP=round(flops / 1e9, 3), TFLOPs=round(flops / (mean_ms * 1e-3) / 1e12, 2))
+                M_, K_, taps_, cols_ = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)) * int(m.group(6))
+                flops = 2.0 * M_ * K_ * taps_ * cols_
+                nbytes = conv_algorithmic_bytes(m.group(1), M_, K_, taps_, cols_, H)
+                row.update(alg_GFLOP=round(flops / 1e9, 3), TFLOPs=round(flops / (mean_ms * 1e-3) / 1e12, 2),
+                           alg_MB=round(nbytes / 1e6, 2), GBps=round(nbytes / (mean_ms * 1e-3) / 1e9, 1),
+                           hbm_frac=round(nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                 mfma[name] = row
             elif name in alg:
                 row.update(alg_MB=round(alg[name] / 1e6, 3), GBps=round(alg[name] / (mean_ms * 1e-3) / 1e9, 1))
@@ -492,18 +538,39 @@ def main():
                 return wrw == "wrw" and K_ == H and ((taps_ == 5 and M_ == 2 * H) or (taps_ == 1 and M_ in (H, 2 * H)))
             return False
 
+        for tag, row in mfma.items():              # which roof bounds each contraction, and how close it is to that roof
+            split = on_bf16_pipe(tag)
+            peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            t_mfma = (6.0 if split else 1.0) * row["alg_GFLOP"] / peak            # us at the pipe's peak (GFLOP / TFLOP/s = ms*1e-3)
+            t_hbm = row["alg_MB"] / HBM_PEAK_GBS                                    # MB / (GB/s) = ms*1e-3 likewise
+            row.update(pipe="bf16 MFMA x6" if split else "fp32 MFMA",
+                       mfma_frac_algorithmic=round(row["TFLOPs"] / peak, 4),
+                       mfma_frac_pipe=round((6.0 if split else 1.0) * row["TFLOPs"] / peak, 4),
+                       bound="hbm" if t_hbm > t_mfma else "mfma",
+                       frac_of_bound=round(max(t_hbm, t_mfma) * 1e3 / row["mean_us"], 4))
         if dom is not None:
             if on_bf16_pipe(dom):
                 # six bf16 products per fp32 product: the pipe's work is 6 x the algorithmic FLOPs, its roof the dense bf16 peak
                 pipe = 6.0 * mfma[dom]["TFLOPs"]
+                pe = pmc_entry(dom, default_math)
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(pipe, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": pipe / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, default_math),
                                    "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)",
+                                   "what_frac_is": "frac = frac_pipe: the six bf16 MFMAs the kernel issues per fp32 product, "
+                                                   "counted as work, over the dense bf16 peak; frac_algorithmic counts the fp32 "
+                                                   "product once",
+                                   "frac_algorithmic": round(mfma[dom]["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS, 4),
+                                   "frac_pipe": round(pipe / BF16_MFMA_PEAK_TFLOPS, 4),
+                                   "mfma_busy_measured": pe.get("mfma_util"), "pmc_source": pe.get("source"),
+                                   "mean_us": mfma[dom]["mean_us"], "alg_GFLOP": mfma[dom]["alg_GFLOP"],
+                                   "alg_MB": mfma[dom]["alg_MB"],
                                    "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
                                    "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
             else:
+                fr = mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": fr, "frac_algorithmic": round(fr, 4), "frac_pipe": round(fr, 4),
+                                   "mfma_busy_measured": pmc_entry(dom, "fp32").get("mfma_util"),
                                    "traffic": pmc_traffic(dom, "fp32"), "pipe": "fp32 MFMA"}
         else:
             dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
@@ -534,22 +601,49 @@ def main():
         from oracle import glow_oracle as O
 
         cores = usable_cores()
-        torch.set_num_threads(cores)
-        hp = O.HParams(n_vocab=148, n_blocks_dec=args.blocks)
+        hp = O.HParams(n_vocab=148, n_blocks_dec=args.blocks, n_speakers=args.speakers,
+                       gin_channels=args.gin if args.speakers > 0 else 0)
         sd = {k: v.requires_grad_(True) for k, v in O.init_state_dict(hp, seed=cfg.seed).items()}
         oopt = O.AdamNoam(sd, dim_model=hp.hidden_channels)
-        cb = (x.cpu(), x_lengths.cpu(), y.cpu(), y_lengths.cpu(), None)
-        log(f"cpu baseline: oracle on {cores} threads")
-        O.train_step(sd, hp, oopt, cb, cfg.grad_clip)                    # warm-up (thread pools, allocator)
-        log("cpu baseline warm-up step done")
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_steps):
-            O.train_step(sd, hp, oopt, cb, cfg.grad_clip)
-        cdt = (time.perf_counter() - t0) / args.cpu_steps
-        out["cpu_baseline"] = {"value": B * T_mel / cdt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-                               "sample": f"{args.cpu_steps} full training steps of the same B={B}, T_mel={T_mel}, "
-                                         f"{args.blocks}-block batch (oracle/glow_oracle.py, torch CPU fp32 + C MAS), "
-                                         f"{cdt:.2f} s/step after 1 warm-up"}
+        cb = tuple(None if t is None else t.cpu() for t in batch)
+        model_name = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+
+        def cpu_run(threads, warm, steps):
+            torch.set_num_threads(threads)
+            for _ in range(warm):                                        # thread pools, allocator, first-touch
+                O.train_step(sd, hp, oopt, cb, cfg.grad_clip)
+            ts = []
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                O.train_step(sd, hp, oopt, cb, cfg.grad_clip)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return ts[len(ts) // 2], ts
+
+        log(f"cpu baseline: oracle on {cores} threads ({model_name})")
+        med, ts = cpu_run(cores, args.cpu_warmup, args.cpu_steps)
+        log(f"cpu baseline: median {med:.2f} s/step over {len(ts)} steps")
+        out["cpu_baseline"] = {"value": B * T_mel / med, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+                               "cpu_model": model_name, "threads": [cores],
+                               "s_per_step_median": round(med, 3), "s_per_step_min_max": [round(ts[0], 3), round(ts[-1], 3)],
+                               "sample": f"{args.cpu_steps} full training steps (median) after {args.cpu_warmup} warm-up steps of the "
+                                         f"same B={B}, T_mel={T_mel}, {args.blocks}-block batch (oracle/glow_oracle.py, torch CPU "
+                                         f"fp32 + C MAS) on {cores} threads of {model_name}"}
+        if args.cpu_steps_1thread > 0:
+            med1, ts1 = cpu_run(1, 1, args.cpu_steps_1thread)
+            out["cpu_baseline"]["threads"] = [cores, 1]
+            out["cpu_baseline"]["one_thread"] = {"value": B * T_mel / med1, "unit": "mel-frames/s", "cores": 1,
+                                                 "s_per_step_median": round(med1, 3),
+                                                 "sample": f"{args.cpu_steps_1thread} steps after 1 warm-up step, same batch, "
+                                                           "torch.set_num_threads(1)"}
+            log(f"cpu baseline, 1 thread: median {med1:.2f} s/step")
 
     if rank == 0:
         sys.stdout.flush()

@@ -475,6 +475,9 @@ struct ConvWrwParams {
 // convgemm_split.hip: the frame-packed weight-gradient kernel on bf16 planes; -1 = not handled
 int conv_wrw_split_dispatch(ConvWrwParams &p, hipStream_t s);
 int conv_wrw_planes_dispatch(ConvWrwParams &p, int ns, hipStream_t s);
+// convwrw_tr.hip: the 5-tap weight gradient from frame-major LDS images (transposing LDS reads, two half-period groups per
+// workgroup); ns = planes per fp32 operand; -1 = not handled (other taps, M % 32, GLOWTTS_WRW_TR=0)
+int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s);
 
 // convgemm_split.hip: bf16 TENSORS (p.xb): one bf16 plane of weights (bound with ns = 1), x loaded as bf16, the epilogue's
 // tensors bf16 or fp32 by p.yb; an error when the shape has no instantiation or no planes are bound (there is no

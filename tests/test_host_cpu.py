@@ -479,3 +479,28 @@ def test_fastcall_binding_matches_the_ctypes_table():
         fast(1, 1, 1, 1, None, 1, None, "0", 4, 0, 0, None)
     with pytest.raises(TypeError, match="expected 12"):
         fast(1, 2)
+
+
+def test_library_has_no_packed_fp32_valu(tmp_path):
+    """DESIGN.md lesson 12: on gfx950 a wave's packed-fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma_f32) goes wrong in lanes
+    48-63 while another wave of the CU runs bf16 MFMAs with ds_write_b64 stores (tools/pk_hazard_repro.py).  The library is built
+    with that instruction class removed from instruction selection (csrc/Makefile: NOPK); this disassembles what was built."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "glow-tts-train_amd", "lib", "libglowtts_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        pytest.skip("needs the built library and the ROCm llvm-objdump")
+    copy = tmp_path / "lib.so"
+    shutil.copy(lib, copy)
+    subprocess.run([objdump, "--offloading", str(copy)], check=True, capture_output=True, cwd=tmp_path)
+    objs = sorted(p for p in tmp_path.iterdir() if "gfx950" in p.name)
+    assert objs, "no gfx950 code object in the library"
+    bad, mfma = 0, 0
+    for o in objs:
+        text = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        bad += sum(text.count(op) for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"))
+        mfma += text.count("v_mfma_f32_16x16x32_bf16")
+    assert mfma > 1000, "disassembly looks empty"
+    assert bad == 0, f"{bad} packed-fp32 VALU instructions in libglowtts_hip.so"

@@ -122,6 +122,88 @@ __global__ __launch_bounds__(256) void victim_kernel(const float4 *__restrict__ 
     }
 }
 
+// The loop of actnorm_invconv_bwd_kernel<4, 4> itself (scalar source; flows.hip): per-workgroup-uniform multipliers (the 4x4
+// matrix, exp(logs), bias) come from memory through scalar loads, so a build WITH the SLP vectorizer turns the arithmetic
+// into v_pk_mul_f32 / v_pk_add_f32 with SGPR-PAIR operands — what the minimal victims above do not have.  dx is stored as in
+// the real kernel; the 24 accumulators go straight to memory (no LDS, no atomics).
+template <bool UNIFORM_IN_VGPR>
+__global__ __launch_bounds__(256) void victim_real_kernel(const float4 *__restrict__ x, const float4 *__restrict__ g,
+                                                          const float4 *__restrict__ m, const float *__restrict__ w,
+                                                          const float *__restrict__ logs, const float *__restrict__ bias,
+                                                          float4 *__restrict__ dx, float *__restrict__ out, int n_items, int nb) {
+    constexpr int N = 4, V = 4;
+    float wr[N * N], e[N], bi[N];
+    int zero = 0;
+    if (UNIFORM_IN_VGPR) asm volatile("" : "+v"(zero));    // an opaque per-lane 0: the loads below become vector loads and
+                                                           // the multipliers live in VGPRs instead of SGPR pairs
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) wr[q] = w[q + zero];
+#pragma unroll
+    for (int k = 0; k < N; ++k) { e[k] = expf(logs[blockIdx.x * N + k + zero]); bi[k] = bias[blockIdx.x * N + k + zero]; }
+    float aw[N * N], al[N], ab[N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) aw[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { al[k] = 0.f; ab[k] = 0.f; }
+    const int i0 = blockIdx.x * nb, i1 = min(n_items, i0 + nb);
+    float4 mv4, xv4[N], gz4[N];
+    auto fetch = [&](int it, float4 &m_, float4 *x_, float4 *g_) {
+        m_ = m[it];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { x_[k] = x[(long)it * 4 + k]; g_[k] = g[(long)it * 4 + k]; }
+    };
+    int it = i0 + threadIdx.x;
+    bool have = it < i1;
+    if (have) fetch(it, mv4, xv4, gz4);
+    while (have) {
+        const int nx = it + 256;
+        const bool have_nx = nx < i1;
+        float4 mv2, xv2[N], gz2[N];
+        if (have_nx) fetch(nx, mv2, xv2, gz2);
+        float mv[V], xv[N][V], gz[N][V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) mv[j] = reinterpret_cast<const float *>(&mv4)[j];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                xv[k][j] = reinterpret_cast<const float *>(&xv4[k])[j];
+                gz[k][j] = reinterpret_cast<const float *>(&gz4[k])[j] * mv[j];
+            }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float yk = (bi[k] + e[k] * xv[k][j]) * mv[j];
+                float dy = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < N; ++oo) {
+                    dy += wr[oo * N + k] * gz[oo][j];
+                    aw[oo * N + k] += gz[oo][j] * yk;
+                }
+                const float dym = dy * mv[j];
+                o[j] = dym * e[k];
+                al[k] += dym * e[k] * xv[k][j];
+                ab[k] += dym;
+            }
+            dx[(long)it * 4 + k] = float4{o[0], o[1], o[2], o[3]};
+        }
+        if (have_nx) {
+            mv4 = mv2;
+#pragma unroll
+            for (int k = 0; k < N; ++k) { xv4[k] = xv2[k]; gz4[k] = gz2[k]; }
+        }
+        it = nx;
+        have = have_nx;
+    }
+    float *op = out + ((long)blockIdx.x * 256 + threadIdx.x) * NACC;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) op[q] = aw[q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { op[16 + k] = al[k]; op[20 + k] = ab[k]; }
+}
+
 // hist: [0] mismatching accumulators in total, [1 .. 64] by lane, [65 .. 68] by wave, [69 .. 92] by accumulator,
 // per_launch[launch] = mismatches of that launch
 __global__ void check_kernel(const float *__restrict__ out, const float *__restrict__ want, long n, unsigned *hist,
@@ -145,15 +227,33 @@ __global__ void check_kernel(const float *__restrict__ out, const float *__restr
 // All of them keep ~200 VGPRs live (at most 256 allocated, like convwrw_split_kernel<3,5,5,2>: victim waves fit beside them) and
 // touch no memory until the guarded store at the end.
 constexpr int NA = 48;
-enum { AG_NONE = 0, AG_MFMA_BF16 = 1, AG_MFMA_F32 = 2, AG_PKVALU = 3, AG_MFMA_BF16_LDS = 4, AG_COUNT = 5 };
+enum { AG_NONE = 0, AG_MFMA_BF16 = 1, AG_MFMA_F32 = 2, AG_PKVALU = 3, AG_MFMA_BF16_LDS = 4, AG_COUNT = 5,
+       // library-only kinds (tools/pk_hazard_repro.py): what else do the real bf16 GEMMs have that the loops above lack?
+       AG_MFMA_BF16_V256 = 5,      // kind 1 with all 256 VGPRs allocated (v255 touched), as convwrw_split_kernel / hipBLASLt kernels
+       AG_MFMA_BF16_A512 = 6,      // ... and the accumulator file too (a255 touched): 512 registers, one wave per SIMD
+       AG_MFMA_BF16_GLOBAL = 7,    // kind 1 with a streaming 16-byte global load per MFMA group
+       AG_VALU_V256 = 8,           // no MFMA at all: plain fp32 VALU with 256 VGPRs allocated
+       AG_MFMA_BF16_LDSW = 9,      // kind 4 that also WRITES its LDS every iteration (ds_write_b64)
+       AG_LDSW64_NOMFMA = 10,      // the LDS reads + ds_write_b64 of kind 9 around plain fp32 VALU work: no MFMA
+       AG_MFMA_LDSW32 = 11,        // kind 9 with a ds_write_b32
+       AG_MFMA_LDSW128 = 12,       // kind 9 with a ds_write_b128
+       AG_LDSW64_ONLY = 13,        // nothing but ds_write_b64 (and a little address arithmetic)
+       AG_MFMA_LDSW2X32 = 14,      // kind 9 with a ds_write2_b32 (two dwords, two addresses)
+       AG_MFMA_LDSW16 = 15,        // kind 9 with a ds_write_b16
+       AG_MFMA_LDSW96 = 16,        // kind 9 with a ds_write_b96
+       AG_F32MFMA_LDSW64 = 17 };   // the ds_write_b64 beside FP32 MFMAs
+constexpr bool ag_has_lds(int k) { return k == 4 || (k >= 9 && k <= 17); }
+constexpr bool ag_has_mfma(int k) { return k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 9 || k == 11 || k == 12 || k == 14 || k == 15 || k == 16; }
 static const char *kAgName[AG_COUNT] = {"none", "bf16 MFMA (registers only)", "fp32 MFMA (registers only)",
                                         "packed-fp32 VALU only", "bf16 MFMA + ds_read_b128 from its own LDS"};
 
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void aggressor_kernel(float *sink, int iters, unsigned seed) {
-    __shared__ __attribute__((aligned(16))) float lds[KIND == AG_MFMA_BF16_LDS ? 4096 : 4];
+__global__ __launch_bounds__(256, KIND == 6 ? 1 : 2) void aggressor_kernel(float *sink, int iters, unsigned seed) {
+    __shared__ __attribute__((aligned(16))) float lds[ag_has_lds(KIND) ? 4096 : 4];
     const int tid = threadIdx.x;
-    if (KIND == AG_MFMA_BF16_LDS) {
+    if (KIND == AG_MFMA_BF16_V256 || KIND == AG_VALU_V256) asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    if (KIND == AG_MFMA_BF16_A512) asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+    if (ag_has_lds(KIND)) {
         for (int i = tid; i < 4096; i += 256) lds[i] = (float)((i * 37 + seed) & 7) - 3.f;
         __syncthreads();
     }
@@ -170,16 +270,42 @@ __global__ __launch_bounds__(256, 2) void aggressor_kernel(float *sink, int iter
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
-        if (KIND == AG_MFMA_BF16_LDS) {
-            const f32x4 l = *reinterpret_cast<const f32x4 *>(lds + ((tid * 4 + it * 16) & 4092));
+        if (ag_has_lds(KIND)) {
+            f32x4 l = f32x4{1.f, 2.f, 3.f, 4.f};
+            if (KIND != AG_LDSW64_ONLY) {
+                l = *reinterpret_cast<const f32x4 *>(lds + ((tid * 4 + it * 16) & 4092));
+                a.u[0] ^= __float_as_uint(l[0]) & 0x00010001u;
+            }
+            if (KIND == AG_MFMA_BF16_LDSW || KIND == AG_LDSW64_NOMFMA || KIND == AG_LDSW64_ONLY || KIND == AG_F32MFMA_LDSW64)
+                *reinterpret_cast<f32x2 *>(lds + ((tid * 2 + it * 8) & 4094)) = f32x2{l[1], l[2]};
+            if (KIND == AG_MFMA_LDSW32) lds[(tid + it * 8) & 4095] = l[1];
+            if (KIND == AG_MFMA_LDSW2X32) {
+                float *q = lds + ((tid + it * 8) & 2047);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float *)q), "v"(l[1]), "v"(l[2]) : "memory");
+            }
+            if (KIND == AG_MFMA_LDSW16) reinterpret_cast<unsigned short *>(lds)[(tid + it * 8) & 8191] = (unsigned short)__float_as_uint(l[1]);
+            if (KIND == AG_MFMA_LDSW96) {
+                float *q = lds + ((tid * 4 + it * 8) & 4092);
+                asm volatile("ds_write_b96 %0, %1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float *)q), "v"(__builtin_shufflevector(l, l, 0, 1, 2)) : "memory");
+            }
+            if (KIND == AG_MFMA_LDSW128) *reinterpret_cast<f32x4 *>(lds + ((tid * 4 + it * 8) & 4092)) = f32x4{l[1], l[2], l[3], l[0]};
+        }
+        if (KIND == AG_MFMA_BF16_GLOBAL) {
+            const f32x4 l = reinterpret_cast<const f32x4 *>(sink)[64 + ((blockIdx.x * 256 + tid + it * 4096) & 0xfffff)];
             a.u[0] ^= __float_as_uint(l[0]) & 0x00010001u;
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (KIND == AG_MFMA_BF16 || KIND == AG_MFMA_BF16_LDS) {
+            if (KIND == AG_LDSW64_ONLY) {
+                if (i == 0) acc[0][0] += 1.f;
+            } else if (ag_has_mfma(KIND)) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc[i], 0, 0, 0);
-            } else if (KIND == AG_MFMA_F32) {
+            } else if (KIND == AG_MFMA_F32 || KIND == AG_F32MFMA_LDSW64) {
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.u[i & 3]), __uint_as_float(b.u[i & 3]), acc[i], 0, 0, 0);
+            } else if (KIND == AG_VALU_V256 || KIND == AG_LDSW64_NOMFMA) {
+                const float sa = __uint_as_float(a.u[i & 3]), sb = __uint_as_float(b.u[(i + 1) & 3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] = acc[i][e] * sa + sb;
             } else {
                 const f32x2 s = {__uint_as_float(a.u[i & 3]), __uint_as_float(b.u[(i + 1) & 3])};
                 f32x2 lo = {acc[i][0], acc[i][1]}, hi = {acc[i][2], acc[i][3]};
@@ -202,6 +328,19 @@ static void launch_aggressor(int kind, int blocks, float *sink, int iters, unsig
     case AG_MFMA_F32: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_F32>), dim3(blocks), dim3(256), 0, s, sink, iters / 2, seed); break;
     case AG_PKVALU: hipLaunchKernelGGL((aggressor_kernel<AG_PKVALU>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
     case AG_MFMA_BF16_LDS: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_BF16_LDS>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_BF16_V256: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_BF16_V256>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_BF16_A512: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_BF16_A512>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_BF16_GLOBAL: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_BF16_GLOBAL>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_VALU_V256: hipLaunchKernelGGL((aggressor_kernel<AG_VALU_V256>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_BF16_LDSW: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_BF16_LDSW>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_LDSW64_NOMFMA: hipLaunchKernelGGL((aggressor_kernel<AG_LDSW64_NOMFMA>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW32: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW32>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW128: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW128>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_LDSW64_ONLY: hipLaunchKernelGGL((aggressor_kernel<AG_LDSW64_ONLY>), dim3(blocks), dim3(256), 0, s, sink, iters * 40, seed); break;
+    case AG_MFMA_LDSW2X32: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW2X32>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW16: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW16>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW96: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW96>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_F32MFMA_LDSW64: hipLaunchKernelGGL((aggressor_kernel<AG_F32MFMA_LDSW64>), dim3(blocks), dim3(256), 0, s, sink, iters / 2, seed); break;
     default: break;
     }
 }
@@ -211,6 +350,17 @@ extern "C" int pk_victim(int pk, const void *x, const void *g, const void *m, fl
     hipStream_t s = (hipStream_t)stream;
     if (pk) hipLaunchKernelGGL((victim_kernel<true>), dim3(groups), dim3(256), 0, s, (const float4 *)x, (const float4 *)g, (const float4 *)m, out, n_items, nb);
     else    hipLaunchKernelGGL((victim_kernel<false>), dim3(groups), dim3(256), 0, s, (const float4 *)x, (const float4 *)g, (const float4 *)m, out, n_items, nb);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pk_victim_real(int uniform_in_vgpr, const void *x, const void *g, const void *m, const float *w, const float *logs,
+                              const float *bias, void *dx, float *out, int groups, int n_items, int nb, void *stream) {
+    if (uniform_in_vgpr)
+        hipLaunchKernelGGL(victim_real_kernel<true>, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float4 *)x,
+                           (const float4 *)g, (const float4 *)m, w, logs, bias, (float4 *)dx, out, n_items, nb);
+    else
+        hipLaunchKernelGGL(victim_real_kernel<false>, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float4 *)x,
+                           (const float4 *)g, (const float4 *)m, w, logs, bias, (float4 *)dx, out, n_items, nb);
     return (int)hipGetLastError();
 }
 
