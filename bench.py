@@ -311,6 +311,16 @@ def main():
     if backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPUs visible")
     local %= max(1, torch.cuda.device_count())
+    # N > 1: every rank (and the autograd thread it spawns later, which inherits the mask) gets its own share of the cores
+    # this job may use — 8 ranks x (Python thread + backward thread) must not migrate over each other (host enqueue time is
+    # within 2x of the step's GPU time: DESIGN.md 4f).  BENCH_NO_PIN=1 leaves the affinity alone.
+    pinned = None
+    if world > 1 and os.environ.get("BENCH_NO_PIN") != "1" and hasattr(os, "sched_setaffinity"):
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per >= 1:
+            pinned = cores[local * per:(local + 1) * per]
+            os.sched_setaffinity(0, pinned)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -360,10 +370,16 @@ def main():
     fence()
     t0 = time.perf_counter()
     loss = None
+    host_s = 0.0                                    # time the host spends queueing a step (no synchronisation inside step_fn)
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step_fn()
+        host_s += time.perf_counter() - h0
     fence()
     dt = time.perf_counter() - t0
+    host_ms = torch.tensor([1e3 * host_s / args.steps], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(host_ms, op=dist.ReduceOp.MAX)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -398,6 +414,10 @@ def main():
                                + (f"{args.speakers} speakers (gin {args.gin}), " if args.speakers > 0 else "")
                                + "random-init weights, synthetic resident batch",
                    "global_batch": world * B, "parallelism": f"dp{world}", "launch": mode, "final_loss": loss_val},
+        # wall time the slowest rank's host needed to QUEUE a step (Python + C launch calls of forward, backward thread,
+        # optimizer); when it approaches ms_per_step the step is host-bound.  It can exceed the GPU time only transiently.
+        "host_enqueue_ms_per_step": round(float(host_ms), 3),
+        "host_cores_per_rank": (len(pinned) if pinned is not None else None),
     }
     if comm is not None:
         out["comm"] = comm

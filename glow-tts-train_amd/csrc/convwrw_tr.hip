@@ -1,5 +1,5 @@
 // convwrw_tr.hip — weight gradient of the WN stack's 5-tap convolutions on the bf16 matrix pipe, frame-major LDS images read
-// with gfx950's transposing LDS load (reference op: autograd of F.conv1d, /root/reference/glow_tts_train/layers.py:146).
+// with gfx950's transposing LDS load (reference op: autograd of F.conv1d, layers.py:146,156).
 //
 //   dW[tap][k][m] = sum_{b,t} x[b][k][t + tap - pad] * d[b][m][t]          (k: input channel, m: output channel)
 //
@@ -244,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     // ---- half-period schedule: group g multiplies its item i in phase 2 i + g and, in phase 2 i + g + 1, stores item i + 1 and
     // issues the loads of item i + 2 (item 0: group 0 before the loop, group 1 in phase 0).  A multiplying wave issues nothing
     // but LDS reads and MFMAs, at raised priority: the SIMD's other wave (storing) fills the issue slots the MFMAs leave.
+    GLOWTTS_TRACE_POINT_Z(0);
     if (tid < MR) rowacc[tid] = 0.f;
     if (n_my > 0) load_next();
     if (grp == 0 && n_my > 0) {
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
         if (n_my > 1) load_next();
     }
     lds_barrier();
+    GLOWTTS_TRACE_POINT_Z(1);
     for (int ph = 0; ph < 2 * n_max; ++ph) {
         const int rel = ph - grp;
         if (rel >= 0 && (rel & 1) == 0) {
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
         lds_barrier();
     }
 
+    GLOWTTS_TRACE_POINT_Z(2);
     // ---- the two groups' sums meet in LDS (the images are dead), group 0 sends the tile's atomics
     float *red = reinterpret_cast<float *>(smem_tr);
     if (grp == 1) {
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
             }
     }
     __syncthreads();
+    GLOWTTS_TRACE_POINT_Z(3);
     if (grp == 0) {
         const int lrow = lane & 15, lk = lane >> 4;
 #pragma unroll
@@ -322,6 +326,11 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
         }
     }
     if (do_bias && tid < MR && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
+#ifdef GLOWTTS_TRACE
+    GLOWTTS_TRACE_POINT_Z(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (trace builds only: point 10 = the atomics have left)
+    GLOWTTS_TRACE_POINT_Z(10);
+#endif
 }
 
 static int compute_units() {
@@ -360,6 +369,8 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     static const bool off = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '0'; }();
     if (off) return -1;
     if (p.taps != 5 || p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
+    static const bool mt4 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '4'; }();
+    if (ns == 3 && mt4 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0)) return launch_wrw_tr<3, 5, 4>(p, s);
     if (ns == 3) return launch_wrw_tr<3, 5, 2>(p, s);
     if (ns == 2) return launch_wrw_tr<2, 5, 2>(p, s);
     if (ns == 1) return launch_wrw_tr<1, 5, 2>(p, s);
@@ -367,3 +378,15 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
 }
 
 }  // namespace glowtts
+
+#ifdef GLOWTTS_TRACE
+extern "C" int glowtts_debug_trace_read_tr(unsigned long long *host, int n_words, int clear) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(glowtts::g_trace), (size_t)n_words * 8);
+    if (e != hipSuccess) return (int)e;
+    if (clear) {
+        static unsigned long long zeros[8192 * 16];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(glowtts::g_trace), zeros, sizeof(zeros));
+    }
+    return (int)e;
+}
+#endif

@@ -7,6 +7,7 @@ A private keyword ``x_len`` (``sum(x_mask)`` per utterance) may be passed by Flo
 """
 from __future__ import annotations
 
+import os
 import typing
 
 import torch
@@ -71,9 +72,10 @@ class ConvReluNorm(nn.Module):
 class WN(nn.Module):
     """WaveNet-style gated conv stack of the coupling network (reference layers.py:83-170).
 
-    The dilated k-tap and 1x1 convolutions run through PyTorch-ROCm (MIOpen / rocBLAS); the gate and the
-    residual/skip update are the fused HIP kernels ``glowtts_gate_*`` / ``glowtts_res_skip_*`` (one launch each
-    instead of the reference's slice / tanh / sigmoid / mul / add / mul chain and its ``zeros_like`` allocation).
+    Every convolution of the stack runs on the hand-written MFMA kernels (csrc/convgemm*.hip, convwrw_tr.hip): the
+    k-tap in-convolution with the gate (bias + conditioning + dropout + tanh * sigmoid) as its epilogue, the 1x1 res/skip
+    convolution with the residual / skip update as its epilogue, their backward-data and weight-gradient kernels; one
+    native call queues the whole stack each way (csrc/wn_stack.hip).  No MIOpen / rocBLAS kernel is involved.
     """
 
     def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
@@ -136,6 +138,9 @@ class ActNorm(nn.Module):
         super().__init__()
         self.channels = channels
         self.initialized = not ddi
+        # data-parallel runs: all-reduce the first batch's masked sums over the ranks before initialising (off by default =
+        # the reference: every rank uses its own batch and rank 0's result wins at the parameter broadcast)
+        self.ddi_all_reduce = os.environ.get("GLOWTTS_DDI_ALLREDUCE", "0") == "1"
         self.logs = nn.Parameter(torch.zeros(1, channels, 1))
         self.bias = nn.Parameter(torch.zeros(1, channels, 1))
 
@@ -163,6 +168,11 @@ class ActNorm(nn.Module):
         """First-batch statistics -> (logs, bias) so the output is zero-mean / unit-variance per channel."""
         with torch.no_grad():
             s1, s2, count = ops.actnorm_stats(x, ops.mask2d(x_mask))
+            if self.ddi_all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
+                packed = torch.cat([s1.flatten(), s2.flatten(), torch.as_tensor(count, dtype=s1.dtype, device=s1.device).flatten()])
+                torch.distributed.all_reduce(packed)
+                n = s1.numel()
+                s1, s2, count = packed[:n].view_as(s1), packed[n:2 * n].view_as(s2), packed[2 * n:]
             mean = s1 / count
             var = s2 / count - mean * mean
             half_log_var = 0.5 * torch.log(torch.clamp_min(var, 1e-6))

@@ -4,15 +4,15 @@ reference, glow_tts_train/__main__.py:83-88,268-271).
 One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm).  The reference leaves
 bucketing to DDP's default 25 MB buckets; here the buckets are *slices of the optimizer's flat gradient buffer*
 cut at flow-block boundaries (one [ActNorm, InvConvNear, CouplingBlock] block ~ 1.79 M parameters = 7.1 MB at the
-default width), so
+default width; TWO blocks per bucket, see default_bucket_key), so
 
   * nothing is copied into or out of bucket storage — RCCL reduces the gradient memory in place;
   * a block's all-reduce is issued the moment its last gradient has been accumulated, i.e. while the backward of
     the blocks below it (and then of the encoder) is still running; RCCL runs on its own stream, so the
     collective overlaps the remaining flow backward;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): twelve 7 MB messages + nine 1.5-3.6 MB encoder messages keep
-    each ring step large enough to be bandwidth- rather than latency-bound without delaying the first launch, and leave
-    only the lowest encoder layers' buckets (~10 MB) in flight when backward ends.
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): six 14.3 MB decoder messages + four encoder messages (28.8 MB
+    together) keep each ring step large enough to be bandwidth- rather than latency-bound without delaying the first
+    launch, and leave only the encoder head's bucket in flight when backward ends (10 collectives per step).
 
 Semantics match DDP: gradients are averaged over ranks (each rank normalises its loss by its own mask sums,
 utils.py:19-21,27) and parameters are broadcast from rank 0 once at start (which is also what makes rank 0's

@@ -22,10 +22,12 @@ def _free_port():
     return p
 
 
-def _build(models, optimize):
+def _build(models, optimize, full=False):
     kw = dict(n_vocab=148, hidden_channels=192, filter_channels=256, filter_channels_dp=64, out_channels=80,
               kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.0, n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1,
               n_block_layers=2, p_dropout_dec=0.0, n_split=4, n_sqz=2, window_size=4, mean_only=True, prenet=True)
+    if full:       # BASELINE configs[1] / [3] model: 12 flow blocks x 4 WN layers, 6 encoder layers -> the 6 + 4 = 10 real buckets
+        kw.update(filter_channels=768, filter_channels_dp=256, n_layers_enc=6, n_blocks_dec=12, n_block_layers=4)
     model = models.FlowGenerator(**kw).cuda().train()
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
@@ -38,8 +40,15 @@ def _build(models, optimize):
     return model, opt
 
 
-def _batch(rank, dev):
+def _batch(rank, dev, full=False):
     g = torch.Generator().manual_seed(500 + rank)
+    if full:       # B = 8 per rank at config-1 lengths (T_text 100, T_mel 400), ragged
+        b, tx, ty = 8, 100, 400
+        yl = torch.linspace(ty, ty // 2, b).long()
+        xl = (yl // 4).clamp(min=1)
+        x = torch.randint(1, 148, (b, tx), generator=g) * (torch.arange(tx)[None] < xl[:, None])
+        y = torch.randn(b, 80, ty, generator=g) * (torch.arange(ty)[None, None] < yl[:, None, None])
+        return x.to(dev), xl.to(dev), y.to(dev), yl.to(dev)
     b, tx, ty = 4, 24, 96
     x = torch.randint(1, 148, (b, tx), generator=g).to(dev)
     xl = torch.tensor([24, 20, 17, 12]).to(dev)
@@ -68,7 +77,7 @@ def _grads_of(model, opt, batch, reducer):
     return opt._optim.flat_g.detach().cpu().numpy().copy(), launched
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, full=False):
     import sys
     import torch.distributed as dist
 
@@ -85,28 +94,35 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(1234)                          # same initial weights on both ranks (broadcast also runs)
-        model, opt = _build(models, optimize)
+        model, opt = _build(models, optimize, full)
         dev = torch.device("cuda", 0)
         first = parallel.FlowBlockReducer(model, opt)
         first.broadcast_parameters(0)
         first.remove_hooks()                             # no reducer listens while the reference gradients are computed
         own = []
         for r in range(world):                           # every rank's un-reduced gradients, computed locally
-            g, _ = _grads_of(model, opt, _batch(r, dev), None)
+            g, _ = _grads_of(model, opt, _batch(r, dev, full), None)
             own.append(g)
         red = parallel.FlowBlockReducer(model, opt)
-        reduced, launched = _grads_of(model, opt, _batch(rank, dev), red)
-        q.put((rank, reduced, np.mean(own, axis=0), launched, len(red.buckets)))
+        reduced, launched = _grads_of(model, opt, _batch(rank, dev, full), red)
+        again, launched2 = _grads_of(model, opt, _batch(rank, dev, full), red)   # second step: hooks of announced parameters are gone
+        mean = np.mean(own, axis=0)
+        scale = float(np.abs(mean).max())
+        assert np.abs(again - reduced).max() <= 1e-5 * scale, "second reduced step differs from the first"
+        q.put((rank, reduced, mean, min(launched, launched2), len(red.buckets)))
     finally:
         dist.destroy_process_group()
 
 
-def test_flow_block_reducer_on_real_operators_two_ranks():
+@pytest.mark.parametrize("full", [False, True], ids=["small", "config1-model-10-buckets"])
+def test_flow_block_reducer_on_real_operators_two_ranks(full):
+    """`full`: the BASELINE configs[1] / [3] MODEL (12 blocks, 6 encoder layers: 6 + 4 = 10 buckets of 14 / 7 MB) with B = 8 per
+    rank — bucket completion order, the three producer streams and `finish()` with the real bucket list."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, full)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -114,11 +130,62 @@ def test_flow_block_reducer_on_real_operators_two_ranks():
         p.join(120)
         assert p.exitcode == 0
     (_, red0, mean0, launched0, nb), (_, red1, mean1, launched1, _) = res
+    assert nb == (10 if full else nb)
     assert launched0 >= nb - 3 and launched1 >= nb - 3, "buckets should be reduced while backward is still running"
     scale = float(np.abs(mean0).max())
     np.testing.assert_allclose(red0, red1, rtol=0, atol=1e-6 * scale, err_msg="ranks disagree after the all-reduce")
     # the reference is computed with the same kernels, so only the atomics' summation order differs
     np.testing.assert_allclose(red0, mean0, rtol=2e-3, atol=2e-5 * scale, err_msg="reduced gradients != mean of per-rank gradients")
+
+
+# ------------------------------------------------------------------------------------------------ ActNorm DDI across ranks
+def _ddi_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+
+    sys.path[:0] = [os.path.join(ROOT, "glow-tts-train_amd"), ROOT]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from glow_tts_train import layers
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        xs = [(torch.randn(3, 16, 40, generator=g) * (1 + r) + r).cuda() for r in range(world)]       # rank r's first batch
+        lens = torch.tensor([40, 31, 22]).cuda()
+        mask = (torch.arange(40).cuda()[None, None] < lens[:, None, None]).float()
+        out = {}
+        for flag in (False, True):
+            an = layers.ActNorm(16, ddi=True).cuda()
+            an.ddi_all_reduce = flag
+            an(xs[rank], mask)
+            out[flag] = (an.logs.detach().flatten().cpu(), an.bias.detach().flatten().cpu())
+        both = layers.ActNorm(16, ddi=True).cuda()       # what one process sees on the concatenated batch
+        both(torch.cat(xs), torch.cat([mask] * world))
+        q.put((rank, out, (both.logs.detach().flatten().cpu(), both.bias.detach().flatten().cpu())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_actnorm_ddi_all_reduce_flag_two_ranks():
+    """SURVEY Q10 / hard part 6: by default every rank initialises ActNorm from its OWN first batch and rank 0's parameters win
+    at the broadcast (the reference's behaviour); with `ddi_all_reduce` the masked sums are all-reduced first, so every rank
+    gets the statistics of the global batch."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddi_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, out0, glob), (_, out1, _) = res
+    assert not torch.allclose(out0[False][0], out1[False][0], atol=1e-3), "default: per-rank statistics"
+    for a, b, c in zip(out0[True], out1[True], glob):
+        assert torch.allclose(a, b, atol=1e-6) and torch.allclose(a, c, atol=1e-5), "flag: statistics of the global batch"
 
 
 # ------------------------------------------------------------------------------------------------ RCCL on one card

@@ -65,6 +65,8 @@ if split:
         call("glowtts_conv_split_weights", ptr(_use), _use.numel(), ptr(_planes[_use.data_ptr()]))
         _hip.conv_bind_planes(_use, _planes[_use.data_ptr()])
 rd = lib.glowtts_debug_trace_read_split if (split or which == "wrw5p") else lib.glowtts_debug_trace_read
+if which == "wrw5" and split and "wrw" in split and os.environ.get("GLOWTTS_WRW_TR", "1") != "0":
+    rd = lib.glowtts_debug_trace_read_tr            # the frame-major / transposed-read kernel (convwrw_tr.hip)
 rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 NW = 8192 * 16
 buf = np.zeros(NW, dtype=np.uint64)
