@@ -415,3 +415,76 @@ extern "C" int glowtts_adam_advance(float *state, float lr, float dim_model, flo
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, dim_model, warmup);
     GLOWTTS_LAUNCH_CHECK("glowtts_adam_advance");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// phoneme embedding (reference models.py:90,121: self.emb(x) * sqrt(H), transposed to (B, H, T)) and its backward
+//   fwd : out[b][h][t] = weight[ids[b][t]][h] * scale          (the (B, T, H) tensor and its transpose never exist)
+//   bwd : dweight[v][h] += scale * sum_{(b,t): ids == v} dout[b][h][t]
+// One workgroup per vocabulary entry in the backward: it collects its positions through LDS in chunks and sums them row by
+// row — a segment sum without atomics (torch's embedding_dense_backward sorts the ids with a device-wide partition first,
+// which also made the step un-capturable in a one-stream hipGraph).
+// ------------------------------------------------------------------------------------------------------------
+namespace glowtts {
+
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long *__restrict__ ids, const float *__restrict__ w, float scale,
+                                                        float *__restrict__ out, int T, int H, int V) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+    if (t >= T) return;
+    long id = ids[(long)b * T + t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float *row = w + id * H;
+    for (int h = wave; h < H; h += 4) out[((long)b * H + h) * T + t] = row[h] * scale;
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long *__restrict__ ids, const float *__restrict__ dout, float scale,
+                                                        float *__restrict__ dw, int B, int T, int H) {
+    constexpr int CH = 2048;
+    __shared__ int pos[CH];
+    __shared__ int count;
+    const int v = blockIdx.x, n = B * T;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                     // h = tid, tid + 256, ... (H <= 1024)
+    for (int c0 = 0; c0 < n; c0 += CH) {
+        if (threadIdx.x == 0) count = 0;
+        __syncthreads();
+        for (int i = c0 + threadIdx.x; i < min(n, c0 + CH); i += 256)
+            if (ids[i] == v) pos[atomicAdd(&count, 1)] = i;
+        __syncthreads();
+        const int m = count;
+        for (int j = 0; j < m; ++j) {
+            const int i = pos[j], b = i / T, t = i - b * T;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int h = threadIdx.x + 256 * k;
+                if (h < H) acc[k] += dout[((long)b * H + h) * T + t];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = threadIdx.x + 256 * k;
+        if (h < H && acc[k] != 0.f) dw[(long)v * H + h] += acc[k] * scale;
+    }
+}
+
+}  // namespace glowtts
+
+extern "C" int glowtts_embed_fwd(const long long *ids, const float *weight, float scale, float *out, int B, int T, int H, int V,
+                                 glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(ids && weight && out, "glowtts_embed_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && V > 0, "glowtts_embed_fwd: bad shape");
+    if ((long)B * T == 0) return 0;
+    hipLaunchKernelGGL(glowtts::embed_fwd_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long *>(ids), weight, scale, out, T, H, V);
+    GLOWTTS_LAUNCH_CHECK("glowtts_embed_fwd");
+}
+
+extern "C" int glowtts_embed_bwd(const long long *ids, const float *dout, float scale, float *dweight, int B, int T, int H, int V,
+                                 glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(ids && dout && dweight, "glowtts_embed_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && H <= 1024 && V > 0, "glowtts_embed_bwd: bad shape (H <= 1024)");
+    if ((long)B * T == 0) return 0;
+    hipLaunchKernelGGL(glowtts::embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long *>(ids),
+                       dout, scale, dweight, B, T, H);
+    GLOWTTS_LAUNCH_CHECK("glowtts_embed_bwd");
+}

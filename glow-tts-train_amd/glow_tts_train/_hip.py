@@ -87,6 +87,10 @@ _SIGNATURES = {
     "glowtts_conv_fwd_act": [_P, _L, _P, _P, _P, _P, _L, _P, _L] + [_I] * 11 + [_P, _F, _P, _F],
     "glowtts_chan_layernorm_fwd_ex": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd_ex": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_chan_layernorm_fwd_act": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P, _F, _I, _I, _I, _F],
+    "glowtts_chan_layernorm_bwd_act": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_embed_fwd": [_P, _P, _F, _P, _I, _I, _I, _I],
+    "glowtts_embed_bwd": [_P, _P, _F, _P, _I, _I, _I, _I],
     "glowtts_encoder_layer_fwd": [_P] * 7 + [_F] + [_P] * 12 + [_I] * 9 + [_F],
     "glowtts_encoder_layer_bwd": [_P] * 7 + [_F] + [_P] * 24 + [_I] * 9 + [_P],
     # `_io` forms (bf16 activation tensors in HBM: BASELINE configs[2]); the trailing int before the stream(s) is the io flag

@@ -281,34 +281,78 @@ def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = 
 
 
 class ChanLayerNormFn(Function):
-    """y = LayerNorm_over_channels(x + res) on (B, C, T) (reference layers.py:19-28 + the residual add before it)."""
+    """y = post(LayerNorm_over_channels(pre(x) + res)) on (B, C, T) (reference layers.py:19-28 + the residual add before it).
+    pre = ReLU when `relu_in` (duration predictor: conv -> ReLU -> LayerNorm, models.py:45-46); post = Dropout(ReLU(.)) by
+    `relu_out` / `p_drop` (pre-net: LayerNorm -> ReLU -> Dropout, layers.py:73-80; duration predictor: LayerNorm -> Dropout):
+    the element-wise neighbours of a norm ride in its kernels (csrc/norm.hip) — no launch, no tensor of their own."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, relu_in=False, relu_out=False, p_drop=0.0):
         x = f32(x.contiguous())
         res = None if res is None else f32(res.contiguous())
         B, C, T = x.shape
         y = torch.empty_like(x)
         stats = torch.empty(B, 2, T, device=x.device, dtype=torch.float32)
-        call("glowtts_chan_layernorm_fwd", ptr(x), ptr(res), ptr(gamma.detach().contiguous()), ptr(beta.detach().contiguous()),
-             ptr(y), ptr(stats), B, C, T, float(eps))
-        ctx.save_for_backward(x, res, stats)
+        keep, scale = None, 1.0
+        if p_drop > 0.0:
+            keep = torch.empty(B, C, T, device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p_drop)
+            scale = 1.0 / (1.0 - p_drop)
+        call("glowtts_chan_layernorm_fwd_act", ptr(x), ptr(res), None, None, 1.0, ptr(gamma.detach().contiguous()),
+             ptr(beta.detach().contiguous()), ptr(y), ptr(stats), int(relu_in), int(relu_out), ptr(keep), scale, B, C, T, float(eps))
+        ctx.save_for_backward(x, res, stats, *([y] if relu_out else []), *([keep] if keep is not None else []))
         ctx.params = (gamma, beta)
+        ctx.opts = (bool(relu_in), bool(relu_out), keep is not None, scale)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, res, stats = ctx.saved_tensors
+        relu_in, relu_out, has_keep, scale = ctx.opts
+        saved = list(ctx.saved_tensors)
+        x, res, stats = saved[:3]
+        y = saved[3] if relu_out else None
+        keep = saved[-1] if has_keep else None
         gamma, beta = ctx.params
         B, C, T = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         sink = _GradSink([gamma, beta])
-        call("glowtts_chan_layernorm_bwd", ptr(x), ptr(res), ptr(gamma.detach().contiguous()), ptr(stats), ptr(dy), ptr(dx),
-             ptr(sink.buf(0)), ptr(sink.buf(1)), B, C, T)
+        call("glowtts_chan_layernorm_bwd_act", ptr(x), ptr(res), None, None, 1.0, ptr(gamma.detach().contiguous()), ptr(stats),
+             ptr(y), ptr(dy), int(relu_in), int(relu_out), ptr(keep), scale, ptr(dx), None, ptr(sink.buf(0)), ptr(sink.buf(1)),
+             B, C, T)
         dg, db = sink.results()
-        return dx, (dx if res is not None else None), dg, db, None
+        return dx, (dx if res is not None else None), dg, db, None, None, None, None
+
+
+class EmbedFn(Function):
+    """h = weight[ids] * scale as (B, H, T) (reference models.py:121-122: `self.emb(x) * sqrt(hidden)` then the transpose): a
+    gather kernel, and in the backward one workgroup per vocabulary entry sums the gradient columns of its positions
+    (csrc/train_ops.hip) — torch's gather + mul + transpose copy and its sort-based embedding backward are gone."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, scale):
+        ids = ids.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.long()
+        B, T = ids.shape
+        V, H = weight.shape
+        out = torch.empty(B, H, T, device=weight.device, dtype=torch.float32)
+        call("glowtts_embed_fwd", ptr(ids), ptr(f32(weight.detach().contiguous())), float(scale), ptr(out), B, T, H, V)
+        ctx.save_for_backward(ids)
+        ctx.weight, ctx.scale = weight, float(scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        weight = ctx.weight
+        B, T = ids.shape
+        V, H = weight.shape
+        sink = _GradSink([weight])
+        call("glowtts_embed_bwd", ptr(ids), ptr(f32(dout.contiguous())), ctx.scale, ptr(sink.buf(0)), B, T, H, V)
+        (dw,) = sink.results()
+        return None, dw, None
 
 
 # Arithmetic of the WN-stack convolutions (see _hip.conv_math / include/glowtts_hip.h).  GLOWTTS_CONV_MATH =

@@ -34,10 +34,15 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x, res=None):
-        """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in)."""
+    def forward(self, x, res=None, relu_in=False, relu_out=False, p_drop=0.0):
+        """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in).
+        relu_in / relu_out / p_drop: the ReLU before and the ReLU / dropout after the norm, inside its kernels (3-D input)."""
+        if x.dim() == 3 and x.is_cuda:
+            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, relu_in, relu_out, p_drop)
+        if relu_in or relu_out or p_drop:
+            raise RuntimeError("LayerNorm: the fused ReLU / dropout forms need a (B, C, T) device tensor")
         if x.dim() == 3:
-            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps)
+            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, False, False, 0.0)     # (a CPU tensor raises in the op)
         # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
         v = x if res is None else x + res
         return F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
@@ -64,8 +69,11 @@ class ConvReluNorm(nn.Module):
     def forward(self, x, x_mask):
         m2 = ops.mask2d(x_mask)
         h = x
+        drop = self.relu_drop[1]
+        p = float(drop.p) if (self.training and drop.p > 0.0) else 0.0
         for conv, norm in zip(self.conv_layers, self.norm_layers):
-            h = self.relu_drop(norm(convops.conv1d(conv, h, m2, mask_in=True)))      # conv(h * mask): mask folded in
+            # conv(h * mask): the mask is folded into the conv; LayerNorm -> ReLU -> Dropout: ONE kernel (csrc/norm.hip)
+            h = norm(convops.conv1d(conv, h, m2, mask_in=True), relu_out=True, p_drop=p)
         return (x + convops.conv1d(self.proj, h)) * x_mask
 
 

@@ -22,6 +22,7 @@ from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 _actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
 _flow_block_apply = _hip.direct_apply(convops.FlowBlockFn)
 _align_expand_apply = _hip.direct_apply(ops.AlignExpandFn)
+_embed_apply = _hip.direct_apply(convops.EmbedFn)
 
 _LOGGER = logging.getLogger("glow_tts_train.models")
 
@@ -43,8 +44,10 @@ class DurationPredictor(nn.Module):
 
     def forward(self, x, x_mask):
         m2 = ops.mask2d(x_mask)
+        p = float(self.drop.p) if (self.training and self.drop.p > 0.0) else 0.0
         for conv, norm in ((self.conv_1, self.norm_1), (self.conv_2, self.norm_2)):
-            x = self.drop(norm(torch.relu(convops.conv1d(conv, x, m2, mask_in=True))))
+            # conv -> ReLU -> LayerNorm -> Dropout: the ReLU and the dropout ride in the norm's kernels (csrc/norm.hip)
+            x = norm(convops.conv1d(conv, x, m2, mask_in=True), relu_in=True, p_drop=p)
         return convops.conv1d(self.proj, x, m2, mask_in=True, mask_out=True)
 
 
@@ -85,7 +88,10 @@ class TextEncoder(nn.Module):
     def forward(self, x, x_lengths, g=None):
         for grp in self._conv_groups:
             grp.begin()
-        h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)          # [b, h, t]
+        if x.is_cuda:     # gather straight into (B, H, T), scaled; segment-sum backward (csrc/train_ops.hip)
+            h = _embed_apply(x, self.emb.weight, math.sqrt(self.hidden_channels))
+        else:
+            h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)      # [b, h, t]
         x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
         if self.prenet:
             h = self.pre(h, x_mask)

@@ -328,6 +328,25 @@ int glowtts_chan_layernorm_fwd_ex(const float *x, const float *res, const float 
 int glowtts_chan_layernorm_bwd_ex(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
                                   float drop_scale, const float *gamma, const float *stats, const float *dy, float *dx,
                                   float *dres, float *dgamma, float *dbeta, int B, int C, int T, glowtts_stream_t stream);
+/* `_act` forms (reference layers.py:73-80: pre-net conv -> LayerNorm -> ReLU -> Dropout; models.py:44-50: duration predictor
+ * conv -> ReLU -> LayerNorm -> Dropout): relu_in: the value normalised is relu(x) * mask_x (+ res ...) and dx is gated by x > 0;
+ * relu_out / (odrop (B, C, T) keep bytes, oscale): y = dropout(relu(LN(v))), the backward gates dy the same way (relu_out: through
+ * the sign of the stored y, which it then needs).  Everything else as the `_ex` forms. */
+int glowtts_chan_layernorm_fwd_act(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                   float drop_scale, const float *gamma, const float *beta, float *y, float *stats, int relu_in,
+                                   int relu_out, const unsigned char *odrop, float oscale, int B, int C, int T, float eps,
+                                   glowtts_stream_t stream);
+int glowtts_chan_layernorm_bwd_act(const float *x, const float *res, const float *mask_x, const unsigned char *drop,
+                                   float drop_scale, const float *gamma, const float *stats, const float *y, const float *dy,
+                                   int relu_in, int relu_out, const unsigned char *odrop, float oscale, float *dx, float *dres,
+                                   float *dgamma, float *dbeta, int B, int C, int T, glowtts_stream_t stream);
+/* Phoneme embedding (reference models.py:90,121: self.emb(x) * sqrt(hidden), transposed to (B, H, T)) and its backward:
+ * out[b][h][t] = weight[ids[b][t]][h] * scale;  dweight[v][h] += scale * sum over the positions holding id v of dout[b][h][t]
+ * (ids int64 (B, T); one workgroup per vocabulary entry, no atomics, no sort). */
+int glowtts_embed_fwd(const long long *ids, const float *weight, float scale, float *out, int B, int T, int H, int V,
+                      glowtts_stream_t stream);
+int glowtts_embed_bwd(const long long *ids, const float *dout, float scale, float *dweight, int B, int T, int H, int V,
+                      glowtts_stream_t stream);
 typedef struct glowtts_enc_layer {
     const float *wf_q, *wb_q, *b_q, *wf_k, *wb_k, *b_k, *wf_v, *wb_v, *b_v, *wf_o, *wb_o, *b_o;   /* attention 1x1 convs */
     const float *wf_1, *wb_1, *b_1, *wf_2, *wb_2, *b_2;                                           /* FFN convs */

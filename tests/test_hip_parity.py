@@ -919,6 +919,68 @@ def test_chan_layernorm_vs_torch(G, b, c, t, with_res):
     assert_close(ln.beta.grad, bo.grad, what="dbeta", rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("b,c,t", [(3, 192, 160), (2, 256, 37), (1, 5, 70)])
+@pytest.mark.parametrize("relu_in,relu_out,p", [(True, False, 0.0), (False, True, 0.0), (False, True, 0.5), (True, False, 0.3)])
+def test_chan_layernorm_fused_relu_dropout_vs_torch(G, b, c, t, relu_in, relu_out, p):
+    """The ReLU before / the ReLU and dropout after a LayerNorm inside its kernels (pre-net: layers.py:73-80; duration
+    predictor: models.py:44-50) against the torch composition with the SAME keep-mask (read back from where y is zero)."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(c + int(10 * p))
+    ln = G.layers.LayerNorm(c).cuda()
+    with torch.no_grad():
+        ln.gamma.copy_(torch.rand(c) + 0.5)
+        ln.beta.copy_(torch.randn(c) * 0.1)
+    x = (torch.randn(b, c, t) * 2 + 0.3).cuda().requires_grad_(True)
+    r = torch.randn(b, c, t).cuda()
+    y = ln(x, relu_in=relu_in, relu_out=relu_out, p_drop=p)
+    (y * r).sum().backward()
+
+    xo = x.detach().cpu().requires_grad_(True)
+    go, bo = ln.gamma.detach().cpu().requires_grad_(True), ln.beta.detach().cpu().requires_grad_(True)
+    v = O.channel_layer_norm(torch.relu(xo) if relu_in else xo, go, bo)
+    if relu_out:
+        v = torch.relu(v)
+    keep = torch.ones_like(v)
+    if p > 0:
+        # an element was dropped iff y is zero where the un-dropped value is not
+        keep = ((y.detach().cpu() != 0) | (v.detach() == 0)).float()
+        live = v.detach() != 0                                 # (where the value itself is zero the mask cannot be read back)
+        frac = float(keep[live].mean())
+        assert abs(frac - (1 - p)) < 0.05 + 2.0 / float(live.sum()) ** 0.5, frac
+        v = v * keep / (1 - p)
+    (v * r.cpu()).sum().backward()
+    assert_close(y, v, what="y", rtol=1e-4, atol=2e-5)
+    assert_close(x.grad, xo.grad, what="dx", rtol=1e-4, atol=4e-5)
+    assert_close(ln.gamma.grad, go.grad, what="dgamma", rtol=2e-4, atol=4e-4)
+    assert_close(ln.beta.grad, bo.grad, what="dbeta", rtol=2e-4, atol=4e-4)
+
+
+def test_embedding_kernels_vs_torch(G):
+    """h = emb(ids) * sqrt(H) as (B, H, T) (models.py:121-122) and its backward (segment sum per vocabulary entry)."""
+    from glow_tts_train import convops
+
+    torch.manual_seed(3)
+    V, H, B, T = 148, 192, 5, 67
+    w = torch.randn(V, H, device="cuda", requires_grad=True)
+    ids = torch.randint(0, V, (B, T), device="cuda")
+    ids[:, -9:] = 0                                           # a padded tail: id 0 repeated
+    r = torch.randn(B, H, T, device="cuda")
+    scale = H ** 0.5
+    out = convops.EmbedFn.apply(ids, w, scale)
+    (out * r).sum().backward()
+    w2 = w.detach().clone().requires_grad_(True)
+    ref = (torch.nn.functional.embedding(ids, w2) * scale).transpose(1, 2)
+    (ref * r).sum().backward()
+    assert torch.equal(out, ref.contiguous())
+    assert_close(w.grad, w2.grad, what="dweight", rtol=1e-5, atol=1e-4)
+    # the model's encoder uses it: one launch, no (B, T, H) tensor
+    enc = G.models.TextEncoder(V, 80, 192, 768, 256, 2, 1, 3, 0.0, window_size=4, mean_only=True, prenet=True).cuda()
+    xl = torch.full((B,), T, device="cuda")
+    x_m, _, logw, _ = enc(ids.clamp(min=1), xl)
+    assert torch.isfinite(x_m).all() and torch.isfinite(logw).all()
+
+
 def test_coupling_block_grouped_and_linked_paths_match_plain_autograd(G):
     """With pre-allocated .grad tensors (the flat-buffer optimizer's situation) a coupling block packs its start / end convs
     in one launch, un-packs their gradients in one launch (convops.ConvGroup) and shares ONE input-gradient buffer between

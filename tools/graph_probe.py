@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Why is hipGraph replay of the training step slower than eager launching?
 
-  python tools/graph_probe.py [steps=20]
+  python tools/graph_probe.py eager3|eager1|graph3|graph1 [steps=20]
 
-Times the configs[1] step four ways in ONE process — eager / graph replay, each with the three-stream schedule and with
+Times the configs[1] step four ways, one per process — eager / graph replay, each with the three-stream schedule and with
 everything on one stream (GLOWTTS_SIDE_STREAM=0) — and dumps the captured graphs (hipGraphDebugDotPrint): nodes, edges, how
 many nodes have more than one predecessor / successor (the cross-stream joins), the length of the longest dependency chain.
 If replay(3 streams) ~ replay(1 stream) ~ eager(1 stream), the graph executor is running the captured branches one after
@@ -55,16 +55,19 @@ def dot_stats(path):
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    """One measurement per process (an eager step AFTER a capture faulted once inside torch's embedding backward: keep
+    captures last): mode = eager3 | eager1 | graph3 | graph1."""
+    mode = sys.argv[1] if len(sys.argv) > 1 else "graph3"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     sys.argv = [sys.argv[0]]                        # bench.parse() reads the defaults: BASELINE configs[1]
     args = bench.parse()
+    os.environ["GLOWTTS_SIDE_STREAM"] = "1" if mode.endswith("3") else "0"
     dev = torch.device("cuda", 0)
     from glow_tts_train import _hip
-    from glow_tts_train.train import train_batch
+    from glow_tts_train.train import GraphedTrainStep, train_batch
 
     _hip.load()
     model, opt, batch, cfg = bench.build_workload(args, dev, 0)
-    step = lambda: train_batch(model, opt, batch, cfg.grad_clip, None)      # noqa: E731
 
     def timed(fn, n=steps):
         for _ in range(3):
@@ -76,34 +79,26 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / n
 
-    out_dir = os.path.join(ROOT, "gpurun_out")
-    os.makedirs(out_dir, exist_ok=True)
-    for streams in ("3", "1"):
-        os.environ["GLOWTTS_SIDE_STREAM"] = "1" if streams == "3" else "0"
-        eager = timed(step)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        host_state = (opt.step_num, opt.cur_lr)
-        g = torch.cuda.CUDAGraph()
-        g.enable_debug_mode()
-        t0 = time.perf_counter()
-        with torch.cuda.graph(g):
-            step()
-        cap_ms = 1e3 * (time.perf_counter() - t0)
-        opt.step_num, opt.cur_lr = host_state
-        dot = os.path.join(out_dir, f"graph_{streams}stream.dot")
-        g.debug_dump(dot)
-        replay = timed(g.replay)
-        print(f"{streams} stream(s): eager {eager:6.2f} ms/step   graph replay {replay:6.2f} ms/step   (capture {cap_ms:.0f} ms)", flush=True)
-        try:
+    if mode.startswith("eager"):
+        print(f"{mode}: {timed(lambda: train_batch(model, opt, batch, cfg.grad_clip, None)):6.2f} ms/step", flush=True)
+        return
+    g = GraphedTrainStep(model, opt, cfg.grad_clip, batch, warmup=2)
+    print(f"{mode}: {timed(lambda: g()):6.2f} ms/step (hipGraph replay)", flush=True)
+    try:                                            # structure of the captured graph, when the runtime can print it
+        g2 = torch.cuda.CUDAGraph()
+        g2.enable_debug_mode()
+        with torch.cuda.graph(g2):
+            train_batch(model, opt, g.static, cfg.grad_clip)
+        dot = os.path.join("/tmp", f"graph_{mode}.dot")
+        g2.debug_dump(dot)
+        if os.path.exists(dot):
             print("   graph:", dot_stats(dot), flush=True)
-        except Exception as exc:
-            print("   dot parse failed:", exc)
-        del g
+        else:
+            print("   hipGraphDebugDotPrint wrote no file")
+    except Exception as exc:
+        print("   graph dump failed:", type(exc).__name__, exc)
+    sys.stdout.flush()
+    os._exit(0)                                     # no teardown of captured graphs
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ r = torch.randn(B, C, T, device="cuda", requires_grad=True)
 g = torch.ones(C, device="cuda", requires_grad=True); b = torch.zeros(C, device="cuda", requires_grad=True)
 go = torch.randn(B, C, T, device="cuda")
 def step():
-    y = convops.ChanLayerNormFn.apply(x, r, g, b, 1e-4)
+    y = convops.ChanLayerNormFn.apply(x, r, g, b, 1e-4, False, False, 0.0)
     y.backward(go)
 for _ in range(5): step()
 torch.cuda.synchronize()
