@@ -279,6 +279,16 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 // ds_read_b128): even shifts are a choice of registers, odd shifts one v_alignbit per register.
 // Chunks stay 80 frames (T' = 400 = 5 chunks): the third step of a chunk is half zeros (d rows are zero past frame 80).
 // ---------------------------------------------------------------------------------------------------------------
+// An 8-byte LDS store as ds_write2_b32 of two adjacent dwords.  Not ds_write_b64 / ds_write2st64_b64: on gfx950 a kernel that
+// issues 64-bit LDS stores next to bf16 MFMAs makes OTHER waves' packed-fp32 VALU results wrong (DESIGN.md lesson 12; this library
+// has no packed-fp32 code, but a collective or a framework kernel on the same CU may).  hipcc does not count an asm LDS store:
+// the staging code waits for lgkmcnt(0) itself before its barriers.
+__device__ __forceinline__ void lds_store8(void *p, int lo, int hi) {
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1"
+                 :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) void *)p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void lds_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // PRE: x and d arrive as bf16 planes already (p.xpl / p.dpl, written by glowtts_split_planes or a producer's epilogue):
 // staging is then 8-byte loads straight into 8-byte LDS stores, with no vector work at all.
 template <int NS, int TAPS, int NGRP, int MT, bool PRE = false>
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                 const int q = idx % (XWL / 4), r = idx / (XWL / 4);
                 if (idx < X4)
 #pragma unroll
-                    for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = xpr[i][pl];
+                    for (int pl = 0; pl < NS; ++pl) lds_store8(Xh + pl * XPLANE + r * XP16 + q * 4, xpr[i][pl][0], xpr[i][pl][1]);
             }
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                         bsum[i] += sum;
                     }
 #pragma unroll
-                    for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = dpr[i][pl];
+                    for (int pl = 0; pl < NS; ++pl) lds_store8(Dh + pl * DPLANE + r * DP16 + q * 4, dpr[i][pl][0], dpr[i][pl][1]);
                 }
             }
             return;
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                     split_planes2<NS>(v[2], v[3], o23);
 #pragma unroll
                     for (int pl = 0; pl < NS; ++pl)
-                        *reinterpret_cast<i32x2 *>(Xh + pl * XPLANE + r * XP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
+                        lds_store8(Xh + pl * XPLANE + r * XP16 + q * 4, (int)o01[pl], (int)o23[pl]);
                 }
             }
         }
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                 split_planes2<NS>(v[2], v[3], o23);
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl)
-                    *reinterpret_cast<i32x2 *>(Dh + pl * DPLANE + r * DP16 + q * 4) = i32x2{(int)o01[pl], (int)o23[pl]};
+                    lds_store8(Dh + pl * DPLANE + r * DP16 + q * 4, (int)o01[pl], (int)o23[pl]);
             }
         }
     };
@@ -571,6 +581,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         load_chunk(0);
         store_chunk();
     }
+    lds_stores_done();
     __syncthreads();
     GLOWTTS_TRACE_POINT_Z(1);
     for (int c = 0; c < nchunks; ++c) {
@@ -582,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         if (c == 0) GLOWTTS_TRACE_POINT_Z(5);
         if (more) {
             store_chunk();
+            lds_stores_done();
             if (c == 0) GLOWTTS_TRACE_POINT_Z(6);
             __syncthreads();
         }

@@ -37,12 +37,10 @@ class LayerNorm(nn.Module):
     def forward(self, x, res=None, relu_in=False, relu_out=False, p_drop=0.0):
         """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in).
         relu_in / relu_out / p_drop: the ReLU before and the ReLU / dropout after the norm, inside its kernels (3-D input)."""
-        if x.dim() == 3 and x.is_cuda:
+        if x.dim() == 3:                               # (a CPU tensor raises in the operator: no fallback)
             return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, relu_in, relu_out, p_drop)
         if relu_in or relu_out or p_drop:
-            raise RuntimeError("LayerNorm: the fused ReLU / dropout forms need a (B, C, T) device tensor")
-        if x.dim() == 3:
-            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, False, False, 0.0)     # (a CPU tensor raises in the op)
+            raise RuntimeError("LayerNorm: the fused ReLU / dropout forms need a (B, C, T) tensor")
         # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
         v = x if res is None else x + res
         return F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)

@@ -88,10 +88,9 @@ class TextEncoder(nn.Module):
     def forward(self, x, x_lengths, g=None):
         for grp in self._conv_groups:
             grp.begin()
-        if x.is_cuda:     # gather straight into (B, H, T), scaled; segment-sum backward (csrc/train_ops.hip)
-            h = _embed_apply(x, self.emb.weight, math.sqrt(self.hidden_channels))
-        else:
-            h = (self.emb(x) * math.sqrt(self.hidden_channels)).transpose(1, -1)      # [b, h, t]
+        # [b, h, t]: gather straight into the transposed layout, scaled; segment-sum backward (csrc/train_ops.hip); a CPU tensor
+        # raises in the operator like everywhere else on the path
+        h = _embed_apply(x, self.emb.weight, math.sqrt(self.hidden_channels))
         x_mask = sequence_mask(x_lengths, h.size(2)).unsqueeze(1).to(h.dtype)
         if self.prenet:
             h = self.pre(h, x_mask)

@@ -241,9 +241,11 @@ enum { AG_NONE = 0, AG_MFMA_BF16 = 1, AG_MFMA_F32 = 2, AG_PKVALU = 3, AG_MFMA_BF
        AG_MFMA_LDSW2X32 = 14,      // kind 9 with a ds_write2_b32 (two dwords, two addresses)
        AG_MFMA_LDSW16 = 15,        // kind 9 with a ds_write_b16
        AG_MFMA_LDSW96 = 16,        // kind 9 with a ds_write_b96
-       AG_F32MFMA_LDSW64 = 17 };   // the ds_write_b64 beside FP32 MFMAs
-constexpr bool ag_has_lds(int k) { return k == 4 || (k >= 9 && k <= 17); }
-constexpr bool ag_has_mfma(int k) { return k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 9 || k == 11 || k == 12 || k == 14 || k == 15 || k == 16; }
+       AG_F32MFMA_LDSW64 = 17,     // the ds_write_b64 beside FP32 MFMAs
+       AG_MFMA_LDSW2X32_ADJ = 18,  // ds_write2_b32 of two ADJACENT dwords (the same 8 bytes as a ds_write_b64)
+       AG_MFMA_LDSW2ST64_B64 = 19 };   // ds_write2st64_b64 (two 8-byte pieces)
+constexpr bool ag_has_lds(int k) { return k == 4 || (k >= 9 && k <= 19); }
+constexpr bool ag_has_mfma(int k) { return k == 1 || k == 4 || k == 5 || k == 6 || k == 7 || k == 9 || k == 11 || k == 12 || k == 14 || k == 15 || k == 16 || k == 18 || k == 19; }
 static const char *kAgName[AG_COUNT] = {"none", "bf16 MFMA (registers only)", "fp32 MFMA (registers only)",
                                         "packed-fp32 VALU only", "bf16 MFMA + ds_read_b128 from its own LDS"};
 
@@ -282,6 +284,14 @@ __global__ __launch_bounds__(256, KIND == 6 ? 1 : 2) void aggressor_kernel(float
             if (KIND == AG_MFMA_LDSW2X32) {
                 float *q = lds + ((tid + it * 8) & 2047);
                 asm volatile("ds_write2_b32 %0, %1, %2 offset1:64" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float *)q), "v"(l[1]), "v"(l[2]) : "memory");
+            }
+            if (KIND == AG_MFMA_LDSW2X32_ADJ) {
+                float *q = lds + ((tid * 2 + it * 8) & 4094);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float *)q), "v"(l[1]), "v"(l[2]) : "memory");
+            }
+            if (KIND == AG_MFMA_LDSW2ST64_B64) {
+                float *q = lds + ((tid * 2 + it * 8) & 1022);
+                asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) float *)q), "v"(f32x2{l[1], l[2]}), "v"(f32x2{l[3], l[0]}) : "memory");
             }
             if (KIND == AG_MFMA_LDSW16) reinterpret_cast<unsigned short *>(lds)[(tid + it * 8) & 8191] = (unsigned short)__float_as_uint(l[1]);
             if (KIND == AG_MFMA_LDSW96) {
@@ -340,6 +350,8 @@ static void launch_aggressor(int kind, int blocks, float *sink, int iters, unsig
     case AG_MFMA_LDSW2X32: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW2X32>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
     case AG_MFMA_LDSW16: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW16>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
     case AG_MFMA_LDSW96: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW96>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW2X32_ADJ: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW2X32_ADJ>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
+    case AG_MFMA_LDSW2ST64_B64: hipLaunchKernelGGL((aggressor_kernel<AG_MFMA_LDSW2ST64_B64>), dim3(blocks), dim3(256), 0, s, sink, iters, seed); break;
     case AG_F32MFMA_LDSW64: hipLaunchKernelGGL((aggressor_kernel<AG_F32MFMA_LDSW64>), dim3(blocks), dim3(256), 0, s, sink, iters / 2, seed); break;
     default: break;
     }

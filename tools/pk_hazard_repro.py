@@ -62,7 +62,8 @@ def main():
             ("synthetic LDS reads + ds_write_b64, fp32 VALU, no MFMA", synth(10)), ("synthetic bf16 MFMA loop + ds_write_b32", synth(11)),
             ("synthetic bf16 MFMA loop + ds_write_b128", synth(12)), ("synthetic ds_write_b64 only", synth(13)),
             ("synthetic bf16 MFMA loop + ds_write2_b32", synth(14)), ("synthetic bf16 MFMA loop + ds_write_b16", synth(15)),
-            ("synthetic bf16 MFMA loop + ds_write_b96", synth(16)), ("synthetic FP32 MFMA loop + ds_write_b64", synth(17))]
+            ("synthetic bf16 MFMA loop + ds_write_b96", synth(16)), ("synthetic FP32 MFMA loop + ds_write_b64", synth(17)),
+            ("synthetic bf16 MFMA loop + ds_write2_b32 adjacent", synth(18)), ("synthetic bf16 MFMA loop + ds_write2st64_b64", synth(19))]
 
     print("== part 1: minimal victim (bitwise against its own solo run)")
     groups = 40

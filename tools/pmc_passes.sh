@@ -3,7 +3,7 @@
 # combined with sys/hip/hsa traces (gpurun refuses that) — one stream so that every dispatch is counted in isolation.
 #   tools/pmc_passes.sh <tag>      ->  gpurun_out/<tag>_pmc_<group>.csv  (+ the kernel-trace stats of a plain pass)
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -25,3 +25,12 @@ echo "[pmc] kernel-trace pass" >&2
 rocprofv3 --kernel-trace --stats -d "$D" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --steps 10 --warmup 3 ${BENCH_EXTRA:-} > "$OUT/${TAG}_trace.bench.json" 2> "$OUT/${TAG}_trace.err"
 DB=$(find "$D" -name '*.db' | head -1)
 python3 "$ROOT/tools/rocpd_summary.py" kernels "$DB" "$OUT/${TAG}_kernel_stats.csv"
+# a second, shorter kernel-trace pass: tools/launch_census.py takes the difference of the two (launches per step)
+D=/tmp/pmc_${TAG}_trace5
+rm -rf "$D"
+echo "[pmc] kernel-trace pass (5 steps)" >&2
+rocprofv3 --kernel-trace --stats -d "$D" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --steps 5 --warmup 3 ${BENCH_EXTRA:-} > "$OUT/${TAG}_trace5.bench.json" 2> "$OUT/${TAG}_trace5.err"
+DB=$(find "$D" -name '*.db' | head -1)
+python3 "$ROOT/tools/rocpd_summary.py" kernels "$DB" "$OUT/${TAG}_kernel_stats_5steps.csv"
+python3 "$ROOT/tools/launch_census.py" "$OUT/${TAG}_kernel_stats_5steps.csv" 5 "$OUT/${TAG}_kernel_stats.csv" 10 > "$OUT/${TAG}_launch_census.txt"
+python3 "$ROOT/tools/pmc_combine.py" "$OUT/${TAG}" "$OUT/${TAG}_pmc.json"
