@@ -48,14 +48,22 @@ struct WrwTrGeom {
     static constexpr int XPL = XR * XP, DPL = CF * DP;  // one plane image
     static_assert(TAPS - 1 + OFF < 8 && (XP / 4) % 8 == 4 && (DP / 4) % 8 == 4, "window and bank layout");
     static constexpr size_t group_bytes(int ns) { return (size_t)ns * (XPL + DPL); }
-    static constexpr size_t lds_bytes(int ns) {
-        const size_t img = 2 * group_bytes(ns), red = (size_t)TAPS * MT * 4 * 256 * 4;
+    static constexpr size_t lds_bytes(int ns, bool w32 = false) {
+        const size_t img = 2 * group_bytes(ns), red = (size_t)TAPS * (w32 ? 16 : MT * 4) * 256 * 4;
         return (img > red ? img : red) + MR * sizeof(float);
     }
 };
 
-template <int NS, int TAPS, int MT>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// W32: the multiply phase on v_mfma_f32_32x32x16_bf16 — a wave owns 32 x channels x 32 d channels of ONE 32-frame step of the chunk
+// (waves 0, 1: the tile's two k halves on step 0; waves 2, 3: on step 1), 60 MFMAs of 32 cycles per chunk instead of 120 of 16.
+// Same matrix work; but a 32x32x16 MFMA holds the SIMD's vector issue port 8 of its 32 cycles where the 16x16x32 one holds it 8 of
+// 16, so the SIMD's OTHER wave — splitting and storing the next chunk, ~2 vector instructions per 16 MFMA cycles, the pace-setter of
+// the W32 = false form — gets three quarters of the issue slots instead of half.  Four partial sums per output meet in LDS.
+template <int NS, int TAPS, int MT, bool W32 = false>
 __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
+    static_assert(!W32 || MT == 2, "the 32x32 form is the 64 x 32 tile");
     using G = WrwTrGeom<TAPS, MT>;
     constexpr int MR = G::MR, CF = G::CF, PAD = G::PAD, OFF = G::OFF, XR = G::XR, XP = G::XP, DP = G::DP;
     constexpr int XPL = G::XPL, DPL = G::DPL;
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, wave = (tid >> 6) & 3, lane = tid & 63;
     char *Xg = smem_tr + grp * G::group_bytes(NS);
     char *Dg = Xg + NS * XPL;
-    float *rowacc = reinterpret_cast<float *>(smem_tr + G::lds_bytes(NS) - MR * sizeof(float));
+    float *rowacc = reinterpret_cast<float *>(smem_tr + G::lds_bytes(NS, W32) - MR * sizeof(float));
 
     // ---- which tile, which frames (workgroups numbered XCD-major: the splits of one tile share frames with the other tiles
     // of the same split, which then sit on one or two XCDs' L2s)
@@ -84,11 +92,16 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     const int n_my = (n_split - grp + 1) / 2;                              // this group: items c0 + grp, c0 + grp + 2, ...
     const int n_max = (n_split + 1) / 2;
 
-    f32x4 acc[TAPS][MT];
+    f32x4 acc[W32 ? 1 : TAPS][W32 ? 1 : MT];
+    f32x16 acc32[W32 ? TAPS : 1];
 #pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp)
+    for (int tp = 0; tp < (W32 ? 1 : TAPS); ++tp)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (W32 ? 1 : MT); ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < (W32 ? TAPS : 1); ++tp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[tp][e] = 0.f;
 
     const bool do_bias = (p.dbias != nullptr) && (kt == 0);
     const int xbytes = (int)(((long)(p.B - 1) * p.x_bs + (long)p.Cin * p.T) * 4);
@@ -202,23 +215,65 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     const int lrow16 = 8 * (lg & 1) + 2 * lq + (lg >> 1);
     const char *xl = Xg + lrow16 * XP + wave * 32 + lp * 8;
     const char *dl = Dg + lrow16 * DP + lp * 8;
-    auto compute = [&](int nsteps) {
+    // W32 addresses: lane group g = lane >> 4: channel half cg = g & 1 (16 of the wave's 32 channels), k slot h = g >> 1; the
+    // 16 frames of a substep map to (h, element j) as 4 (j & 3) + 2 h + (j >> 2): a transposed read takes 4 rows spaced by FOUR
+    // (36 x 4 and 20 x 4 dwords are 16 mod 64), its two 16-lane groups neighbouring 32-byte column chunks: 64 banks, no conflict
+    const int kh = wave & 1, fh = wave >> 1;
+    const char *xl32 = Xg + (4 * lq + 2 * (lg >> 1)) * XP + (32 * kh + 16 * (lg & 1)) * 2 + lp * 8;
+    const char *dl32 = Dg + (4 * lq + 2 * (lg >> 1)) * DP + (16 * (lg & 1)) * 2 + lp * 8;
+    auto compute32 = [&](int nsteps) {
+        if (fh >= nsteps) return;
 #pragma unroll
-        for (int s = 0; s < CF / 32; ++s) {
-            if (s < nsteps) {
+        for (int ss = 0; ss < 2; ++ss) {
+            const int f0 = fh * 32 + ss * 16;              // (fh is wave-uniform: two copies of the loop body)
+            bf16x8 bv[NS];
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) {
+                const char *q = dl32 + pl * DPL + f0 * DP;
+                bv[pl] = lds_tr8(q, q + DP);
+            }
+            bf16x8 av[2][NS];
+            auto afetch = [&](int tp, int sl) {
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl) {
+                    const char *q = xl32 + pl * XPL + (f0 + tp + OFF) * XP;
+                    av[sl][pl] = lds_tr8(q, q + XP);
+                }
+            };
+            afetch(0, 0);
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+                if (tp + 1 < TAPS) afetch(tp + 1, (tp + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < n_products(NS); ++k)
+                    acc32[W32 ? tp : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[tp & 1][product_a(NS, k)], bv[product_b(NS, k)],
+                                                                                 acc32[W32 ? tp : 0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto compute = [&](int nsteps) {
+        if constexpr (W32) { compute32(nsteps); return; }
+        // (a software pipeline ACROSS the two steps — the next step's operands read before the last tap's MFMAs — was measured
+        //  slower: 60.6 us of main loop against 52.4; 40 more registers and a longer dependence-free window did not help the
+        //  scheduler)
+#pragma unroll
+        for (int s_ = 0; s_ < CF / 32; ++s_) {
+            if (s_ < nsteps) {
                 bf16x8 bv[MT][NS];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int pl = 0; pl < NS; ++pl) {
-                        const char *q = dl + pl * DPL + (s * 32) * DP + i * 32;
+                        const char *q = dl + pl * DPL + (s_ * 32) * DP + i * 32;
                         bv[i][pl] = lds_tr8(q, q + 16 * DP);
                     }
                 bf16x8 av[2][NS];
                 auto afetch = [&](int tp, int sl) {
 #pragma unroll
                     for (int pl = 0; pl < NS; ++pl) {
-                        const char *q = xl + pl * XPL + (s * 32 + tp + OFF) * XP;
+                        const char *q = xl + pl * XPL + (s_ * 32 + tp + OFF) * XP;
                         av[sl][pl] = lds_tr8(q, q + 16 * XP);
                     }
                 };
@@ -231,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int k = 0; k < n_products(NS); ++k)
-                            acc[tp][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[tp & 1][product_a(NS, k)], bv[i][product_b(NS, k)],
-                                                                                 acc[tp][i], 0, 0, 0);
+                            acc[W32 ? 0 : tp][W32 ? 0 : i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                av[tp & 1][product_a(NS, k)], bv[i][product_b(NS, k)], acc[W32 ? 0 : tp][W32 ? 0 : i], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -243,7 +298,9 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
 
     // ---- half-period schedule: group g multiplies its item i in phase 2 i + g and, in phase 2 i + g + 1, stores item i + 1 and
     // issues the loads of item i + 2 (item 0: group 0 before the loop, group 1 in phase 0).  A multiplying wave issues nothing
-    // but LDS reads and MFMAs, at raised priority: the SIMD's other wave (storing) fills the issue slots the MFMAs leave.
+    // but LDS reads and MFMAs; the SIMD's other wave (storing) fills the issue slots the MFMAs leave and runs at RAISED priority:
+    // per half period the storing wave needs ~3 000 cycles, the multiplying one ~2 650 (trace build, tools/trace_conv.py wrw5:
+    // whichever side is raised, the sum stays — the SIMD's issue port and the LDS are shared — but the storing side is the longer).
     GLOWTTS_TRACE_POINT_Z(0);
     if (tid < MR) rowacc[tid] = 0.f;
     if (n_my > 0) load_next();
@@ -253,35 +310,53 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     }
     lds_barrier();
     GLOWTTS_TRACE_POINT_Z(1);
+#ifdef GLOWTTS_TRACE   // where a half period goes (shader cycles, summed over the loop; wave 0 of each group): slots 5-8 / 9, 11-13
+    unsigned long long tr_mul = 0, tr_mul_wait = 0, tr_store = 0, tr_store_wait = 0;
+#define TR_NOW() __builtin_readcyclecounter()
+#else
+#define TR_NOW() 0ull
+#endif
     for (int ph = 0; ph < 2 * n_max; ++ph) {
         const int rel = ph - grp;
+        [[maybe_unused]] const unsigned long long t_a = TR_NOW();
+        [[maybe_unused]] bool mul = false;
         if (rel >= 0 && (rel & 1) == 0) {
+            mul = true;
             if ((rel >> 1) < n_my) {
-                __builtin_amdgcn_s_setprio(1);
+                if (p.xs_pitch == 0) __builtin_amdgcn_s_setprio(1);
                 compute(steps_staged);
-                __builtin_amdgcn_s_setprio(0);
+                if (p.xs_pitch == 0) __builtin_amdgcn_s_setprio(0);
             }
         } else {
             const int i = (rel + 1) >> 1;
             if (i < n_my && (i > 0 || grp == 1)) {
+                if (p.xs_pitch == 2) __builtin_amdgcn_s_setprio(1);
                 stage();
                 if (i + 1 < n_my) load_next();
+                if (p.xs_pitch == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
+        [[maybe_unused]] const unsigned long long t_b = TR_NOW();
         lds_barrier();
+#ifdef GLOWTTS_TRACE
+        const unsigned long long t_c = TR_NOW();
+        if (mul) { tr_mul += t_b - t_a; tr_mul_wait += t_c - t_b; } else { tr_store += t_b - t_a; tr_store_wait += t_c - t_b; }
+#endif
     }
+#ifdef GLOWTTS_TRACE
+    if (gt == 0) {
+        unsigned long long *rec = g_trace + ((blockIdx.z * gridDim.x + blockIdx.x) & 8191) * 16;
+        const int o = grp == 0 ? 5 : 9;
+        rec[o] = tr_mul;
+        rec[grp == 0 ? 6 : 11] = tr_mul_wait;
+        rec[grp == 0 ? 7 : 12] = tr_store;
+        rec[grp == 0 ? 8 : 13] = tr_store_wait;
+    }
+#endif
 
     GLOWTTS_TRACE_POINT_Z(2);
     // ---- the two groups' sums meet in LDS (the images are dead), group 0 sends the tile's atomics
     float *red = reinterpret_cast<float *>(smem_tr);
-    if (grp == 1) {
-#pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) red[((tp * MT + i) * 4 + reg) * 256 + gt] = acc[tp][i][reg];
-    }
     if (do_bias) {
 #pragma unroll
         for (int r = 0; r < NDR; ++r)
@@ -292,37 +367,99 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
                 atomicAdd(rowacc + 2 * cp + 1, bs1[r]);
             }
     }
-    __syncthreads();
-    GLOWTTS_TRACE_POINT_Z(3);
-    if (grp == 0) {
-        const int lrow = lane & 15, lk = lane >> 4;
-#pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[tp][i][reg] += red[((tp * MT + i) * 4 + reg) * 256 + gt];
-        if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
-            const int lane_off = (wave * 16 + lk * 4) * p.M + lrow;          // per lane, once; the rest of an address is uniform
+    if constexpr (W32) {
+        // four partial sums per output: (group, frame half).  Group 1 -> LDS -> the same wave of group 0; then group 0's
+        // step-1 waves -> LDS -> its step-0 waves, which send the atomics (128 lanes x 80 values = the tile once)
+        if (grp == 1) {
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    float *u = p.dwp + ((long)tp * p.Cin + k0 + reg) * p.M + m0;
+                for (int e = 0; e < 16; ++e) red[(tp * 16 + e) * 256 + gt] = acc32[tp][e];
+        }
+        __syncthreads();
+        if (grp == 0) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) atomicAdd(u + i * 16 + lane_off, acc[tp][i][reg]);
-                }
-        } else {
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[tp][e] += red[(tp * 16 + e) * 256 + gt];
+        }
+        __syncthreads();
+        if (grp == 0 && fh == 1) {
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[(tp * 16 + e) * 128 + (gt - 128)] = acc32[tp][e];
+        }
+        __syncthreads();
+        GLOWTTS_TRACE_POINT_Z(3);
+        if (grp == 0 && fh == 0) {
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc32[tp][e] += red[(tp * 16 + e) * 128 + gt];
+            // C layout of the 32x32 MFMA: column (d channel) = lane & 31, row (x channel) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+            const int lm = lane & 31, lr4 = 4 * (lane >> 5);
+            if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
+                const int lane_off = lr4 * p.M + lm;
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float *u = p.dwp + ((long)tp * p.Cin + k0 + 32 * kh + (e & 3) + 8 * (e >> 2)) * p.M + m0;
+                        atomicAdd(u + lane_off, acc32[tp][e]);
+                    }
+            } else {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int k = k0 + 32 * kh + (e & 3) + 8 * (e >> 2) + lr4;
+                        const int m = m0 + lm;
+                        if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc32[tp][e]);
+                    }
+            }
+        }
+    } else {
+        if (grp == 1) {
 #pragma unroll
             for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[((tp * MT + i) * 4 + reg) * 256 + gt] = acc[tp][i][reg];
+        }
+        __syncthreads();
+        GLOWTTS_TRACE_POINT_Z(3);
+        if (grp == 0) {
+            const int lrow = lane & 15, lk = lane >> 4;
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[tp][i][reg] += red[((tp * MT + i) * 4 + reg) * 256 + gt];
+            if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
+                const int lane_off = (wave * 16 + lk * 4) * p.M + lrow;      // per lane, once; the rest of an address is uniform
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const int k = k0 + wave * 16 + lk * 4 + reg;
-                        const int m = m0 + i * 16 + lrow;
-                        if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+                        float *u = p.dwp + ((long)tp * p.Cin + k0 + reg) * p.M + m0;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) atomicAdd(u + i * 16 + lane_off, acc[tp][i][reg]);
                     }
+            } else {
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int k = k0 + wave * 16 + lk * 4 + reg;
+                            const int m = m0 + i * 16 + lrow;
+                            if (k < p.Cin && m < p.M) atomicAdd(p.dwp + ((long)tp * p.Cin + k) * p.M + m, acc[tp][i][reg]);
+                        }
+            }
         }
     }
     if (do_bias && tid < MR && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowacc[tid]);
@@ -346,21 +483,23 @@ static int compute_units() {
     return n[dev];
 }
 
-template <int NS, int TAPS, int MT>
+template <int NS, int TAPS, int MT, bool W32 = false>
 static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     using G = WrwTrGeom<TAPS, MT>;
-    constexpr size_t lds = G::lds_bytes(NS);
+    constexpr size_t lds = G::lds_bytes(NS, W32);
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
     static LdsLimit attr_max_e;
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_tr_kernel<NS, TAPS, MT>), lds, "glowtts_conv_wrw (tr)")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_tr_kernel<NS, TAPS, MT, W32>), lds, "glowtts_conv_wrw (tr)")) return rc_;
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + G::MR - 1) / G::MR);
     const int total = p.B * ((p.T + G::CF - 1) / G::CF);
     int splits = compute_units() / tiles;               // ONE workgroup (8 waves) per CU, one round
     if (splits > (total + 1) / 2) splits = (total + 1) / 2;      // a workgroup wants an item for each of its two groups
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
+    static const int prio_mode = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_PRIO"); return e ? std::atoi(e) : 2; }();
+    p.xs_pitch = prio_mode;          // (tuning switch: 0 = the multiplying waves run at raised priority, 1 = nobody, 2 = the storing waves)
     dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
-    hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT>), grid, dim3(512), lds, s, p);
+    hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT, W32>), grid, dim3(512), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (tr)");
 }
 
@@ -370,6 +509,11 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     if (off) return -1;
     if (p.taps != 5 || p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
     static const bool mt4 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '4'; }();
+    // default: the 32x32x16 form with the storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per
+    // back-to-back launch; 16x16x32 form 66.3; either form with the MULTIPLYING waves raised 67-69); GLOWTTS_WRW_TR=1 selects the
+    // 16x16x32 form
+    static const bool w16 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '1'; }();
+    if (ns == 3 && !w16 && !mt4) return launch_wrw_tr<3, 5, 2, true>(p, s);
     if (ns == 3 && mt4 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0)) return launch_wrw_tr<3, 5, 4>(p, s);
     if (ns == 3) return launch_wrw_tr<3, 5, 2>(p, s);
     if (ns == 2) return launch_wrw_tr<2, 5, 2>(p, s);

@@ -86,7 +86,7 @@ t00 = tr[:, 0].min()
 us = lambda a: (a - t00) / 100.0      # 100 MHz wall clock -> microseconds
 print(f"{which}: {len(tr)} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us, "
       f"first start -> last end {us(tr[:, 10].max()):.1f} us")
-cols = [c for c in range(11) if (tr[:, c] > 0).all()]
+cols = [c for c in ((0, 1, 2, 3, 4, 10) if rd is getattr(lib, "glowtts_debug_trace_read_tr", None) else range(11)) if (tr[:, c] > 0).all()]
 print("trace point : " + "  ".join(f"{c:>7d}" for c in cols))
 for name, f in (("min", np.min), ("median", np.median), ("max", np.max)):
     print(f"abs {name:7s}: " + "  ".join(f"{f(us(tr[:, c])):7.1f}" for c in cols))
@@ -97,7 +97,12 @@ for c in cols:
         d = (tr[:, c] - tr[:, prev]) / 100.0
         print(f"  {prev:2d} -> {c:2d}: min {d.min():6.1f}  median {np.median(d):6.1f}  max {d.max():6.1f}")
     prev = c
-if (tr[:, 11] > 0).all():
+if rd is getattr(lib, "glowtts_debug_trace_read_tr", None):
+    # convwrw_tr.hip: shader cycles of the main loop by role, summed over a workgroup's half periods (wave 0 of each group)
+    for g, cols_ in (("group 0", (5, 6, 7, 8)), ("group 1", (9, 11, 12, 13))):
+        v = [np.median(tr[:, c]) for c in cols_]
+        print(f"main loop, {g}: multiply {v[0]:.0f} + barrier wait {v[1]:.0f}; store {v[2]:.0f} + barrier wait {v[3]:.0f}  (cycles, median)")
+elif (tr[:, 11] > 0).all():
     cyc = (tr[:, 12] - tr[:, 11]).astype(float)
     wall = (tr[:, 4] - tr[:, 3]) / 100.0
     print(f"shader clock over the 3 -> 4 phase: median {np.median(cyc / wall):.0f} cycles/us")
