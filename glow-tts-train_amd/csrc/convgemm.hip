@@ -764,16 +764,45 @@ __device__ __forceinline__ void unpack_weight_grad_row(const float *__restrict__
         }
         return;
     }
+    // the row of dW is a gather with stride Cout (one 4-byte element per cache line): read it ONCE and keep it in registers
+    // between the dot product and the update (rows up to 12 x 256 elements: every convolution of the model)
+    constexpr int KEEP = 12;
+    float wreg[KEEP], vreg[KEEP];
+    const bool keep = n <= KEEP * 256;
     float dot = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int c = i / taps, tap = i - c * taps;
-        dot += dwp[((long)tap * Cin + c) * Cout + o] * vo[i];
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            wreg[k] = 0.f;
+            vreg[k] = 0.f;
+            if (i < n) {
+                const int c = i / taps, tap = i - c * taps;
+                wreg[k] = dwp[((long)tap * Cin + c) * Cout + o];
+                vreg[k] = vo[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) dot += wreg[k] * vreg[k];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = i / taps, tap = i - c * taps;
+            dot += dwp[((long)tap * Cin + c) * Cout + o] * vo[i];
+        }
     }
     dot = block_sum_256(dot, red);
     const float inv = inv_norm[o];
     const float gn = g[o] * inv;
     if (threadIdx.x == 0) dg[o] += dot * inv;
     const float proj = dot * inv * inv;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n) dv[(long)o * n + i] += gn * (wreg[k] - vreg[k] * proj);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += 256) {
         const int c = i / taps, tap = i - c * taps;
         dv[(long)o * n + i] += gn * (dwp[((long)tap * Cin + c) * Cout + o] - vo[i] * proj);
@@ -881,18 +910,20 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
                          (!p.mask_in || aligned16(p.mask)) && ((p.taps - 1) * p.dil <= 12) &&
                          (EPI != EPI_GATE || p.H % 4 == 0);
     if (p.xb) return conv_bf16_dispatch(p, EPI, big, n5, pipe_ok, s);                     // bf16 tensors in HBM
-    if (int rc = conv_split_dispatch(p, EPI, big, n5, pipe_ok, s); rc >= 0) return rc;   // opt-in bf16-plane arithmetic
     // Small problems (the text encoder: T = 160) give only ~190 workgroups with 80-frame tiles — less than one per CU.
     // 32-frame tiles fill the chip (480+ workgroups): -15..20 % on the encoder's 3-tap and 1-tap convs.  At the decoder's
     // T' = 400 (480 workgroups already) the smaller tiles only lose operand reuse, so the switch is on the grid size.
+    bool use32 = false;
     if constexpr (EPI == EPI_PLAIN) if (pipe_ok) {
         const int rows_per = big ? 128 : 64;
         const long wg5 = (long)((p.T + 79) / 80) * p.B * ((p.M + rows_per - 1) / rows_per);
         const int t32 = ((p.T + 31) / 32) * 32;
-        if (wg5 < 440 && t32 * 10 <= p.T * 11) {
-            if (big) return dispatch_taps<2, 2, EPI>(p, s, pipe_ok);
-            return dispatch_taps<1, 2, EPI>(p, s, pipe_ok);
-        }
+        use32 = wg5 < 440 && t32 * 10 <= p.T * 11;
+    }
+    if (int rc = conv_split_dispatch(p, EPI, big, use32 ? 2 : (n5 ? 5 : 4), pipe_ok, s); rc >= 0) return rc;   // bf16-plane arithmetic
+    if (use32) {
+        if (big) return dispatch_taps<2, 2, EPI>(p, s, pipe_ok);
+        return dispatch_taps<1, 2, EPI>(p, s, pipe_ok);
     }
     if (EPI == EPI_GATE) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);
     if (big) return n5 ? dispatch_taps<2, 5, EPI>(p, s, pipe_ok) : dispatch_taps<2, 4, EPI>(p, s, pipe_ok);

@@ -486,6 +486,6 @@ int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_
 
 // convgemm_split.hip: bf16-plane arithmetic for the forward-type kernels; -1 = not handled (mode off / weights not
 // registered / shape not instantiated), otherwise the launch's return code
-int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s);
+int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, int nct, bool pipe_ok, hipStream_t s);   // nct: 16-frame column tiles (5 / 4 / 2)
 
 }  // namespace glowtts

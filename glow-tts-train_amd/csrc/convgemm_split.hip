@@ -705,9 +705,10 @@ static int dispatch_bf16_io(ConvGemmParams &p, int epi, bool big, bool n5, const
 }
 
 template <int NS>
-static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, bool n5, const unsigned short *pl, long st, hipStream_t s) {
+static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, int nct, const unsigned short *pl, long st, hipStream_t s) {
+    const bool n5 = nct == 5;
 #define GLOWTTS_SPLIT_CASE(E, R, TP)                                                   \
-    if (epi == E && (R == 2) == big && p.taps == TP)                                   \
+    if (epi == E && (R == 2) == big && p.taps == TP && nct != 2)                       \
         return n5 ? launch_split<NS, R, 5, E, TP>(p, pl, st, s) : launch_split<NS, R, 4, E, TP>(p, pl, st, s);
     GLOWTTS_SPLIT_CASE(EPI_GATE, 2, 5)
     GLOWTTS_SPLIT_CASE(EPI_RESSKIP, 2, 1)
@@ -715,6 +716,17 @@ static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, bool n5, cons
     GLOWTTS_SPLIT_CASE(EPI_GATEBWD, 1, 1)
     GLOWTTS_SPLIT_CASE(EPI_ADD, 1, 5)
     GLOWTTS_SPLIT_CASE(EPI_PLAIN, 1, 5)
+    // round 3: the text encoder's 3-tap FFN convolutions (attentions.py:347-381; forward, and backward-data as a forward-type
+    // convolution) when their ConvGroup's planes are bound — fp32-equivalent form only; with 32-frame tiles where the native
+    // dispatch would pick them (T_text = 160: 80-frame tiles leave a quarter of the CUs without a workgroup)
+    if constexpr (NS == 3) {
+        GLOWTTS_SPLIT_CASE(EPI_PLAIN, 1, 3)
+        GLOWTTS_SPLIT_CASE(EPI_PLAIN, 2, 3)
+        GLOWTTS_SPLIT_CASE(EPI_ADD, 1, 3)
+        GLOWTTS_SPLIT_CASE(EPI_ADD, 2, 3)
+        if (epi == EPI_PLAIN && p.taps == 3 && nct == 2)
+            return big ? launch_split<NS, 2, 2, EPI_PLAIN, 3>(p, pl, st, s) : launch_split<NS, 1, 2, EPI_PLAIN, 3>(p, pl, st, s);
+    }
 #undef GLOWTTS_SPLIT_CASE
     return -1;
 }
@@ -797,15 +809,15 @@ int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_
 }
 
 // called first by dispatch_convgemm: -1 = not handled here (mode off, weights not registered, shape not instantiated)
-int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s) {
+int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, int nct, bool pipe_ok, hipStream_t s) {
     const int ns = g_conv_math;
     if (ns == 0 || !pipe_ok) return -1;
     const unsigned short *pl = nullptr;
     long st = 0;
     if (!find_planes(p.wp, ns, &pl, &st)) return -1;
-    if (ns == 3) return dispatch_split_ns<3>(p, epi, big, n5, pl, st, s);
-    if (ns == 2) return dispatch_split_ns<2>(p, epi, big, n5, pl, st, s);
-    return dispatch_split_ns<1>(p, epi, big, n5, pl, st, s);
+    if (ns == 3) return dispatch_split_ns<3>(p, epi, big, nct, pl, st, s);
+    if (ns == 2) return dispatch_split_ns<2>(p, epi, big, nct, pl, st, s);
+    return dispatch_split_ns<1>(p, epi, big, nct, pl, st, s);
 }
 
 }  // namespace glowtts

@@ -507,7 +507,12 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
 int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     static const bool off = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '0'; }();
     if (off) return -1;
-    if (p.taps != 5 || p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
+    if (p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
+    if (p.taps == 3) {        // the text encoder's FFN convolutions (768 <-> 192 channels, T_text frames)
+        static const bool no3 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR3"); return e && e[0] == '0'; }();
+        return (ns == 3 && !no3) ? launch_wrw_tr<3, 3, 2, true>(p, s) : -1;
+    }
+    if (p.taps != 5) return -1;
     static const bool mt4 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '4'; }();
     // default: the 32x32x16 form with the storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per
     // back-to-back launch; 16x16x32 form 66.3; either form with the MULTIPLYING waves raised 67-69); GLOWTTS_WRW_TR=1 selects the

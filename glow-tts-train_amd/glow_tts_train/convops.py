@@ -214,7 +214,11 @@ class Conv1dFn(Function):
         ctx.group = (group, gidx)
         y = torch.empty(B, cout, T, device=x.device, dtype=torch.float32)
         b1 = None if bias is None else f32(bias.detach().contiguous())
-        conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_in=bool(mask_in), mask_out=bool(mask_out))
+        bound = group.plan.bind() if group is not None else False          # (a group with bf16 planes: the selected conv arithmetic)
+        try:
+            conv_fwd(x, wp_f, b1, m2, y, cin, cout, taps, dil, pad, mask_in=bool(mask_in), mask_out=bool(mask_out))
+        finally:
+            WNPackPlan.unbind(bound)
         ctx.save_for_backward(x, wp_b, inv, m2 if (mask_out or mask_in) else None)
         ctx.params = (v, g, bias)
         ctx.cfg = (taps, dil, pad, bool(mask_in), bool(mask_out))
@@ -231,20 +235,25 @@ class Conv1dFn(Function):
         cout = dy.shape[1]
         group, gidx = ctx.group
         dx = None
-        if ctx.needs_input_grad[0]:
-            link = ctx.link
-            if link is not None:
-                full = link.buf                         # gradient of the other consumer of x (None if it did not run)
-                link.buf = None
-                if full is None:
-                    full = torch.zeros(ctx.x_full_shape, device=dy.device, dtype=torch.float32)
-                part = full[:, :cin]
-                conv_fwd(dy, wp_b, None, m2, part, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out,
-                         mask_out=mask_in, addend=part)
-                dx = full
-            else:
-                dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
-                conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out, mask_out=mask_in)
+        bound = group.plan.bind() if group is not None else False
+        try:
+            if ctx.needs_input_grad[0]:
+                link = ctx.link
+                if link is not None:
+                    full = link.buf                     # gradient of the other consumer of x (None if it did not run)
+                    link.buf = None
+                    if full is None:
+                        full = torch.zeros(ctx.x_full_shape, device=dy.device, dtype=torch.float32)
+                    part = full[:, :cin]
+                    conv_fwd(dy, wp_b, None, m2, part, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out,
+                             mask_out=mask_in, addend=part)
+                    dx = full
+                else:
+                    dx = torch.empty(B, cin, T, device=dy.device, dtype=torch.float32)
+                    conv_fwd(dy, wp_b, None, m2, dx, cout, cin, taps, dil, (taps - 1) * dil - pad, mask_in=mask_out,
+                             mask_out=mask_in)
+        finally:
+            WNPackPlan.unbind(bound)
         if group is not None:
             # packed weight gradient into the group's accumulator (un-packed once, by the group's last backward); the bias
             # gradient rides along with the same launch, straight into bias.grad
@@ -518,9 +527,12 @@ class ConvGroup:
     group un-packs into `param.grad` and announces the gradients.  Needs every gradient to exist already (the flat-buffer
     optimizer keeps them allocated); otherwise the group stays inactive and every conv packs for itself."""
 
-    def __init__(self, convs):
+    def __init__(self, convs, planes: bool = False):
+        """`planes`: also keep bf16 planes of the packed weights (one split launch per pack) so that convolutions of this group
+        with a bf16-plane kernel (round 3: the text encoder's 3-tap FFN convolutions) run in the selected conv arithmetic —
+        whoever launches them binds the planes around the launch (`self.plan.bind()` / `WNPackPlan.unbind`)."""
         self.modules = list(convs)
-        self.plan = WNPackPlan()
+        self.plan = WNPackPlan(want_planes=planes)
         self.index = {}
         self.active = False
         self.pending = 0
@@ -1189,9 +1201,13 @@ class EncoderLayerFn(Function):
         stats1, stats2 = take(2 * B * T, B, 2, T), take(2 * B * T, B, 2, T)
         da, do_, dh, d2 = drops if drops is not None else (None, None, None, None)
         scale = 1.0 / (1.0 - p_drop) if drops is not None else 1.0
-        call("glowtts_encoder_layer_fwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), scale,
-             ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(x2), ptr(stats2),
-             B, H, F_, T, heads, taps, window, share, blk, float(eps))
+        bound = group.plan.bind()                        # the FFN convolutions take the group's bf16 planes (conv arithmetic)
+        try:
+            call("glowtts_encoder_layer_fwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), scale,
+                 ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(x2),
+                 ptr(stats2), B, H, F_, T, heads, taps, window, share, blk, float(eps))
+        finally:
+            WNPackPlan.unbind(bound)
         attn.attn = p_attn.detach()
         ctx.save_for_backward(x, m2, buf, *([] if drops is None else drops))
         ctx.cfg, ctx.mods, ctx.dims, ctx.scale, ctx.live = cfg, mods, (B, H, F_, T), scale, live
@@ -1231,10 +1247,15 @@ class EncoderLayerFn(Function):
         # behind its 5-tap kernels and lengthen the tail every step ends with (A/B: +0.4 ms per step).
         wgrad = _WgradStream(dev)
         wgrad.enabled = wgrad.enabled and _ENC_WGRAD
-        call("glowtts_encoder_layer_bwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), ctx.scale,
-             ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(stats2), ptr(dx2),
-             ptr(dx1a), ptr(dy2), ptr(d_pre1), ptr(dx1), ptr(dxa), ptr(d_o), ptr(dy_att), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dx),
-             B, H, F_, T, heads, taps, window, share, blk, wgrad.side.cuda_stream if wgrad.enabled else None)
+        bound = group.plan.bind()
+        try:
+            call("glowtts_encoder_layer_bwd", ctypes.addressof(tab), ptr(x), ptr(m2), ptr(da), ptr(do_), ptr(dh), ptr(d2), ctx.scale,
+                 ptr(q), ptr(k), ptr(v), ptr(p_attn), ptr(y_att), ptr(o), ptr(x1), ptr(stats1), ptr(h), ptr(y2), ptr(stats2),
+                 ptr(dx2), ptr(dx1a), ptr(dy2), ptr(d_pre1), ptr(dx1), ptr(dxa), ptr(d_o), ptr(dy_att), ptr(ds), ptr(dq), ptr(dk_),
+                 ptr(dv), ptr(dx), B, H, F_, T, heads, taps, window, share, blk,
+                 wgrad.side.cuda_stream if wgrad.enabled else None)
+        finally:
+            WNPackPlan.unbind(bound)
         _mark_direct(live, True)
         if wgrad.enabled:
             for t in (x, buf, ws, dx2):                  # read by the second stream after this returns

@@ -6,6 +6,7 @@ state-dict keys — computing the flow stack, the alignment search and the losse
 from __future__ import annotations
 
 import logging
+import os
 import math
 import typing
 
@@ -83,7 +84,9 @@ class TextEncoder(nn.Module):
         layered = [convs_of(a) + convs_of(f) for a, f in zip(self.encoder.attn_layers, self.encoder.ffn_layers)]
         taken = {id(m) for grp in layered for m in grp}
         rest = [m for m in convs_of(self) if id(m) not in taken]
-        self._conv_groups = [convops.ConvGroup(grp) for grp in layered + [rest] if grp]
+        # (the transformer layers' groups keep bf16 planes: their 3-tap FFN convolutions run in the selected conv arithmetic)
+        enc_planes = os.environ.get("GLOWTTS_ENC_PLANES", "1") != "0"
+        self._conv_groups = [convops.ConvGroup(grp, planes=enc_planes) for grp in layered if grp] + ([convops.ConvGroup(rest)] if rest else [])
 
     def forward(self, x, x_lengths, g=None):
         for grp in self._conv_groups:

@@ -311,3 +311,47 @@ def test_weight_gradient_from_presplit_planes(M, b, h, t):
         assert rel_err(db, d.double().sum((0, 2))) < 1e-6
     with pytest.raises(RuntimeError, match="no kernel"):
         call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), h * t, ptr(dp), d.numel(), 2 * h * t, ptr(dwp), None, b, h, 2 * h, t, 3, 3)
+
+
+def test_encoder_ffn_convs_take_the_group_planes(M):
+    """Round 3: the text encoder's 3-tap FFN convolutions (attentions.py:347-381; 192 -> 768 -> 192 channels at T_text frames)
+    run in the selected conv arithmetic when their ConvGroup keeps bf16 planes: forward, backward-data (32-frame tiles at
+    T = 160) and the 3-tap weight gradient (convwrw_tr.hip) against torch fp64 — bf16x6 no worse than the native kernels, and
+    bit-different from them (the plane kernels really ran)."""
+    import torch.nn as nn
+
+    torch.manual_seed(11)
+    b, h, f, t = 8, 192, 768, 160
+    c1, c2 = nn.Conv1d(h, f, 3, padding=1).cuda(), nn.Conv1d(f, h, 3, padding=1).cuda()
+    for p_ in list(c1.parameters()) + list(c2.parameters()):
+        p_.grad = torch.zeros_like(p_)
+    grp = M.convops.ConvGroup([c1, c2], planes=True)
+    x0 = torch.randn(b, h, t, device="cuda")
+    r = torch.randn(b, h, t, device="cuda")
+    m2 = torch.ones(b, t, device="cuda")
+
+    xd = x0.double().requires_grad_(True)
+    w1, w2 = c1.weight.detach().double().requires_grad_(True), c2.weight.detach().double().requires_grad_(True)
+    yd = F.conv1d(F.conv1d(xd, w1, c1.bias.detach().double(), padding=1), w2, c2.bias.detach().double(), padding=1)
+    (yd * r.double()).sum().backward()
+    ref = {"y": yd.detach(), "dx": xd.grad, "dw1": w1.grad, "dw2": w2.grad}
+
+    def run(mode):
+        M.convops.set_conv_math(mode)
+        for p_ in list(c1.parameters()) + list(c2.parameters()):
+            p_.grad.zero_()
+        x = x0.clone().requires_grad_(True)
+        grp.begin()
+        y = M.convops.conv1d(c2, M.convops.conv1d(c1, x, m2), m2)
+        (y * r).sum().backward()
+        M.convops.flush_groups()
+        torch.cuda.synchronize()
+        got = {"y": y.detach().clone(), "dx": x.grad.clone(), "dw1": c1.weight.grad.clone(), "dw2": c2.weight.grad.clone()}
+        return {k: float((got[k].double() - ref[k]).abs().max() / ref[k].abs().max()) for k in ref}, got
+
+    (native, t_native), (x6, t_x6) = run("fp32"), run("bf16x6+wrw")
+    for k in ref:
+        assert native[k] < 2e-5, (k, native)
+        assert x6[k] <= 1.5 * native[k] + 2e-7, (k, x6, native)
+        # the plane kernels really ran: the same numbers to fp32 accuracy, not the same bits (another summation order)
+        assert not torch.equal(t_x6[k], t_native[k]), f"{k}: bit-identical to the native kernels"
