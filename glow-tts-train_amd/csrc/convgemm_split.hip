@@ -724,8 +724,9 @@ static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, int nct, cons
         GLOWTTS_SPLIT_CASE(EPI_PLAIN, 2, 3)
         GLOWTTS_SPLIT_CASE(EPI_ADD, 1, 3)
         GLOWTTS_SPLIT_CASE(EPI_ADD, 2, 3)
-        if (epi == EPI_PLAIN && p.taps == 3 && nct == 2)
-            return big ? launch_split<NS, 2, 2, EPI_PLAIN, 3>(p, pl, st, s) : launch_split<NS, 1, 2, EPI_PLAIN, 3>(p, pl, st, s);
+        // 32-frame tiles: only the 64-row form pays (rocprofv3, T = 160: 192 <- 768 channels 50.0 -> 45.4 us; the 128-row form
+        // of 768 <- 192 channels measured 47.3 us against 45.3 native: it stays on the fp32 MFMA kernel)
+        if (epi == EPI_PLAIN && p.taps == 3 && nct == 2 && !big) return launch_split<NS, 1, 2, EPI_PLAIN, 3>(p, pl, st, s);
     }
 #undef GLOWTTS_SPLIT_CASE
     return -1;
