@@ -544,18 +544,30 @@ def main():
         conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
 
         def on_bf16_pipe(tag):
-            """Does this launch run as the bf16-plane kernel in the mode being measured?  (the WN stack's convolutions)"""
+            """Does this launch run as a bf16-plane kernel in the mode being measured?  Mirrors the library's dispatch
+            (csrc/convgemm.hip dispatch_convgemm, convgemm_split.hip dispatch_split_ns / conv_wrw_split_dispatch,
+            convwrw_tr.hip conv_wrw_tr_dispatch): forward-type launches need planes bound to their weights (the WN stack; the
+            encoder's FFN convolutions unless GLOWTTS_ENC_PLANES=0), weight gradients need nothing but the mode."""
             base, _, wrw = default_math.partition("+")
             if base != "bf16x6":
                 return False
-            m_ = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+)", tag)
+            m_ = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)", tag)
             name_, M_, K_, taps_ = m_.group(1), int(m_.group(2)), int(m_.group(3)), int(m_.group(4))
+            B_, T_ = int(m_.group(5)), int(m_.group(6))
             if name_ in ("glowtts_conv_gate_fwd", "glowtts_conv_res_skip_fwd", "glowtts_conv_gate_bwd"):
                 return True
             if name_ == "glowtts_conv_fwd":
-                return taps_ == 5 and K_ == 2 * H and M_ == H
+                if taps_ == 5 and K_ == 2 * H and M_ == H:
+                    return True                                     # backward-data of the WN stack's 5-tap convolution
+                Fc = cfg.model.filter_channels
+                if taps_ == 3 and {M_, K_} == {H, Fc} and os.environ.get("GLOWTTS_ENC_PLANES", "1") != "0":
+                    big = M_ % 128 == 0 or M_ > 192                 # 128-row workgroups
+                    wg5 = -(-T_ // 80) * B_ * -(-M_ // (128 if big else 64))
+                    use32 = wg5 < 440 and -(-T_ // 32) * 32 * 10 <= T_ * 11
+                    return not (use32 and big)                      # that one case stays on the fp32 MFMA kernel
+                return False
             if name_ in ("glowtts_conv_wrw", "glowtts_conv_wrw2"):
-                return wrw == "wrw" and K_ == H and ((taps_ == 5 and M_ == 2 * H) or (taps_ == 1 and M_ in (H, 2 * H)))
+                return wrw == "wrw" and (taps_ == 1 or (taps_ in (3, 5) and M_ % 32 == 0))
             return False
 
         for tag, row in mfma.items():              # which roof bounds each contraction, and how close it is to that roof
