@@ -736,18 +736,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     pack_weight_row(v, g, wp_f, wp_b, inv_norm, blockIdx.x, Cout, Cin, taps, red);
 }
 
-// several convolutions in ONE launch (a WN stack has 2 per layer): desc[c] = {v, g, wp_f, wp_b, inv_norm, Cout, Cin, taps}
-// as 8 x int64, row_prefix[c] = first workgroup of convolution c.  The table is built once per module and reused.
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const long long *__restrict__ desc,
-                                                                const int *__restrict__ row_prefix, int n_conv) {
-    __shared__ float red[4];
-    int c = 0;
-    while (c + 1 < n_conv && (int)blockIdx.x >= row_prefix[c + 1]) ++c;
-    const long long *d = desc + (long)c * 8;
-    pack_weight_row(reinterpret_cast<const float *>(d[0]), reinterpret_cast<const float *>(d[1]),
-                    reinterpret_cast<float *>(d[2]), reinterpret_cast<float *>(d[3]), reinterpret_cast<float *>(d[4]),
-                    (int)blockIdx.x - row_prefix[c], (int)d[5], (int)d[6], (int)d[7], red);
-}
+// (several convolutions per launch: packw.hip, on 16-row tiles)
 
 // backward of the packing: dw[o][c][tap] = dwp[tap][c][o];  plain conv: dweight += dw
 // weight norm: dg[o] += sum(dw * v) / n ;  dv += (g / n) * (dw - v * sum(dw * v) / n^2)      (n = ||v[o]||)
@@ -815,19 +804,6 @@ __global__ __launch_bounds__(256) void unpack_weight_grad_kernel(const float *__
                                                                  int Cin, int taps) {
     __shared__ float red[4];
     unpack_weight_grad_row(dwp, v, g, inv_norm, dv, dg, blockIdx.x, Cout, Cin, taps, red);
-}
-
-// desc[c] = {dwp, v, g, inv_norm, dv, dg, Cout, Cin, taps} as 9 x int64
-__global__ __launch_bounds__(256) void unpack_weight_grad_multi_kernel(const long long *__restrict__ desc,
-                                                                       const int *__restrict__ row_prefix, int n_conv) {
-    __shared__ float red[4];
-    int c = 0;
-    while (c + 1 < n_conv && (int)blockIdx.x >= row_prefix[c + 1]) ++c;
-    const long long *d = desc + (long)c * 9;
-    unpack_weight_grad_row(reinterpret_cast<const float *>(d[0]), reinterpret_cast<const float *>(d[1]),
-                           reinterpret_cast<const float *>(d[2]), reinterpret_cast<const float *>(d[3]),
-                           reinterpret_cast<float *>(d[4]), reinterpret_cast<float *>(d[5]), (int)blockIdx.x - row_prefix[c],
-                           (int)d[6], (int)d[7], (int)d[8], red);
 }
 
 // out[m] += sum_{b,t} d[b][m][t]   (bias gradients) — grid (M, slabs of utterances)
@@ -1190,20 +1166,6 @@ extern "C" int glowtts_unpack_weight_grad(const float *dwp, const float *v, cons
     GLOWTTS_CHECK_ARG(Cout > 0 && Cin > 0 && taps > 0, "glowtts_unpack_weight_grad: bad shape");
     hipLaunchKernelGGL(unpack_weight_grad_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, dwp, v, g, inv_norm, dv, dg, Cout, Cin, taps);
     GLOWTTS_LAUNCH_CHECK("glowtts_unpack_weight_grad");
-}
-
-extern "C" int glowtts_pack_weight_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
-                                         glowtts_stream_t stream) {
-    GLOWTTS_CHECK_ARG(desc && row_prefix && n_conv > 0 && total_rows > 0, "glowtts_pack_weight_multi: bad argument");
-    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, desc, row_prefix, n_conv);
-    GLOWTTS_LAUNCH_CHECK("glowtts_pack_weight_multi");
-}
-
-extern "C" int glowtts_unpack_weight_grad_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
-                                                glowtts_stream_t stream) {
-    GLOWTTS_CHECK_ARG(desc && row_prefix && n_conv > 0 && total_rows > 0, "glowtts_unpack_weight_grad_multi: bad argument");
-    hipLaunchKernelGGL(unpack_weight_grad_multi_kernel, dim3(total_rows), dim3(256), 0, (hipStream_t)stream, desc, row_prefix, n_conv);
-    GLOWTTS_LAUNCH_CHECK("glowtts_unpack_weight_grad_multi");
 }
 
 extern "C" int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int B, int M, int T,

@@ -12,7 +12,7 @@ __device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.f, 0.f, 0.f
 
 #ifdef GLOWTTS_TRACE   // tuning builds only (tools/trace_conv.py): per-workgroup phase timestamps, 100 MHz wall clock
 static __device__ unsigned long long g_trace[8192 * 16];   // one copy per translation unit
-#define GLOWTTS_TRACE_POINT(i) do { if (threadIdx.x == 0) { g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); if ((i) == 3 || (i) == 4) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 8 + (i)] = __builtin_readcyclecounter(); if ((i) == 0) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#define GLOWTTS_TRACE_POINT(i) do { if (threadIdx.x == 0) { g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); if ((i) == 3 || (i) == 4) g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 8 + (i)] = __builtin_readcyclecounter(); if ((i) == 0) { g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); g_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + 14] = 0x100 | __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); } } } while (0)
 #define GLOWTTS_TRACE_POINT_Z(i) do { if (threadIdx.x == 0) g_trace[((blockIdx.z * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define GLOWTTS_TRACE_POINT(i) do { } while (0)

@@ -512,6 +512,8 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
         static const bool no3 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR3"); return e && e[0] == '0'; }();
         return (ns == 3 && !no3) ? launch_wrw_tr<3, 3, 2, true>(p, s) : -1;
     }
+    // 1x1 convolutions stay on the frame-packed kernel: this one is staging-bound there (measured at B=32 / T'=400, 384 <- 192
+    // channels: 45 us as 64x32 tiles, 34 us as 64x64, against 30.5 us)
     if (p.taps != 5) return -1;
     static const bool mt4 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '4'; }();
     // default: the 32x32x16 form with the storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per

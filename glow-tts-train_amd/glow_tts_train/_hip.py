@@ -59,6 +59,7 @@ _SIGNATURES = {
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_rowsum": [_P, _L, _P, _P, _I, _I, _I],
     "glowtts_pack_weight_multi": [_P, _P, _I, _I],
+    "glowtts_pack_weight_planes_multi": [_P, _P, _I, _I, _P, _L, _P],
     "glowtts_unpack_weight_grad_multi": [_P, _P, _I, _I],
     "glowtts_gate_bwd_ts": [_P, _P, _P, _F, _P, _I, _I, _I],
     "glowtts_rel_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I],

@@ -445,11 +445,13 @@ class WNPackPlan:
 
     def pack(self):
         self.pack_count = getattr(self, "pack_count", 0) + 1      # (planes made from the packed weights go stale here)
-        call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
-        if _SPLIT_MATH[0] and self.want_planes:   # bf16-plane arithmetic is on: refresh the planes of the new weights
-            if self.wp_planes is None:
-                self.wp_planes = torch.empty(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
-            call("glowtts_conv_split_weights", ptr(self.wp_arena), self.wp_arena.numel(), ptr(self.wp_planes))
+        if _SPLIT_MATH[0] and self.want_planes:   # bf16-plane arithmetic is on: the planes of the new weights in the same pass
+            if self.wp_planes is None:            # (zeros: the k positions no packing covers must read as zero in every plane)
+                self.wp_planes = torch.zeros(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
+            call("glowtts_pack_weight_planes_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows,
+                 ptr(self.wp_arena), self.wp_arena.numel(), ptr(self.wp_planes))
+        else:
+            call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
 
     def bind(self) -> bool:
         """Hand this stack's planes to the calling thread's next convolution launches (no-op in native fp32 mode)."""

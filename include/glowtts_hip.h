@@ -230,6 +230,13 @@ int glowtts_rowsum(const float *d, long d_bs, const float *mask, float *out, int
  * row_prefix[c] = sum of Cout of the convolutions before c (int32, n_conv + 1 entries); both tables in DEVICE memory. */
 int glowtts_pack_weight_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
                               glowtts_stream_t stream);
+/* The same, and the three bf16 planes of every packed value in the same pass (what glowtts_conv_split_weights would make of
+ * the packed buffers afterwards): all wp_f / wp_b of the table lie inside [arena, arena + n_floats), planes is 3 * n_floats
+ * uint16 with planes[pl * n_floats + (p - arena)] = plane pl of *p.  Positions of the arena that no packing covers are not
+ * written.  (csrc/packw.hip: 16 output channels per workgroup, so both packings are written — and the packed gradient is read
+ * by the un-packing — as whole 64-byte segments; packed buffers must be 8-byte aligned.) */
+int glowtts_pack_weight_planes_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
+                                     const float *arena, long n_floats, uint16_t *planes, glowtts_stream_t stream);
 int glowtts_unpack_weight_grad_multi(const long long *desc, const int *row_prefix, int n_conv, int total_rows,
                                      glowtts_stream_t stream);
 int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char *drop, float drop_scale, float *da,

@@ -1473,3 +1473,83 @@ def test_first_step_gradients_repeat_across_multi_stream_runs(G, io):
         got = run(True)
         worst = float((got - ref).abs().max()) / gmax
         assert worst < 5e-6, (i, worst)
+
+
+# ---- several convolutions per launch on 16-row tiles (csrc/packw.hip): weight norm + both packings + bf16 planes, and the
+# backward through the weight norm, against torch.nn.utils.weight_norm semantics (reference layers.py:113,125,135)
+_PACK_SHAPES = [(384, 192, 5, True), (384, 192, 1, True), (192, 80, 1, False), (160, 192, 1, False), (80, 192, 1, True),
+                (1, 256, 1, False), (256, 1, 1, False), (768, 192, 3, False), (192, 768, 3, True), (40, 24, 2, True), (50, 70, 3, True)]
+
+
+def _pack_reference(v, g):
+    w = v if g is None else v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    co, ci, k = v.shape
+    gi, go = (ci + 15) // 16, (co + 15) // 16
+    wf = torch.zeros(k, gi * 16, co, dtype=w.dtype, device=w.device)
+    wf[:, :ci] = w.permute(2, 1, 0)                                  # [tap][c][o]
+    wf = wf.view(k, gi, 16, co).permute(0, 1, 3, 2).contiguous()     # [tap][c/16][o][c%16]
+    wb = torch.zeros(k, go * 16, ci, dtype=w.dtype, device=w.device)
+    wb[:, :co] = w.flip(2).permute(2, 0, 1)                          # [taps-1-tap][o][c]
+    wb = wb.view(k, go, 16, ci).permute(0, 1, 3, 2).contiguous()     # [tap'][o/16][c][o%16]
+    return wf, wb
+
+
+def test_pack_and_unpack_tile_kernels_vs_torch(G):
+    call, ptr = G.hip.call, G.hip.ptr
+    torch.manual_seed(3)
+    dev = "cuda"
+    vs = [torch.randn(co, ci, k, device=dev) * 0.2 for co, ci, k, _ in _PACK_SHAPES]
+    gs = [(torch.rand(co, 1, 1, device=dev) + 0.5) if wn else None for co, ci, k, wn in _PACK_SHAPES]
+    sizes = [(k * ((ci + 15) // 16) * co * 16, k * ((co + 15) // 16) * ci * 16) for co, ci, k, _ in _PACK_SHAPES]
+    arena = torch.zeros(sum(a + b for a, b in sizes), device=dev)
+    planes = torch.zeros(3 * arena.numel(), device=dev, dtype=torch.int16)
+    invs = [torch.zeros(co, device=dev) for co, _, _, _ in _PACK_SHAPES]
+    desc, views, cur, rows = [], [], 0, [0]
+    for (co, ci, k, wn), v, g, inv, (sa, sb) in zip(_PACK_SHAPES, vs, gs, invs, sizes):
+        f, b = arena[cur: cur + sa], arena[cur + sa: cur + sa + sb]
+        cur += sa + sb
+        views.append((f, b))
+        desc.append([v.data_ptr(), 0 if g is None else g.data_ptr(), f.data_ptr(), b.data_ptr(), inv.data_ptr() if wn else 0, co, ci, k])
+        rows.append(rows[-1] + co)
+    desc_t = torch.tensor(desc, dtype=torch.int64, device=dev)
+    prefix = torch.tensor(rows, dtype=torch.int32, device=dev)
+    call("glowtts_pack_weight_planes_multi", ptr(desc_t), ptr(prefix), len(desc), rows[-1], ptr(arena), arena.numel(), ptr(planes))
+    torch.cuda.synchronize()
+    for (co, ci, k, wn), v, g, inv, (f, b) in zip(_PACK_SHAPES, vs, gs, invs, views):
+        wf, wb = _pack_reference(v.double(), None if g is None else g.double())
+        assert_close(f.view_as(wf), wf.float(), rtol=2e-6, atol=1e-7, what=f"wp_f {co, ci, k}")
+        assert_close(b.view_as(wb), wb.float(), rtol=2e-6, atol=1e-7, what=f"wp_b {co, ci, k}")
+        if wn:
+            assert_close(inv, (1.0 / v.double().flatten(1).norm(dim=1)).float(), rtol=2e-6, atol=0, what="inv_norm")
+    # the planes are the exact three-way split of the packed fp32 values: h + m + l == w bit for bit, h = bf16(w)
+    pl = planes.view(3, -1).to(torch.int32).bitwise_and(0xFFFF).bitwise_left_shift(16).view(torch.float32)
+    assert torch.equal(pl[0] + pl[1] + pl[2], arena), "planes do not add up to the packed weights"
+    assert torch.equal(pl[0], arena.to(torch.bfloat16).float()), "plane 0 is not the nearest bf16"
+    # the plain entry point writes the same fp32 packings
+    arena2 = arena.clone().zero_()
+    desc2 = desc_t.clone()
+    desc2[:, 2] += arena2.data_ptr() - arena.data_ptr()
+    desc2[:, 3] += arena2.data_ptr() - arena.data_ptr()
+    call("glowtts_pack_weight_multi", ptr(desc2), ptr(prefix), len(desc), rows[-1])
+    assert torch.equal(arena2, arena)
+
+    # ---- backward: packed gradient [tap][c][o] -> dv (+=), dg (+=)
+    dws = [torch.randn(k, ci, co, device=dev) for co, ci, k, _ in _PACK_SHAPES]
+    dvs = [torch.randn_like(v) for v in vs]
+    dgs = [None if g is None else torch.randn_like(g) for g in gs]
+    dv0 = [d.clone() for d in dvs]
+    dg0 = [None if d is None else d.clone() for d in dgs]
+    ud = [[dw.data_ptr(), v.data_ptr(), 0 if g is None else g.data_ptr(), inv.data_ptr() if g is not None else 0, dv.data_ptr(),
+           0 if dg is None else dg.data_ptr(), co, ci, k]
+          for (co, ci, k, _), dw, v, g, inv, dv, dg in zip(_PACK_SHAPES, dws, vs, gs, invs, dvs, dgs)]
+    ud_t = torch.tensor(ud, dtype=torch.int64, device=dev)
+    call("glowtts_unpack_weight_grad_multi", ptr(ud_t), ptr(prefix), len(ud), rows[-1])
+    torch.cuda.synchronize()
+    for (co, ci, k, wn), dw, v, g, dv, dg, a0, b0 in zip(_PACK_SHAPES, dws, vs, gs, dvs, dgs, dv0, dg0):
+        v64 = v.double().requires_grad_(True)
+        g64 = None if g is None else g.double().requires_grad_(True)
+        w = v64 if g64 is None else v64 * (g64 / v64.flatten(1).norm(dim=1).view(-1, 1, 1))
+        (w * dw.double().permute(2, 1, 0)).sum().backward()
+        assert_close(dv - a0, v64.grad.float(), rtol=1e-5, atol=2e-6 * float(v64.grad.abs().max()), what=f"dv {co, ci, k}")
+        if wn:
+            assert_close(dg - b0, g64.grad.float(), rtol=1e-5, atol=2e-6 * float(g64.grad.abs().max()), what=f"dg {co, ci, k}")

@@ -81,6 +81,7 @@ e1.record()
 torch.cuda.synchronize()
 rd(buf.ctypes.data, NW, 0)
 tr = buf.reshape(8192, 16).astype(np.int64)
+wg_index = np.nonzero(tr[:, 0] > 0)[0]
 tr = tr[tr[:, 0] > 0]
 t00 = tr[:, 0].min()
 us = lambda a: (a - t00) / 100.0      # 100 MHz wall clock -> microseconds
@@ -116,3 +117,22 @@ for i in order[:24]:
     print(f"  {cu_key[i]:6x} " + " ".join(f"{us(tr[i, c]):6.1f}" for c in (0, 1, 2, 3, 4, 10)))
 start = us(tr[:, 0])
 print("start-time histogram (us):", np.histogram(start, bins=8)[0].tolist(), [round(v, 1) for v in np.histogram(start, bins=8)[1].tolist()])
+
+if (tr[:, 14] & 0x100).all() and rd is not getattr(lib, "glowtts_debug_trace_read_tr", None):
+    # which CU a workgroup ran on (XCC, SE, SH, CU), how many workgroups shared it, and whether the slow ones have anything in common
+    xcc = tr[:, 14] & 0xF
+    cu = (xcc << 16) | ((hw >> 8) & 0xFFFF)
+    keys, inv, cnt = np.unique(cu, return_inverse=True, return_counts=True)
+    print("compute units used:", len(keys), " workgroups per CU:", dict(zip(*np.unique(cnt, return_counts=True))))
+    life = us(tr[:, 10]) - us(tr[:, 0])
+    for n in np.unique(cnt):
+        sel = cnt[inv] == n
+        print(f"  CUs with {n} workgroup(s): lifetime median {np.median(life[sel]):.1f} max {life[sel].max():.1f}; end median "
+              f"{np.median(us(tr[sel, 10])):.1f} max {us(tr[sel, 10]).max():.1f}")
+    print("per XCC: end-time median / max:", [(int(x), round(float(np.median(us(tr[xcc == x, 10]))), 1), round(float(us(tr[xcc == x, 10]).max()), 1))
+                                               for x in np.unique(xcc)])
+    slow = np.argsort(-life)[:16]
+    print("slowest workgroups (index, xcc, cu key, co-resident, start, p1, p2, p3, p4, end):")
+    for i in slow:
+        print(f"  {wg_index[i]:5d} {xcc[i]:2d} {(hw[i] >> 8) & 0xFFFF:6x} {cnt[inv[i]]:2d} " + " ".join(f"{us(tr[i, c]):6.1f}" for c in (0, 1, 2, 3, 4, 10)))
+    print("lifetime histogram:", np.histogram(life, bins=10)[0].tolist(), [round(v, 1) for v in np.histogram(life, bins=10)[1].tolist()])

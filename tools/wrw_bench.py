@@ -17,7 +17,9 @@ from glow_tts_train._hip import call, ptr  # noqa: E402
 def main():
     _hip.load()
     shapes = [(32, 192, 384, 400, 5), (48, 192, 384, 600, 5), (64, 192, 384, 500, 5), (8, 192, 384, 200, 5), (32, 192, 384, 400, 1)]
-    for mode in ("bf16x6+wrw", "fp32"):
+    if os.environ.get("WRW_BENCH_TAPS"):
+        shapes = [sh for sh in shapes + [(32, 192, 192, 400, 1), (32, 192, 192, 160, 1)] if sh[4] == int(os.environ["WRW_BENCH_TAPS"])]
+    for mode in ("bf16x6+wrw", "fp32")[:1 if os.environ.get("WRW_BENCH_TAPS") else 2]:
         convops.set_conv_math(mode)
         for (b, k, m, t, taps) in shapes:
             torch.manual_seed(1)
