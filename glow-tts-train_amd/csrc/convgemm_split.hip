@@ -47,6 +47,16 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float *__restr
     }
 }
 
+// An 8-byte LDS store as ds_write2_b32 of two adjacent dwords.  Not ds_write_b64 / ds_write2st64_b64: on gfx950 a kernel that
+// issues 64-bit LDS stores next to bf16 MFMAs makes OTHER waves' packed-fp32 VALU results wrong (DESIGN.md lesson 12; this library
+// has no packed-fp32 code, but a collective or a framework kernel on the same CU may).  hipcc does not count an asm LDS store:
+// the staging code waits for lgkmcnt(0) itself before its barriers.
+__device__ __forceinline__ void lds_store8(void *p, int lo, int hi) {
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1"
+                 :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) void *)p), "v"(lo), "v"(hi) : "memory");
+}
+__device__ __forceinline__ void lds_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // IOB: 0 = fp32 tensors (operands split / rounded while they are staged); 1 = x and the epilogue's tensors are bf16 in HBM
 // (NS = 1 only: nothing to split — 8-byte loads go to LDS as they are, results leave as bf16); 2 = x bf16, epilogue fp32
 // (the coupling's end conv: its output (m, logs) feeds the log-determinant and stays fp32).
@@ -152,8 +162,46 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         xvo[jq] = ok ? ((gsel * 16 + kk) * p.T + t) * ES : 0x7fffffff;
     }
     const int dbase = (qq * 4) * RP + (kk >> 2) * 8 + gsel * 4 + (kk & 3);     // bf16 index inside a plane image
-    f32x4 xreg[XB ? 1 : NG][XB ? 1 : NQ];
     i32x2 xregb[XB ? NG : 1][XB ? NQ : 1];           // bf16 tensors: 4 frames of one channel = 8 bytes
+    // fp32 tensors (round 3): a piece is 4 channels x 4 frames — four 16-byte loads; v_cvt_pk_bf16_f32 of two neighbouring
+    // channels of one frame IS a dword of the plane image, so a frame of the piece is ONE 8-byte LDS store per plane (12 per 16
+    // values; the channel-per-thread map above needs 12 two-byte stores per 4 values, which made the staging phase of a 1x1
+    // convolution as long as its MFMA loop).  Thread bits: c4l (3: channel quad of a group pair), fql (2), hl (3); a round covers
+    // hl + 8 r of the HI = (group pairs) x (frame quads / 4) values; 16 lanes with equal hl store two rows 4 frames apart x 8
+    // even dword offsets: all 32 banks once.  What does not fill a round goes as quarter pieces (1 channel x 4 frames).
+    constexpr int NFQ = (TAPS > 1 ? XC : NT) / 4;    // frame quads staged per channel (a 1x1 convolution has no halo)
+    constexpr int NFQH = NFQ / 4, HI = G2C * NFQH;
+    constexpr int F0 = HI / 8, LH0 = HI - 8 * F0;
+    constexpr int FR = XB ? 0 : F0 + (LH0 >= 5 ? 1 : 0), LH = (XB || LH0 >= 5) ? 0 : LH0, QR = (LH + 1) / 2;
+    static_assert(NFQ % 4 == 0, "frame quads in fours");
+    f32x4 xf[FR > 0 ? FR : 1][4], xq[QR > 0 ? QR : 1];
+    unsigned xfo[FR > 0 ? FR : 1], xqo[QR > 0 ? QR : 1];
+    int xfd[FR > 0 ? FR : 1], xqd[QR > 0 ? QR : 1], xfq[FR > 0 ? FR : 1], xqq[QR > 0 ? QR : 1];
+    const unsigned rowb = (unsigned)p.T * 4u;
+    if constexpr (!XB) {
+        const int c4l = tid & 7, c4 = c4l & 3, gs = c4l >> 2, fql = (tid >> 3) & 3;
+#pragma unroll
+        for (int r = 0; r < FR; ++r) {
+            const int hi = (tid >> 5) + 8 * r;
+            const int gp = hi / NFQH, fq = (hi - gp * NFQH) * 4 + fql;
+            const int t = ts + fq * 4;
+            const bool ok = hi < HI && t >= 0 && t < p.T;
+            xfo[r] = ok ? (unsigned)((gp * 32 + gs * 16 + c4 * 4) * p.T + t) * 4u : 0x7fffffffu;
+            xfd[r] = hi < HI ? (gp * XC + fq * 4) * RP + c4 * 8 + gs * 4 : -1;
+            xfq[r] = fq;
+        }
+#pragma unroll
+        for (int r = 0; r < QR; ++r) {
+            const int ch = tid & 3, c4q = (tid >> 2) & 3, gsq = (tid >> 4) & 1, fqlq = (tid >> 5) & 3, hl = (tid >> 7) + 2 * r;
+            const int hi = 8 * F0 + hl;
+            const int gp = hi / NFQH, fq = (hi - gp * NFQH) * 4 + fqlq;
+            const int t = ts + fq * 4;
+            const bool ok = hl < LH && t >= 0 && t < p.T;
+            xqo[r] = ok ? (unsigned)((gp * 32 + gsq * 16 + c4q * 4 + ch) * p.T + t) * 4u : 0x7fffffffu;
+            xqd[r] = hl < LH ? (gp * XC + fq * 4) * RP + c4q * 8 + gsq * 4 + ch : -1;
+            xqq[r] = fq;
+        }
+    }
     if (p.mask_in && tid < XC) {
         const int t = ts + tid;
         Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
@@ -161,26 +209,34 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
     auto xload = [&](int c) {
         const bool second = p.x2 != nullptr && c * KG * 16 >= p.x_split;
         const int cbase = c * KG * 16 - (second ? p.x_split : 0);
+        if constexpr (XB) {
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi)
+            for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-            for (int jq = 0; jq < NQ; ++jq) {
-                if constexpr (XB)
+                for (int jq = 0; jq < NQ; ++jq)
                     xregb[gi][jq] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(
                         second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * ES, 0));
-                else
-                    xreg[gi][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        second ? xrs2 : xrs, xvo[jq], (cbase + 2 * gi * 16) * p.T * ES, 0));
-            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < FR; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xf[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        second ? xrs2 : xrs, (int)(xfo[r] + i * rowb)   /* an out-of-range offset stays out of range */, cbase * p.T * ES, 0));
+#pragma unroll
+            for (int r = 0; r < QR; ++r)
+                xq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? xrs2 : xrs, (int)xqo[r], cbase * p.T * ES, 0));
+        }
     };
     auto xstore = [&]() {
+        if constexpr (XB) {
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi)
+            for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-            for (int jq = 0; jq < NQ; ++jq)
-                if (qq + 8 * jq < XC / 4) {
-                    unsigned short *d = Xh + dbase + (gi * XC + 32 * jq) * RP;
-                    if constexpr (XB) {                  // already bf16: the 0 / 1 mask selects, nothing is rounded
+                for (int jq = 0; jq < NQ; ++jq)
+                    if (qq + 8 * jq < XC / 4) {
+                        unsigned short *d = Xh + dbase + (gi * XC + 32 * jq) * RP;
+                        // already bf16: the 0 / 1 mask selects, nothing is rounded
                         unsigned w0 = (unsigned)xregb[gi][jq][0], w1 = (unsigned)xregb[gi][jq][1];
                         if (p.mask_in) {
                             const f32x4 m = *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
@@ -189,21 +245,43 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
                         }
                         d[0] = (unsigned short)w0; d[RP] = (unsigned short)(w0 >> 16);
                         d[2 * RP] = (unsigned short)w1; d[3 * RP] = (unsigned short)(w1 >> 16);
-                    } else {
-                        f32x4 v = xreg[gi][jq];
-                        if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + (qq + 8 * jq) * 4);
+                    }
+        } else {
 #pragma unroll
-                        for (int f = 0; f < 4; f += 2) {
-                            unsigned o[NS];
-                            split_planes2<NS>(v[f], v[f + 1], o);
+            for (int r = 0; r < FR; ++r)
+                if (xfd[r] >= 0) {
+                    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+                    if (p.mask_in) m = *reinterpret_cast<const f32x4 *>(Ms + xfq[r] * 4);
 #pragma unroll
-                            for (int pl = 0; pl < NS; ++pl) {
-                                d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
-                                d[pl * PLANE16 + (f + 1) * RP] = (unsigned short)(o[pl] >> 16);
-                            }
+                    for (int f = 0; f < 4; ++f) {
+                        unsigned oa[NS], ob[NS];
+                        float a0 = xf[r][0][f], a1 = xf[r][1][f], a2 = xf[r][2][f], a3 = xf[r][3][f];
+                        if (p.mask_in) { a0 *= m[f]; a1 *= m[f]; a2 *= m[f]; a3 *= m[f]; }
+                        split_planes2<NS>(a0, a1, oa);
+                        split_planes2<NS>(a2, a3, ob);
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) lds_store8(Xh + pl * PLANE16 + xfd[r] + f * RP, (int)oa[pl], (int)ob[pl]);
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < QR; ++r)
+                if (xqd[r] >= 0) {
+                    unsigned short *d = Xh + xqd[r];
+                    f32x4 v = xq[r];
+                    if (p.mask_in) v *= *reinterpret_cast<const f32x4 *>(Ms + xqq[r] * 4);
+#pragma unroll
+                    for (int f = 0; f < 4; f += 2) {
+                        unsigned o[NS];
+                        split_planes2<NS>(v[f], v[f + 1], o);
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) {
+                            d[pl * PLANE16 + f * RP] = (unsigned short)o[pl];
+                            d[pl * PLANE16 + (f + 1) * RP] = (unsigned short)(o[pl] >> 16);
                         }
                     }
                 }
+            lds_stores_done();                           // the asm stores are not counted by the compiler's own waits
+        }
     };
     const float *xd = smem + (off + lrow) * (RP / 2) + lk * 4;      // dword view of a plane image
     i32x4 bv[2][NS];
@@ -279,16 +357,6 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
 // ds_read_b128): even shifts are a choice of registers, odd shifts one v_alignbit per register.
 // Chunks stay 80 frames (T' = 400 = 5 chunks): the third step of a chunk is half zeros (d rows are zero past frame 80).
 // ---------------------------------------------------------------------------------------------------------------
-// An 8-byte LDS store as ds_write2_b32 of two adjacent dwords.  Not ds_write_b64 / ds_write2st64_b64: on gfx950 a kernel that
-// issues 64-bit LDS stores next to bf16 MFMAs makes OTHER waves' packed-fp32 VALU results wrong (DESIGN.md lesson 12; this library
-// has no packed-fp32 code, but a collective or a framework kernel on the same CU may).  hipcc does not count an asm LDS store:
-// the staging code waits for lgkmcnt(0) itself before its barriers.
-__device__ __forceinline__ void lds_store8(void *p, int lo, int hi) {
-    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1"
-                 :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) void *)p), "v"(lo), "v"(hi) : "memory");
-}
-__device__ __forceinline__ void lds_stores_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 // PRE: x and d arrive as bf16 planes already (p.xpl / p.dpl, written by glowtts_split_planes or a producer's epilogue):
 // staging is then 8-byte loads straight into 8-byte LDS stores, with no vector work at all.
 template <int NS, int TAPS, int NGRP, int MT, bool PRE = false>

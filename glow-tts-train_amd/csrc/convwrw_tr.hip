@@ -515,13 +515,15 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     // 1x1 convolutions stay on the frame-packed kernel: this one is staging-bound there (measured at B=32 / T'=400, 384 <- 192
     // channels: 45 us as 64x32 tiles, 34 us as 64x64, against 30.5 us)
     if (p.taps != 5) return -1;
-    static const bool mt4 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '4'; }();
-    // default: the 32x32x16 form with the storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per
-    // back-to-back launch; 16x16x32 form 66.3; either form with the MULTIPLYING waves raised 67-69); GLOWTTS_WRW_TR=1 selects the
-    // 16x16x32 form
+    // default: 64 x 64 tiles (x staged once per 64 output channels: the loop runs at 86 % of the pipe), whose 20 MB of atomics
+    // drain while the other stream's kernels run — alone it is no faster than the 64 x 32 form (61 us either way), in the step it
+    // is (16.25 -> 16.00 ms, three alternating runs).  GLOWTTS_WRW_TR_MT=2 selects 64 x 32 tiles in the 32x32x16 form with the
+    // storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per back-to-back launch; 16x16x32 form
+    // 66.3; either form with the MULTIPLYING waves raised 67-69), GLOWTTS_WRW_TR=1 their 16x16x32 form
+    static const bool mt2 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '2'; }();
     static const bool w16 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '1'; }();
-    if (ns == 3 && !w16 && !mt4) return launch_wrw_tr<3, 5, 2, true>(p, s);
-    if (ns == 3 && mt4 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0)) return launch_wrw_tr<3, 5, 4>(p, s);
+    if (ns == 3 && !mt2 && !w16 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0)) return launch_wrw_tr<3, 5, 4>(p, s);
+    if (ns == 3 && !w16) return launch_wrw_tr<3, 5, 2, true>(p, s);
     if (ns == 3) return launch_wrw_tr<3, 5, 2>(p, s);
     if (ns == 2) return launch_wrw_tr<2, 5, 2>(p, s);
     if (ns == 1) return launch_wrw_tr<1, 5, 2>(p, s);
