@@ -112,6 +112,32 @@ __device__ __forceinline__ void stage_rows64(float *dst, int pitch, const float 
     }
 }
 
+// The same tile in two halves — its loads into registers, its LDS stores later — so that the NEXT tile's trip to L2 / HBM runs
+// under the MFMAs of the tile being multiplied (16-byte pieces only: T % 4 == 0 and 16-byte aligned rows; rows <= 128).
+template <int N> struct TileRegsN { float4 v[N]; };       // N * 16 rows at most
+typedef TileRegsN<8> TileRegs;
+template <int N>
+__device__ __forceinline__ void tile_load(TileRegsN<N> &r, const float *src, int rows, int T, int col0, int tid) {
+    const int total4 = rows * 16;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int idx = u * 256 + tid;
+        const int row = idx >> 4, c = (idx & 15) << 2;
+        r.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < total4 && col0 + c < T) r.v[u] = *reinterpret_cast<const float4 *>(src + (long)row * T + col0 + c);
+    }
+}
+template <int N>
+__device__ __forceinline__ void tile_store(const TileRegsN<N> &r, float *dst, int pitch, int rows, int tid) {
+    const int total4 = rows * 16;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int idx = u * 256 + tid;
+        if (idx < total4) *reinterpret_cast<float4 *>(dst + (idx >> 4) * pitch + ((idx & 15) << 2)) = r.v[u];
+    }
+}
+__device__ __forceinline__ bool rows16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 #ifdef GLOWTTS_TRACE   // tuning builds only (tools/trace_attn.py)
 __device__ unsigned long long g_attn_trace[1024 * 8];
 #define ATTN_TRACE(i) do { if (threadIdx.x == 0) g_attn_trace[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % 1024 * 8 + (i)] = wall_clock64(); } while (0)
@@ -119,10 +145,15 @@ __device__ unsigned long long g_attn_trace[1024 * 8];
 #define ATTN_TRACE(i) do { } while (0)
 #endif
 
-template <int MODE, bool BF = false>
+// NT: 16-column tiles of the score strip the kernel is compiled for (T <= 16 NT): 10 covers config 2's T_text = 160 with 40
+// accumulator registers per lane instead of 64, and every loop over the strip shorter by 3/8.
+// DTC: head width / 16 when it is compiled in (6: the model's d_k = 96 — MFMA loops without a uniform branch per d tile, which
+// is what lets the compiler put a k-step's LDS reads ahead of the previous step's MFMAs), 0 = any width <= 128.
+template <int MODE, bool BF, int NT, int DTC>
 __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     extern __shared__ __align__(16) float smem[];
-    const int dk = p.dk, T = p.T, w = p.w, TP = p.TP;
+    const int dk = DTC ? DTC * 16 : p.dk, T = p.T, w = p.w, TP = p.TP;
+    constexpr int DA = DTC ? DTC : 8;
     const int EP = dk + 4, E2P = dk + 16;
     float *As = smem;                         // [dk][kAP]
     float *Bs = As + dk * kAP;                // [dk][kBP]
@@ -130,12 +161,16 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     float *E1s = Ps + 64 * TP;                // [16][EP]     E1[r][d]
     float *E2s = E1s + 16 * EP;               // [16][E2P]    E2[r][d]
     float *Rs = E2s + 16 * E2P;               // [4 waves][16][17]
+    unsigned char *Ks = reinterpret_cast<unsigned char *>(Rs + 4 * 16 * 17);   // [64][TP] dropout keep bytes of the strip
+    constexpr int NJT = (NT + 3) / 4;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int waveu = __builtin_amdgcn_readfirstlane(wave);
     const int lcol = lane & 15, lk = lane >> 4;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int DT = dk >> 4;                               // 16-wide tiles along d
+    const int DT = DTC ? DTC : (dk >> 4);                 // 16-wide tiles along d
     const int njt = (T + 63) >> 6;                        // 64-key tiles
+    const int ntile = (T + 15) >> 4;                      // 16-key tiles (<= NT: checked by the launcher)
     const long cbase = ((long)b * p.H + h) * dk;          // first channel row of this head in a (B, C, T) tensor
     const float *Ag = p.a + cbase * T;
     const float *B1g = p.b1 + cbase * T;
@@ -143,8 +178,19 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     const float *mk = p.mask + (long)b * T;
     const long pbase = ((long)b * p.H + h) * T * T;
     const bool rel = (p.e1 != nullptr) && (w >= 0);
+    const bool has_drop = p.drop != nullptr;
 
     ATTN_TRACE(0);
+    // B tiles are double-buffered through registers when their rows can be moved in 16-byte pieces: the loads of tile n + 1 are
+    // issued before the MFMAs of tile n (round 2's kernel made seven trips to memory one after the other: 62 us at T = 160)
+    const bool fast = (T & 3) == 0 && rows16(B1g) && rows16(B2g);
+    TileRegs nx;
+    auto prefetch = [&](const float *src, int col0) { if (fast) tile_load(nx, src, dk, T, col0, tid); };
+    auto commit = [&](const float *src, int col0) {
+        if (fast) tile_store(nx, Bs, kBP, dk, tid);
+        else stage_rows64(Bs, kBP, src, dk, T, col0, tid);
+    };
+    prefetch(B1g, 0);
     // ---- stage the A block [d][64 queries] and both embedding tables --------------------------------------------------
     stage_rows64(As, kAP, Ag, dk, T, q0, tid);
     for (int base = 0; base < 16 * dk; base += 256 * 8) {       // both tables: loads first (independent), stores after
@@ -167,36 +213,105 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             }
         }
     }
+    // ---- the strip's keep bytes, and (backward) its probabilities, as whole rows into LDS: phase 2 then reads them with LDS
+    // latency, per element, without a global load between its stores
+    const int nrow = min(64, T - q0);                     // query rows of this block that exist
+    if (has_drop) {
+        const unsigned char *dg = p.drop + pbase + (long)q0 * T;
+        if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(dg) & 3u) == 0) {
+            const int total = nrow * (T >> 2);            // rows are contiguous: word idx of the strip = word idx in memory
+            const unsigned *dgw = reinterpret_cast<const unsigned *>(dg);
+            const int W = T >> 2;
+            for (int base = 0; base < total; base += 256 * 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    v[u] = idx < total ? dgw[idx] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int r = idx / W, c = idx - r * W;
+                    if (idx < total) reinterpret_cast<unsigned *>(Ks + r * TP)[c] = v[u];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < nrow * T; idx += 256) {
+                const int r = idx / T, c = idx - r * T;
+                Ks[r * TP + c] = dg[idx];
+            }
+        }
+    }
+    if (MODE == 1) {
+        const float *pg = p.p + pbase + (long)q0 * T;
+        const int ncol = ntile * 16;                       // columns the strip uses: zeros beyond T and below row nrow
+        if ((T & 3) == 0 && rows16(pg)) {
+            const int W = ncol >> 2, total = 64 * W;
+            for (int base = 0; base < total; base += 256 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int r = idx / W, c = (idx - r * W) << 2;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < total && r < nrow && c < T) v[u] = *reinterpret_cast<const float4 *>(pg + (long)r * T + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 256 + tid;
+                    const int r = idx / W, c = (idx - r * W) << 2;
+                    if (idx < total) *reinterpret_cast<float4 *>(Ps + r * TP + c) = v[u];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < 64 * ncol; idx += 256) {
+                const int r = idx / ncol, c = idx - r * ncol;
+                Ps[r * TP + c] = (r < nrow && c < T) ? pg[(long)r * T + c] : 0.f;
+            }
+        }
+    }
 
     // ---- phase 1: S strip (16 queries x T keys per wave) ------------------------------------------------------------------
-    f32x4 S[16];
+    f32x4 S[NT];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    commit(B1g, 0);
+    __syncthreads();
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
+    for (int jt = 0; jt < NJT; ++jt) {
         if (jt < njt) {
-            __syncthreads();
-            stage_rows64(Bs, kBP, B1g, dk, T, jt * 64, tid);
-            __syncthreads();
+            if (jt + 1 < njt) prefetch(B1g, (jt + 1) * 64);
+            else prefetch(B2g, 0);
             if constexpr (BF) {
                 for (int kk = 0; kk < dk; kk += 16) {
                     const bf16x4_s av = bf4_strided(As + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        S[jt * 4 + ct] = mma_bf16(av, bf4_strided(Bs + (kk + 4 * lk) * kBP + ct * 16 + lcol, kBP), S[jt * 4 + ct]);
+                        if (jt * 4 + ct < NT)
+                            S[jt * 4 + ct] = mma_bf16(av, bf4_strided(Bs + (kk + 4 * lk) * kBP + ct * 16 + lcol, kBP), S[jt * 4 + ct]);
                 }
             } else {
+#pragma unroll 4
                 for (int kk = 0; kk < dk; kk += 4) {
                     const float av = As[(kk + lk) * kAP + wave * 16 + lcol];
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
-                        const float bv = Bs[(kk + lk) * kBP + ct * 16 + lcol];
-                        S[jt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, S[jt * 4 + ct], 0, 0, 0);
+                        if (jt * 4 + ct < NT) {
+                            const float bv = Bs[(kk + lk) * kBP + ct * 16 + lcol];
+                            S[jt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, S[jt * 4 + ct], 0, 0, 0);
+                        }
                     }
                 }
             }
+            __syncthreads();                           // every wave is done with this tile
+            if (jt + 1 < njt) {
+                commit(B1g, (jt + 1) * 64);
+                __syncthreads();
+            }
         }
     }
+    commit(B2g, 0);                                    // first tile of phase 4: visible after the barrier that opens it
     ATTN_TRACE(1);
     // ---- phase 1b: relative term R[i][r] = sum_d A[d][i] E1[r][d], added on the band j - i + w = r ----------------------
     if (rel) {
@@ -214,106 +329,118 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         float *rw = Rs + wave * 16 * 17;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) rw[(lk * 4 + reg) * 17 + lcol] = R[reg];
+        if (lcol == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) rw[(lk * 4 + reg) * 17 + 16] = 0.f;       // column 16: "outside the band"
+        }
         // (same wave wrote and reads: LDS is in order within a wave; the barrier below is for the compiler)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+        // the band |j - i| <= w <= 7 of this wave's 16 rows touches the column tiles tq - 1 .. tq + 1 only (a uniform test)
+        const int tq = (q0 >> 4) + waveu;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < NT; ++t) {
+            if (t >= tq - 1 && t <= tq + 1) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int il = lk * 4 + reg;
-                const int r = t * 16 + lcol - (q0 + wave * 16 + il) + w;
-                if (r >= 0 && r <= 2 * w) S[t][reg] += rw[il * 17 + r];
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int il = lk * 4 + reg;
+                    const int r = t * 16 + lcol - (q0 + wave * 16 + il) + w;
+                    const int rc = (unsigned)r <= (unsigned)(2 * w) ? r : 16;
+                    S[t][reg] += rw[il * 17 + rc];
+                }
             }
         }
     }
 
     ATTN_TRACE(2);
     // ---- phase 2: softmax (MODE 0) / softmax backward (MODE 1) in registers -----------------------------------------------
-    const int ntile = (T + 15) >> 4;
+    // Branch-free per element: every condition that is not uniform is a select, the global stores are range-checked buffer
+    // stores (a row beyond T lies beyond the buffer; a column beyond T — last tile only — gets an out-of-range offset), keep
+    // bytes and probabilities come from LDS.  (Round 2's form — a guarded load / store per element — compiled to ~90
+    // instructions per element, most of them exec-mask bookkeeping: 19 us of the kernel's 58.)
     float mi[4];
-    int ig[4];
+    int ig[4], voff[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         ig[reg] = q0 + wave * 16 + lk * 4 + reg;
-        mi[reg] = ig[reg] < T ? mk[ig[reg]] : 0.f;
+        mi[reg] = mk[min(ig[reg], T - 1)];
+        mi[reg] = ig[reg] < T ? mi[reg] : 0.f;
+        voff[reg] = (ig[reg] * T + lcol) * 4;             // byte offset of (row, column lcol) in this head's (T, T) matrix
     }
+    float mkc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = t * 16 + lcol;
+        mkc[t] = mk[min(j, T - 1)];
+        mkc[t] = j < T ? mkc[t] : 0.f;
+    }
+    const bool lastok = (ntile - 1) * 16 + lcol < T;      // the only tile with columns beyond T is the last one
+    const float cb_last = lastok ? 0.f : -3.0e38f;
+    const int co_last = lastok ? 0 : 0x40000000;
+    const int bl = p.block_len < 0 ? (1 << 20) : p.block_len;
     float *pw = Ps + wave * 16 * TP;
+    const unsigned char *kw = Ks + wave * 16 * TP;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (MODE == 0 ? p.p : p.ds) + pbase, 0, T * T * 4, 0x00020000);
     if (MODE == 0) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            const int il = lk * 4 + reg;
             float mx = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = t * 16 + lcol;
-                float s = S[t][reg] * p.scale;
-                if (t < ntile && j < T) {
-                    const bool keep = (mi[reg] * mk[j] != 0.f) && (p.block_len < 0 || abs(j - ig[reg]) <= p.block_len);
-                    s = keep ? s : -1e4f;
-                    mx = fmaxf(mx, s);
-                } else {
-                    s = -3.0e38f;
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntile) {
+                    const bool keep = (mi[reg] * mkc[t] != 0.f) && (abs(t * 16 + lcol - ig[reg]) <= bl);
+                    float sv = keep ? S[t][reg] * p.scale : -1e4f;
+                    if (t == ntile - 1) sv += cb_last;
+                    S[t][reg] = sv;
+                    mx = fmaxf(mx, sv);
                 }
-                S[t][reg] = s;
             }
             mx = group16_max(mx);
             float sum = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float e = (t < ntile) ? expf(S[t][reg] - mx) : 0.f;
-                S[t][reg] = e;
-                sum += e;
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntile) {
+                    const float e = __expf(S[t][reg] - mx);
+                    S[t][reg] = e;
+                    sum += e;
+                }
             }
             sum = group16_sum(sum);
-            const float inv = 1.0f / sum;
-            const int il = lk * 4 + reg;
+            const float inv = ig[reg] < T ? 1.0f / sum : 0.f;       // rows beyond T: zeros into the strip, stores dropped
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = t * 16 + lcol;
-                if (t < ntile && j < T) {
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntile) {
                     float pv = S[t][reg] * inv;
-                    if (ig[reg] < T) p.p[pbase + (long)ig[reg] * T + j] = pv;
-                    if (p.drop && ig[reg] < T) pv = p.drop[pbase + (long)ig[reg] * T + j] ? pv * p.drop_scale : 0.f;
-                    pw[il * TP + j] = (ig[reg] < T) ? pv : 0.f;
-                } else if (t < ntile) {
-                    pw[il * TP + j] = 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), prs, voff[reg] + t * 64 + (t == ntile - 1 ? co_last : 0), 0, 0);
+                    if (has_drop) pv = kw[il * TP + t * 16 + lcol] ? pv * p.drop_scale : 0.f;
+                    pw[il * TP + t * 16 + lcol] = pv;
                 }
             }
         }
     } else {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            const int il = lk * 4 + reg;
             float dot = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = t * 16 + lcol;
-                float dp = 0.f, pv = 0.f;
-                if (t < ntile && j < T && ig[reg] < T) {
-                    const long o = pbase + (long)ig[reg] * T + j;
-                    pv = p.p[o];
-                    dp = S[t][reg];
-                    if (p.drop) dp = p.drop[o] ? dp * p.drop_scale : 0.f;
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntile) {
+                    float dp = S[t][reg];
+                    if (has_drop) dp = kw[il * TP + t * 16 + lcol] ? dp * p.drop_scale : 0.f;
+                    S[t][reg] = dp;
+                    dot += pw[il * TP + t * 16 + lcol] * dp;           // (staged as zero beyond T in either direction)
                 }
-                S[t][reg] = dp;
-                dot += pv * dp;
-                // keep pv for the second sweep in the low bits of nothing: re-read below (L2-resident, tiny)
             }
             dot = group16_sum(dot);
-            const int il = lk * 4 + reg;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = t * 16 + lcol;
-                if (t < ntile && j < T) {
-                    float dsv = 0.f;
-                    if (ig[reg] < T) {
-                        const long o = pbase + (long)ig[reg] * T + j;
-                        const bool keep = (mi[reg] * mk[j] != 0.f) && (p.block_len < 0 || abs(j - ig[reg]) <= p.block_len);
-                        dsv = keep ? p.p[o] * (S[t][reg] - dot) * p.scale : 0.f;
-                        p.ds[o] = dsv;
-                    }
-                    pw[il * TP + j] = dsv;
-                } else if (t < ntile) {
-                    pw[il * TP + j] = 0.f;
+            for (int t = 0; t < NT; ++t) {
+                if (t < ntile) {
+                    const bool keep = (mi[reg] * mkc[t] != 0.f) && (abs(t * 16 + lcol - ig[reg]) <= bl);
+                    const float dsv = keep ? pw[il * TP + t * 16 + lcol] * (S[t][reg] - dot) * p.scale : 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dsv), prs, voff[reg] + t * 64 + (t == ntile - 1 ? co_last : 0), 0, 0);
+                    pw[il * TP + t * 16 + lcol] = dsv;
                 }
             }
         }
@@ -321,32 +448,37 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
 
     ATTN_TRACE(3);
     // ---- phase 4: O (16 queries x dk per wave) = P B2^T + PW E2 -----------------------------------------------------------
-    f32x4 O[8];
+    f32x4 O[DA];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DA; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
     for (int jt = 0; jt < njt; ++jt) {
-        __syncthreads();
-        stage_rows64(Bs, kBP, B2g, dk, T, jt * 64, tid);
-        __syncthreads();
+        if (jt + 1 < njt) prefetch(B2g, (jt + 1) * 64);
         const int jmax = min(64, ((T - jt * 64 + 15) >> 4) << 4);     // keys of this tile that exist in the P strip
         if constexpr (BF) {
             for (int kk = 0; kk < jmax; kk += 16) {
                 const bf16x4_s av = bf4_row(pw + lcol * TP + jt * 64 + kk + 4 * lk);
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt)
-                    if (dt < DT) O[dt] = mma_bf16(av, bf4_row(Bs + (dt * 16 + lcol) * kBP + kk + 4 * lk), O[dt]);
+                for (int dt = 0; dt < DA; ++dt)
+                    if (DTC || dt < DT) O[dt] = mma_bf16(av, bf4_row(Bs + (dt * 16 + lcol) * kBP + kk + 4 * lk), O[dt]);
             }
         } else {
+#pragma unroll 4
             for (int kk = 0; kk < jmax; kk += 4) {
                 const float av = pw[lcol * TP + jt * 64 + kk + lk];
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    if (dt < DT) {
+                for (int dt = 0; dt < DA; ++dt) {
+                    if (DTC || dt < DT) {
                         const float bv = Bs[(dt * 16 + lcol) * kBP + kk + lk];
                         O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
                     }
                 }
             }
+        }
+        if (jt + 1 < njt) {
+            __syncthreads();
+            commit(B2g, (jt + 1) * 64);
+            __syncthreads();
         }
     }
     if (rel) {
@@ -360,16 +492,16 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             }
             const bf16x4_s av = bf4(pv[0], pv[1], pv[2], pv[3]);
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
-                if (dt < DT) O[dt] = mma_bf16(av, bf4_strided(E2s + (4 * lk) * E2P + dt * 16 + lcol, E2P), O[dt]);
+            for (int dt = 0; dt < DA; ++dt)
+                if (DTC || dt < DT) O[dt] = mma_bf16(av, bf4_strided(E2s + (4 * lk) * E2P + dt * 16 + lcol, E2P), O[dt]);
         } else {
             for (int kk = 0; kk < 2 * w + 1; kk += 4) {
                 const int r = kk + lk;
                 const int j = iq + r - w;
                 const float av = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    if (dt < DT) {
+                for (int dt = 0; dt < DA; ++dt) {
+                    if (DTC || dt < DT) {
                         const float bv = E2s[r * E2P + dt * 16 + lcol];
                         O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
                     }
@@ -382,8 +514,8 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     // ---- phase 5: transpose O through LDS (reuse the A block) and store rows of 64 queries -----------------------------
     __syncthreads();
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-        if (dt < DT)
+    for (int dt = 0; dt < DA; ++dt)
+        if (DTC || dt < DT)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) As[(dt * 16 + lcol) * kAP + wave * 16 + lk * 4 + reg] = O[dt][reg];
     __syncthreads();
@@ -408,10 +540,11 @@ struct AttnDkvParams {
     float drop_scale;
 };
 
-template <bool BF = false>
+template <bool BF, int DTC>
 __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
     extern __shared__ __align__(16) float smem[];
-    const int dk = p.dk, T = p.T;
+    const int dk = DTC ? DTC * 16 : p.dk, T = p.T;
+    constexpr int DA = DTC ? DTC : 8;
     float *Dos = smem;                  // [dk][kBP]  dO chunk   [d][i]
     float *Qs = Dos + dk * kBP;         // [dk][kBP]  Q chunk
     float *Pds = Qs + dk * kBP;         // [64][kAP]  dropped P chunk  [i][j]
@@ -419,17 +552,58 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lcol = lane & 15, lk = lane >> 4;
     const int j0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int DT = dk >> 4;
+    const int DT = DTC ? DTC : (dk >> 4);
     const long cbase = ((long)b * p.H + h) * dk;
     const long pbase = ((long)b * p.H + h) * T * T;
-    f32x4 aV[8], aK[8];
+    const float *dog = p.dout + cbase * T, *qg = p.q + cbase * T;
+    f32x4 aV[DA], aK[DA];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) { aV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int dt = 0; dt < DA; ++dt) { aV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; aK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // the four tiles of the next 64-query chunk travel while this chunk is multiplied (16-byte pieces; else staged in place)
+    const bool fast = (T & 3) == 0 && rows16(dog) && rows16(qg) && rows16(p.p + pbase) && rows16(p.ds + pbase) &&
+                      (!p.drop || (reinterpret_cast<uintptr_t>(p.drop + pbase) & 3u) == 0);
+    TileRegs rDo, rQ;
+    TileRegsN<4> rP, rDs;                       // 64 rows
+    unsigned rK[4];
+    auto prefetch = [&](int i0) {
+        const int rows = min(64, T - i0);
+        tile_load(rDo, dog, dk, T, i0, tid);
+        tile_load(rQ, qg, dk, T, i0, tid);
+        tile_load(rP, p.p + pbase + (long)i0 * T, rows, T, j0, tid);
+        tile_load(rDs, p.ds + pbase + (long)i0 * T, rows, T, j0, tid);
+        if (p.drop) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = u * 256 + tid;
+                const int row = idx >> 4, c = (idx & 15) << 2;
+                rK[u] = (row < rows && j0 + c < T)
+                            ? *reinterpret_cast<const unsigned *>(p.drop + pbase + (long)(i0 + row) * T + j0 + c) : 0u;
+            }
+        }
+    };
+    auto commit = [&]() {
+        tile_store(rDo, Dos, kBP, dk, tid);
+        tile_store(rQ, Qs, kBP, dk, tid);
+        if (p.drop) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rP.v[u].x = (rK[u] & 0xffu) ? rP.v[u].x * p.drop_scale : 0.f;
+                rP.v[u].y = (rK[u] & 0xff00u) ? rP.v[u].y * p.drop_scale : 0.f;
+                rP.v[u].z = (rK[u] & 0xff0000u) ? rP.v[u].z * p.drop_scale : 0.f;
+                rP.v[u].w = (rK[u] & 0xff000000u) ? rP.v[u].w * p.drop_scale : 0.f;
+            }
+        }
+        tile_store(rP, Pds, kAP, 64, tid);            // all 64 rows: rows beyond the chunk were loaded as zeros
+        tile_store(rDs, Dss, kAP, 64, tid);
+    };
+    if (fast) prefetch(0);
     for (int i0 = 0; i0 < T; i0 += 64) {
         __syncthreads();
-        stage_rows64(Dos, kBP, p.dout + cbase * T, dk, T, i0, tid);
-        stage_rows64(Qs, kBP, p.q + cbase * T, dk, T, i0, tid);
-        {
+        if (fast) {
+            commit();
+        } else {
+            stage_rows64(Dos, kBP, dog, dk, T, i0, tid);
+            stage_rows64(Qs, kBP, qg, dk, T, i0, tid);
             const int rows = min(64, T - i0);
             stage_rows64(Dss, kAP, p.ds + pbase + (long)i0 * T, rows, T, j0, tid);
             // dropped probabilities: keep byte applied while staging, 8 independent loads per thread as above
@@ -456,14 +630,15 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
             for (int idx = rows * 64 + tid; idx < 64 * 64; idx += 256) Dss[(idx >> 6) * kAP + (idx & 63)] = 0.f;
         }
         __syncthreads();
+        if (fast && i0 + 64 < T) prefetch(i0 + 64);
         if constexpr (BF) {
             const int imax = min(64, ((T - i0 + 15) >> 4) << 4);               // (rows / columns beyond T are staged as zeros)
             for (int kk = 0; kk < imax; kk += 16) {
                 const bf16x4_s bp = bf4_strided(Pds + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
                 const bf16x4_s bd = bf4_strided(Dss + (kk + 4 * lk) * kAP + wave * 16 + lcol, kAP);
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    if (dt < DT) {
+                for (int dt = 0; dt < DA; ++dt) {
+                    if (DTC || dt < DT) {
                         aV[dt] = mma_bf16(bf4_row(Dos + (dt * 16 + lcol) * kBP + kk + 4 * lk), bp, aV[dt]);
                         aK[dt] = mma_bf16(bf4_row(Qs + (dt * 16 + lcol) * kBP + kk + 4 * lk), bd, aK[dt]);
                     }
@@ -471,12 +646,13 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
             }
         } else {
             const int imax = min(64, ((T - i0 + 3) >> 2) << 2);
+#pragma unroll 2
             for (int kk = 0; kk < imax; kk += 4) {
                 const float bp = Pds[(kk + lk) * kAP + wave * 16 + lcol];      // B[k = query][col = key]
                 const float bd = Dss[(kk + lk) * kAP + wave * 16 + lcol];
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    if (dt < DT) {
+                for (int dt = 0; dt < DA; ++dt) {
+                    if (DTC || dt < DT) {
                         const float ao = Dos[(dt * 16 + lcol) * kBP + kk + lk];   // A[row = d][k = query]
                         const float aq = Qs[(dt * 16 + lcol) * kBP + kk + lk];
                         aV[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao, bp, aV[dt], 0, 0, 0);
@@ -488,8 +664,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(AttnDkvParams p) {
     }
     const int j = j0 + wave * 16 + lcol;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-        if (dt < DT && j < T) {
+    for (int dt = 0; dt < DA; ++dt) {
+        if ((DTC || dt < DT) && j < T) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const long o = (cbase + dt * 16 + lk * 4 + reg) * T + j;
@@ -578,19 +754,25 @@ static int attn_check(const char *name, int B, int H, int T, int dk, int w) {
 
 static size_t attn_lds(int dk, int TP) {
     return ((size_t)dk * kAP + (size_t)dk * kBP + (size_t)64 * TP + (size_t)16 * (dk + 4) + (size_t)16 * (dk + 16) + 4 * 16 * 17) *
-           sizeof(float);
+               sizeof(float) + (size_t)64 * TP;        // + the keep bytes of the strip
 }
 
-template <int MODE, bool BF>
-static int attn_launch(AttnParams &p, hipStream_t s) {
+template <int MODE, bool BF, int NT, int DTC>
+static int attn_launch_nt(AttnParams &p, hipStream_t s) {
     p.TP = ((p.T + 15) / 16) * 16 + 4;
     const size_t lds = attn_lds(p.dk, p.TP);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE, BF>), lds, "glowtts_rel_attn")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE, BF, NT, DTC>), lds, "glowtts_rel_attn")) return rc_;
     dim3 grid((p.T + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL((attn_qblock_kernel<MODE, BF>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_qblock_kernel<MODE, BF, NT, DTC>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
+}
+
+template <int MODE, bool BF>
+static int attn_launch(AttnParams &p, hipStream_t s) {
+    if (p.dk == 96) return p.T <= 160 ? attn_launch_nt<MODE, BF, 10, 6>(p, s) : attn_launch_nt<MODE, BF, 16, 6>(p, s);
+    return p.T <= 160 ? attn_launch_nt<MODE, BF, 10, 0>(p, s) : attn_launch_nt<MODE, BF, 16, 0>(p, s);
 }
 
 }  // namespace glowtts
@@ -641,14 +823,19 @@ extern "C" int glowtts_rel_attn_bwd_ex(const float *dout, const float *q, const 
     d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
     d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
     const size_t lds = ((size_t)2 * dk * kBP + (size_t)2 * 64 * kAP) * sizeof(float);
-    static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (bf16_mma) {
-        static LdsLimit attr_max_b;
-        if (int rc_ = attr_max_b.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel<true>), lds, "glowtts_rel_attn_bwd")) return rc_;
-        hipLaunchKernelGGL(attn_dkv_kernel<true>, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
-    } else {
-        if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_dkv_kernel<false>), lds, "glowtts_rel_attn_bwd")) return rc_;
-        hipLaunchKernelGGL(attn_dkv_kernel<false>, dim3((T + 63) / 64, H, B), dim3(256), lds, s, d);
+    {
+        const void *fn = bf16_mma ? (dk == 96 ? reinterpret_cast<const void *>(&attn_dkv_kernel<true, 6>) : reinterpret_cast<const void *>(&attn_dkv_kernel<true, 0>))
+                                  : (dk == 96 ? reinterpret_cast<const void *>(&attn_dkv_kernel<false, 6>) : reinterpret_cast<const void *>(&attn_dkv_kernel<false, 0>));
+        static LdsLimit lim[4];   // per device and instantiation: raised only when a launch needs more than any earlier one
+        if (int rc_ = lim[(bf16_mma ? 2 : 0) + (dk == 96 ? 1 : 0)].ensure(fn, lds, "glowtts_rel_attn_bwd")) return rc_;
+        const dim3 grid((T + 63) / 64, H, B);
+        if (bf16_mma) {
+            if (dk == 96) hipLaunchKernelGGL((attn_dkv_kernel<true, 6>), grid, dim3(256), lds, s, d);
+            else hipLaunchKernelGGL((attn_dkv_kernel<true, 0>), grid, dim3(256), lds, s, d);
+        } else {
+            if (dk == 96) hipLaunchKernelGGL((attn_dkv_kernel<false, 6>), grid, dim3(256), lds, s, d);
+            else hipLaunchKernelGGL((attn_dkv_kernel<false, 0>), grid, dim3(256), lds, s, d);
+        }
     }
     if (emb_k) {
         const int nr = 2 * window + 1;

@@ -5,9 +5,8 @@ run() { # name, env...
   python -c "
 import json
 d=json.loads(open('gpurun_out/ab/$name.json').read().strip().splitlines()[-1])
-r=d['roofline']; k=r['mfma_kernels']
-pick=['glowtts_conv_wrw[M384 K192x5 N32x400]','glowtts_conv_gate_fwd[M384 K192x5 N32x400]','glowtts_conv_fwd[M192 K384x5 N32x400]','glowtts_conv_gate_bwd[M192 K384x1 N32x400]','glowtts_conv_res_skip_fwd[M384 K192x1 N32x400]','glowtts_conv_wrw[M384 K192x1 N32x400]']
-print('$name:', round(d['ms_per_step'],3), 'native', round(d['native_fp32']['ms_per_step'],2), ' '.join(str(k[x]['mean_us']) for x in pick))"
+r=d['roofline']; k=r['other_kernels']
+print('$name:', round(d['ms_per_step'],3), 'native', round(d['native_fp32']['ms_per_step'],2), 'attn fwd/bwd', k['glowtts_rel_attn_fwd_ex']['mean_us'], k['glowtts_rel_attn_bwd_ex']['mean_us'])"
 }
 for rep in 1 2; do
 run new_$rep A=1
