@@ -119,7 +119,7 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
 
 # bench tag -> (HIP kernel, grid size) of the committed counter passes, per arithmetic of the WN convolutions
 _PMC_KERNEL = {
-    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,2,true> grid=129024",
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false> grid=129024",
     ("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32"): "convwrw_fp_kernel<5,5,2> grid=196608",
     ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
     ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
