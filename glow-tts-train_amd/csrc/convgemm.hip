@@ -1150,6 +1150,53 @@ extern "C" int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long 
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw");
 }
 
+// Several weight gradients of ONE shape in one launch (dilation 1, 'same' padding): x[q] (B, Cin, T), d[q] (B, M, T) or, with d2,
+// rows [d_split, M) from d2[q]; dwp[q] / dbias[q] accumulated as in glowtts_conv_wrw; mask / mask_x (single-source form only) are
+// shared by the problems.  The arrays are HOST arrays of device pointers.  Without a kernel for the batch (native fp32 arithmetic,
+// other shapes) the problems are launched one by one.
+extern "C" int glowtts_conv_wrw_batch(int n, const float *const *x, long x_bs, const float *const *d, long d_bs,
+                                      const float *const *d2, long d2_bs, int d_split, const float *mask, const float *mask_x,
+                                      float *const *dwp, float *const *dbias, int B, int Cin, int M, int T, int taps, int dil,
+                                      int pad, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(n >= 1 && x && d && dwp, "glowtts_conv_wrw_batch: null pointer");
+    GLOWTTS_CHECK_ARG(!d2 || (!mask && !mask_x), "glowtts_conv_wrw_batch: the two-source form takes no masks");
+    GLOWTTS_CHECK_ARG(B >= 0 && Cin > 0 && M > 0 && T >= 0 && taps >= 1 && dil >= 1 && pad >= 0, "glowtts_conv_wrw_batch: bad shape");
+    GLOWTTS_CHECK_ARG(!d2 || (d_split > 0 && d_split < M), "glowtts_conv_wrw_batch: bad d_split");
+    if ((long)B * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    for (int q0 = 0; q0 < n; q0 += ConvWrwParams::kMaxBatch) {
+        const int nb = n - q0 < ConvWrwParams::kMaxBatch ? n - q0 : ConvWrwParams::kMaxBatch;
+        bool ok = nb > 1 && dil == 1 && pad == (taps - 1) / 2 && (taps == 1 || taps == 3 || taps == 5) && T % 4 == 0 &&
+                  x_bs % 4 == 0 && d_bs % 4 == 0 && (!d2 || (d2_bs % 4 == 0 && d_split % 64 == 0)) &&
+                  (!mask || aligned16(mask)) && (!mask_x || aligned16(mask_x));
+        ConvWrwParams p{};
+        for (int q = 0; q < nb && ok; ++q) {
+            const float *dq2 = d2 ? d2[q0 + q] : nullptr;
+            GLOWTTS_CHECK_ARG(x[q0 + q] && d[q0 + q] && dwp[q0 + q] && (!d2 || dq2), "glowtts_conv_wrw_batch: null pointer in problem %d", q0 + q);
+            ok = aligned16(x[q0 + q]) && aligned16(d[q0 + q]) && (!dq2 || aligned16(dq2));
+            p.bx[q] = x[q0 + q]; p.bd[q] = d[q0 + q]; p.bd2[q] = dq2; p.bdwp[q] = dwp[q0 + q];
+            p.bdbias[q] = dbias ? dbias[q0 + q] : nullptr;
+        }
+        if (ok) {
+            p.x = p.bx[0]; p.d = p.bd[0]; p.d2 = p.bd2[0]; p.dwp = p.bdwp[0]; p.dbias = p.bdbias[0];
+            p.d2_bs = d2_bs; p.d_split = d_split; p.x_bs = x_bs; p.d_bs = d_bs; p.mask = mask; p.mask_x = mask_x;
+            p.B = B; p.Cin = Cin; p.M = M; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
+            p.nbatch = nb;
+            const int rc = conv_wrw_split_dispatch(p, s);
+            if (rc > 0) return rc;
+            if (rc == 0) continue;
+        }
+        for (int q = q0; q < q0 + nb; ++q) {               // one by one
+            const int rc = d2 ? glowtts_conv_wrw2(x[q], x_bs, d[q], d_bs, d2[q], d2_bs, d_split, dwp[q], dbias ? dbias[q] : nullptr, B, Cin,
+                                                  M, T, taps, dil, pad, stream)
+                              : glowtts_conv_wrw(x[q], x_bs, d[q], d_bs, mask, mask_x, dwp[q], dbias ? dbias[q] : nullptr, B, Cin, M,
+                                                 T, taps, dil, pad, stream);
+            if (rc != 0) return rc;
+        }
+    }
+    return 0;
+}
+
 extern "C" int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout,
                                    int Cin, int taps, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(v && (wp_f || wp_b), "glowtts_pack_weight: null pointer");

@@ -470,6 +470,14 @@ struct ConvWrwParams {
     long xpl_stride, dpl_stride;       //   the fp32 tensors, plane pl at + pl * stride elements); x / d are then unused
     int nb;              // utterances per workgroup (split of the contraction)
     int xs_pitch, ds_pitch;
+    // Several problems of ONE shape in one launch (the weight gradients of a WN stack's layers: their operands all exist when the
+    // stack's dx chain has run): nbatch > 0 -> problem q takes bx[q], bd[q], bd2[q] (or null), bdwp[q], bdbias[q] (or null); the
+    // grid's z extent is nbatch x splits.  A launch per problem ends with its split-K atomics draining before the next one may
+    // start; in one launch the next problem's workgroups take the compute units as they free up.
+    static constexpr int kMaxBatch = 4;
+    const float *bx[kMaxBatch], *bd[kMaxBatch], *bd2[kMaxBatch];
+    float *bdwp[kMaxBatch], *bdbias[kMaxBatch];
+    int nbatch;
 };
 
 // convgemm_split.hip: the frame-packed weight-gradient kernel on bf16 planes; -1 = not handled

@@ -382,7 +382,14 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     const int ntiles = gridDim.x, nwg = gridDim.x * gridDim.z;
     const int id = blockIdx.x + blockIdx.z * gridDim.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    int item = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    if (p.nbatch > 0) {                               // several problems of one shape (ConvWrwParams::nbatch)
+        const int per = nwg / p.nbatch, q = item / per;
+        item -= q * per;
+#pragma unroll
+        for (int j = 0; j < ConvWrwParams::kMaxBatch; ++j)         // static indices: a run-time index would put the tables in scratch
+            if (j == q) { p.x = p.bx[j]; p.d = p.bd[j]; p.d2 = p.bd2[j]; p.dwp = p.bdwp[j]; p.dbias = p.bdbias[j]; }
+    }
     const int tile = item % ntiles, split = item / ntiles;
     const int kt = tile % nkt, mt = tile / nkt;
     const int k0 = kt * 64, m0 = mt * MR;
@@ -813,7 +820,7 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
-    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
+    dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");
 }

@@ -82,7 +82,14 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     const int ntiles = gridDim.x, nwg = gridDim.x * gridDim.z;
     const int id = blockIdx.x + blockIdx.z * gridDim.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int witem = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    int witem = xcd * (nwg >> 3) + min(xcd, nwg & 7) + slot;
+    if (p.nbatch > 0) {                               // XCD-major over the whole batch: an XCD works on one problem at a time
+        const int per = nwg / p.nbatch, q = witem / per;
+        witem -= q * per;
+#pragma unroll
+        for (int j = 0; j < ConvWrwParams::kMaxBatch; ++j)         // static indices: a run-time index would put the tables in scratch
+            if (j == q) { p.x = p.bx[j]; p.d = p.bd[j]; p.d2 = p.bd2[j]; p.dwp = p.bdwp[j]; p.dbias = p.bdbias[j]; }
+    }
     const int tile = witem % ntiles, split = witem / ntiles;
     const int kt = tile % nkt, mt = tile / nkt;
     const int k0 = kt * 64, m0 = mt * MR;
@@ -498,7 +505,7 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     p.nb = (total + splits - 1) / splits;
     static const int prio_mode = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_PRIO"); return e ? std::atoi(e) : 2; }();
     p.xs_pitch = prio_mode;          // (tuning switch: 0 = the multiplying waves run at raised priority, 1 = nobody, 2 = the storing waves)
-    dim3 grid(tiles, 1, (total + p.nb - 1) / p.nb);
+    dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT, W32>), grid, dim3(512), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (tr)");
 }

@@ -133,6 +133,50 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
         const float *actsf = static_cast<const float *>(acts), *tsf = static_cast<const float *>(ts);
         float *d_rsf = static_cast<float *>(d_rs), *d_xinf = static_cast<float *>(d_xin), *dxf = static_cast<float *>(dx);
         const float *dskf = static_cast<const float *>(dskip);
+        // Default: the dx chain of the whole stack first, then the stack's weight gradients as batched launches
+        // (glowtts_conv_wrw_batch: the 5-tap ones of all layers in one launch, the 1x1 two-source ones of layers 0 .. n-2 in
+        // another): a launch per problem ends with its split-K atomics draining before the stream's next kernel may start; in one
+        // launch the next problem's workgroups take the compute units as they free up — 15.54 -> 15.30 ms per step (three
+        // alternating runs).  GLOWTTS_WRW_BATCH=0: a launch per layer, each as soon as its operands exist.
+        static const bool batch = [] { const char *e = getenv("GLOWTTS_WRW_BATCH"); return !(e && e[0] == '0'); }();
+        if (batch && n_layers <= 8) {
+            const float *bx5[8], *bd5[8], *bx1[8], *bd1[8], *bd1b[8];
+            float *bw5[8], *bb5[8], *bw1[8], *bb1[8];
+            for (int i = n_layers - 1; i >= 0; --i) {
+                const glowtts_wn_layer &L = layers[i];
+                const bool last = i == n_layers - 1;
+                const float *ts_i = tsf + (long)i * 2 * BHT;
+                const unsigned char *drop_i = drop ? drop + (long)i * 2 * BHT : nullptr;
+                float *dxin_i = d_xinf + (long)i * 2 * BHT, *dx_i = dxf + (long)i * BHT;
+                const float *half = last ? nullptr : dxf + (long)(i + 1) * BHT;
+                if (last) {
+                    WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
+                    dskf = d_rsf;
+                    WN_TRY(glowtts_conv_gate_bwd_io(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                                                    dcond ? dcond + (long)i * B * 2 * H : nullptr, B, H, H, T, 0, stream));
+                } else {
+                    WN_TRY(glowtts_conv_gate_bwd_io(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                                                    dcond ? dcond + (long)i * B * 2 * H : nullptr, B, 2 * H, H, T, 0, stream));
+                }
+                const bool m_out = i > 0 || mask_input_grad;
+                WN_TRY(glowtts_conv_fwd(dxin_i, (long)2 * H * T, L.wb_in, nullptr, m_out ? mask : nullptr, half, (long)H * T, dx_i,
+                                        (long)H * T, B, 2 * H, H, T, taps, 1, (taps - 1) - pad, 0, m_out ? 1 : 0, 0, stream));
+                bx5[i] = i == 0 ? xf : xsf + (long)(i - 1) * BHT; bd5[i] = dxin_i; bw5[i] = L.dwp_in; bb5[i] = L.db_in;
+                bx1[i] = actsf + (long)i * BHT; bd1[i] = half; bd1b[i] = dskf; bw1[i] = L.dwp_rs; bb1[i] = L.db_rs;
+            }
+            WN_TRY(order_after(ms, ws));
+            const int nl = n_layers - 1;
+            WN_TRY(glowtts_conv_wrw(bx1[nl], (long)H * T, d_rsf, (long)H * T, nullptr, nullptr, bw1[nl], bb1[nl], B, H, H, T, 1, 1, 0,
+                                    (glowtts_stream_t)ws));
+            if (nl > 0)
+                WN_TRY(glowtts_conv_wrw_batch(nl, bx1, (long)H * T, bd1, (long)H * T, bd1b, (long)H * T, H, nullptr, nullptr, bw1, bb1, B, H,
+                                              2 * H, T, 1, 1, 0, (glowtts_stream_t)ws));
+            WN_TRY(glowtts_conv_wrw_batch(n_layers, bx5, (long)H * T, bd5, (long)2 * H * T, nullptr, 0, 0, nullptr, nullptr, bw5, bb5, B, H,
+                                          2 * H, T, taps, 1, pad, (glowtts_stream_t)ws));
+            if (unpack_desc)
+                WN_TRY(glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows, (glowtts_stream_t)ws));
+            return 0;
+        }
         for (int i = n_layers - 1; i >= 0; --i) {
             const glowtts_wn_layer &L = layers[i];
             const bool last = i == n_layers - 1;
@@ -424,9 +468,11 @@ extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float
                                 L->demb_v, B, heads, T, dk, window, heads_share, block_len, L->attn_bf16, stream));
     // q, k, v convs of x * mask: dx = dxa + mask * (Wq^T dq + Wk^T dk + Wv^T dv)
     WN_TRY(order_after(ms, ws));
-    WN_TRY(glowtts_conv_wrw(x, HT, dq, HT, nullptr, mask, L->dwp_q, L->db_q, B, H, H, T, 1, 1, 0, wss));
-    WN_TRY(glowtts_conv_wrw(x, HT, dkk, HT, nullptr, mask, L->dwp_k, L->db_k, B, H, H, T, 1, 1, 0, wss));
-    WN_TRY(glowtts_conv_wrw(x, HT, dv, HT, nullptr, mask, L->dwp_v, L->db_v, B, H, H, T, 1, 1, 0, wss));
+    {
+        const float *bx[3] = {x, x, x}, *bd[3] = {dq, dkk, dv};
+        float *bw[3] = {L->dwp_q, L->dwp_k, L->dwp_v}, *bb[3] = {L->db_q, L->db_k, L->db_v};
+        WN_TRY(glowtts_conv_wrw_batch(3, bx, HT, bd, HT, nullptr, 0, 0, nullptr, mask, bw, bb, B, H, H, T, 1, 1, 0, wss));
+    }
     // dxa is masked already and mask * mask = mask, so dxa + mask * S = mask * (dxa + S): the chain starts from dxa and the
     // last convolution masks the sum
     WN_TRY(glowtts_conv_fwd(dq, HT, L->wb_q, nullptr, nullptr, dxa, HT, dx, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));

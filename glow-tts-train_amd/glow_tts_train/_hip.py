@@ -50,6 +50,7 @@ _SIGNATURES = {
     "glowtts_conv_gate_bwd": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I],
     "glowtts_conv_wrw2": [_P, _L, _P, _L, _P, _L, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_wrw": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_conv_wrw_batch": [_I, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_chan_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],

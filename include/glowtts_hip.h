@@ -194,6 +194,14 @@ int glowtts_conv_wrw2(const float *x, long x_bs, const float *d, long d_bs, cons
 int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const float *mask, const float *mask_x,
                      float *dwp, float *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad,
                      glowtts_stream_t stream);
+/* n weight gradients of ONE shape in one launch (the layers of a WN stack, whose operands all exist once the stack's dx chain has
+ * run): problem q is glowtts_conv_wrw (d2 == NULL) or glowtts_conv_wrw2 on (x[q], d[q], d2[q]) -> dwp[q], dbias[q] (dbias or its
+ * entries may be NULL); mask / mask_x as in glowtts_conv_wrw, shared by the problems (single-source form only).  x, d, d2, dwp, dbias are HOST arrays of n device pointers.  In the bf16-plane arithmetic the
+ * problems share a launch (the next problem's workgroups start while the previous one's split-K atomics drain); otherwise, and
+ * for shapes without such a kernel, they are launched one by one — the results are the same either way. */
+int glowtts_conv_wrw_batch(int n, const float *const *x, long x_bs, const float *const *d, long d_bs, const float *const *d2,
+                           long d2_bs, int d_split, const float *mask, const float *mask_x, float *const *dwp,
+                           float *const *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
 int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
                         int taps, glowtts_stream_t stream);
 

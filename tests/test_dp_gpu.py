@@ -159,10 +159,11 @@ def _ddi_worker(rank, world, port, q):
             an = layers.ActNorm(16, ddi=True).cuda()
             an.ddi_all_reduce = flag
             an(xs[rank], mask)
-            out[flag] = (an.logs.detach().flatten().cpu(), an.bias.detach().flatten().cpu())
+            out[flag] = (an.logs.detach().flatten().cpu().numpy(), an.bias.detach().flatten().cpu().numpy())
         both = layers.ActNorm(16, ddi=True).cuda()       # what one process sees on the concatenated batch
         both(torch.cat(xs), torch.cat([mask] * world))
-        q.put((rank, out, (both.logs.detach().flatten().cpu(), both.bias.detach().flatten().cpu())))
+        # numpy arrays travel by value: a torch tensor in a Queue is a handle to the SENDER's shared memory, gone when it exits
+        q.put((rank, out, (both.logs.detach().flatten().cpu().numpy(), both.bias.detach().flatten().cpu().numpy())))
     finally:
         dist.destroy_process_group()
 
@@ -183,9 +184,10 @@ def test_actnorm_ddi_all_reduce_flag_two_ranks():
         p.join(120)
         assert p.exitcode == 0
     (_, out0, glob), (_, out1, _) = res
-    assert not torch.allclose(out0[False][0], out1[False][0], atol=1e-3), "default: per-rank statistics"
+    tt = torch.from_numpy
+    assert not torch.allclose(tt(out0[False][0]), tt(out1[False][0]), atol=1e-3), "default: per-rank statistics"
     for a, b, c in zip(out0[True], out1[True], glob):
-        assert torch.allclose(a, b, atol=1e-6) and torch.allclose(a, c, atol=1e-5), "flag: statistics of the global batch"
+        assert torch.allclose(tt(a), tt(b), atol=1e-6) and torch.allclose(tt(a), tt(c), atol=1e-5), "flag: statistics of the global batch"
 
 
 # ------------------------------------------------------------------------------------------------ RCCL on one card

@@ -1553,3 +1553,48 @@ def test_pack_and_unpack_tile_kernels_vs_torch(G):
         assert_close(dv - a0, v64.grad.float(), rtol=1e-5, atol=2e-6 * float(v64.grad.abs().max()), what=f"dv {co, ci, k}")
         if wn:
             assert_close(dg - b0, g64.grad.float(), rtol=1e-5, atol=2e-6 * float(g64.grad.abs().max()), what=f"dg {co, ci, k}")
+
+
+# ---- several weight gradients of one shape in one launch (glowtts_conv_wrw_batch) against one launch per problem
+@pytest.mark.parametrize("taps,two,masked,n", [(5, False, False, 4), (1, True, False, 3), (1, False, True, 3), (3, False, False, 5)])
+def test_conv_wrw_batch_matches_single_launches(G, conv_mode, taps, two, masked, n):
+    import ctypes
+
+    call, ptr = G.hip.call, G.hip.ptr
+    torch.manual_seed(taps + n)
+    b, k, m, t = 6, 192, 384, 120
+    keep = []
+
+    def parr(ts):
+        a = (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+        keep.append(a)
+        return ctypes.addressof(a)
+
+    xs = [torch.randn(b, k, t, device="cuda") for _ in range(n)]
+    ds = [torch.randn(b, m // 2 if two else m, t, device="cuda") for _ in range(n)]
+    d2 = [torch.randn(b, m // 2, t, device="cuda") for _ in range(n)] if two else None
+    lens = torch.linspace(t, t // 2, b).long()
+    mask = (torch.arange(t)[None] < lens[:, None]).float().cuda() if masked else None
+    ref = [torch.zeros(taps, k, m, device="cuda") for _ in range(n)]
+    out = [torch.zeros(taps, k, m, device="cuda") for _ in range(n)]
+    rb = [torch.zeros(m, device="cuda") for _ in range(n)]
+    ob = [torch.zeros(m, device="cuda") for _ in range(n)]
+    pad = (taps - 1) // 2
+    for q in range(n):
+        if two:
+            call("glowtts_conv_wrw2", ptr(xs[q]), xs[q].stride(0), ptr(ds[q]), ds[q].stride(0), ptr(d2[q]), d2[q].stride(0), m // 2,
+                 ptr(ref[q]), ptr(rb[q]), b, k, m, t, taps, 1, pad)
+        else:
+            call("glowtts_conv_wrw", ptr(xs[q]), xs[q].stride(0), ptr(ds[q]), ds[q].stride(0), ptr(mask) if masked else None,
+                 ptr(mask) if masked else None, ptr(ref[q]), ptr(rb[q]), b, k, m, t, taps, 1, pad)
+    call("glowtts_conv_wrw_batch", n, parr(xs), xs[0].stride(0), parr(ds), ds[0].stride(0), parr(d2) if two else None,
+         d2[0].stride(0) if two else 0, m // 2 if two else 0, ptr(mask) if masked else None, ptr(mask) if masked else None, parr(out),
+         parr(ob), b, k, m, t, taps, 1, pad)
+    torch.cuda.synchronize()
+    for q in range(n):          # same kernels, same arithmetic: only the order of the split-K atomics differs
+        assert_close(out[q], ref[q], rtol=0, atol=2e-6 * float(ref[q].abs().max()), what=f"dW of problem {q}")
+        assert_close(ob[q], rb[q], rtol=0, atol=2e-6 * float(rb[q].abs().max()), what=f"dbias of problem {q}")
+    xd = xs[0].double() * (mask[:, None].double() if masked else 1.0)
+    dd = (torch.cat([ds[0], d2[0]], 1) if two else ds[0]).double() * (mask[:, None].double() if masked else 1.0)
+    want = torch.nn.grad.conv1d_weight(xd, (m, k, taps), dd, padding=pad).permute(2, 1, 0)
+    assert rel_err(out[0], want.float()) < 2e-5
