@@ -467,6 +467,44 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long *__restrict__
     }
 }
 
+// Dropout keep-masks (1 = keep) for a whole step's worth of activations from one launch: Philox4x32-7 (Salmon et al., SC'11: passes
+// BigCrush from 7 rounds), counter = the index of an 8-byte group, key = the seed; each 32-bit output gives two 16-bit draws, a
+// byte is 1 when its draw is >= round(p * 65536) (p to 1.5e-5).  Reference: torch.nn.functional.dropout inside layers.py:147 —
+// a Bernoulli(1 - p) keep decision per element; which generator makes it is not part of the model.  torch's bernoulli_ spends a
+// Philox-10 call on four BYTES: 203 us for the 236 MB of a config-2 step, on the decoder's forward chain.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+}
+
+__global__ __launch_bounds__(256) void keep_mask_kernel(unsigned char *__restrict__ out, long n, unsigned seed_lo, unsigned seed_hi,
+                                                        unsigned thr) {
+    const long groups = (n + 7) >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < groups; i += (long)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)i, (unsigned)(i >> 32), 0x6b656570u, 0x6d61736bu};
+        unsigned k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        unsigned w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned a = c[2 * h], b = c[2 * h + 1];
+            w[h] = ((a & 0xffffu) >= thr ? 1u : 0u) | ((a >> 16) >= thr ? 0x100u : 0u) | ((b & 0xffffu) >= thr ? 0x10000u : 0u) |
+                   ((b >> 16) >= thr ? 0x1000000u : 0u);
+        }
+        if (i * 8 + 8 <= n) {
+            *reinterpret_cast<uint2 *>(out + i * 8) = make_uint2(w[0], w[1]);
+        } else {
+            for (long j = i * 8; j < n; ++j) out[j] = (unsigned char)((w[(j >> 2) & 1] >> (8 * (j & 3))) & 1u);
+        }
+    }
+}
+
 }  // namespace glowtts
 
 extern "C" int glowtts_embed_fwd(const long long *ids, const float *weight, float scale, float *out, int B, int T, int H, int V,
@@ -487,4 +525,16 @@ extern "C" int glowtts_embed_bwd(const long long *ids, const float *dout, float 
     hipLaunchKernelGGL(glowtts::embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long *>(ids),
                        dout, scale, dweight, B, T, H);
     GLOWTTS_LAUNCH_CHECK("glowtts_embed_bwd");
+}
+
+extern "C" int glowtts_keep_mask(unsigned char *out, long n, unsigned long long seed, float p_drop, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(out && n >= 0 && p_drop >= 0.f && p_drop < 1.f, "glowtts_keep_mask: bad argument");
+    GLOWTTS_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 7u) == 0, "glowtts_keep_mask: the mask buffer must be 8-byte aligned");
+    if (n == 0) return 0;
+    const unsigned thr = (unsigned)(p_drop * 65536.0f + 0.5f);
+    long grid = (((n + 7) >> 3) + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(glowtts::keep_mask_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, out, n, (unsigned)seed,
+                       (unsigned)(seed >> 32), thr);
+    GLOWTTS_LAUNCH_CHECK("glowtts_keep_mask");
 }

@@ -30,6 +30,7 @@ _SIGNATURES = {
     "glowtts_align_expand_fwd": [_P, _P, _P, _I, _I, _I, _I],
     "glowtts_align_expand_bwd": [_P, _P, _P, _I, _I, _I, _I],
     "glowtts_mask_len": [_P, _P, _I, _I],
+    "glowtts_keep_mask": [_P, _L, _L, _F],
     "glowtts_actnorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_actnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_actnorm_stats": [_P, _P, _P, _P, _I, _I, _I],

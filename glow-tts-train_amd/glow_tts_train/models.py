@@ -190,8 +190,8 @@ class FlowSpecDecoder(nn.Module):
                     and all(f.wn.n_layers == blocks[0].wn.n_layers and f.wn.hidden_channels == blocks[0].wn.hidden_channels
                             and f.wn.p_dropout == blocks[0].wn.p_dropout and f.wn.training for f in blocks)):
                 wn0 = blocks[0].wn
-                masks = torch.empty(len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2), device=x.device,
-                                    dtype=torch.uint8).bernoulli_(1.0 - float(wn0.p_dropout))
+                masks = ops.keep_mask((len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2)),
+                                      float(wn0.p_dropout), x.device)
                 for k, f in enumerate(blocks):
                     f.wn._drop_pre = masks[k]
             i = 0

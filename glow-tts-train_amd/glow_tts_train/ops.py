@@ -34,6 +34,27 @@ def mask_len(m2: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_TORCH_MASKS = __import__("os").environ.get("GLOWTTS_KEEP_MASK", "1") == "0"      # tuning / A-B switch: torch's generator
+
+
+def keep_mask(shape, p_drop: float, device) -> torch.Tensor:
+    """uint8 dropout keep-mask (1 = keep with probability 1 - p_drop) of `shape`, in ONE launch whatever its size
+    (`glowtts_keep_mask`: Philox4x32-7, two bytes of randomness per decision).  The seed comes from torch's CPU generator, so
+    `torch.manual_seed` makes it repeatable; inside a graph capture the seed would be frozen into the graph, so there the mask
+    is drawn by torch's graph-aware `bernoulli_`."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    out = torch.empty(shape, device=device, dtype=torch.uint8)
+    if n == 0:
+        return out
+    if torch.cuda.is_current_stream_capturing() or _TORCH_MASKS:
+        return out.bernoulli_(1.0 - p_drop)
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    call("glowtts_keep_mask", ptr(out), n, seed, float(p_drop))
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class ActNormFn(Function):
     """z = (bias + exp(logs) x) mask, logdet = sum(logs) x_len   (layers.py:196-197)."""

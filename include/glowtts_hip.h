@@ -358,6 +358,10 @@ int glowtts_chan_layernorm_bwd_act(const float *x, const float *res, const float
 /* Phoneme embedding (reference models.py:90,121: self.emb(x) * sqrt(hidden), transposed to (B, H, T)) and its backward:
  * out[b][h][t] = weight[ids[b][t]][h] * scale;  dweight[v][h] += scale * sum over the positions holding id v of dout[b][h][t]
  * (ids int64 (B, T); one workgroup per vocabulary entry, no atomics, no sort). */
+/* Dropout keep-masks for many tensors from one launch: out[i] = 1 with probability 1 - p_drop (else 0), i < n; Philox4x32-7 keyed
+ * by `seed`, counter = byte group index, so a (seed, n) pair always gives the same mask.  Stands in for the generator behind
+ * F.dropout (layers.py:147, attentions.py:248): the kernels that apply dropout take such byte masks.  `out` 8-byte aligned. */
+int glowtts_keep_mask(unsigned char *out, long n, unsigned long long seed, float p_drop, glowtts_stream_t stream);
 int glowtts_embed_fwd(const long long *ids, const float *weight, float scale, float *out, int B, int T, int H, int V,
                       glowtts_stream_t stream);
 int glowtts_embed_bwd(const long long *ids, const float *dout, float scale, float *dweight, int B, int T, int H, int V,

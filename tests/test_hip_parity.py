@@ -1177,7 +1177,7 @@ def test_encoder_layer_executor_vs_torch_and_per_op_path(G, b, hch, fch, t, nl, 
     if p > 0:
         torch.manual_seed(99)
         n_keep = nl * (b * 2 * t * t + 2 * b * hch * t + b * fch * t)
-        keep = torch.empty(n_keep, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p)
+        keep = G.ops.keep_mask((n_keep,), p, "cuda")          # the same generator, the same seed draw
     for p_ in enc.parameters():
         p_.grad = None
     xr = x0.clone().requires_grad_(True)
@@ -1598,3 +1598,32 @@ def test_conv_wrw_batch_matches_single_launches(G, conv_mode, taps, two, masked,
     dd = (torch.cat([ds[0], d2[0]], 1) if two else ds[0]).double() * (mask[:, None].double() if masked else 1.0)
     want = torch.nn.grad.conv1d_weight(xd, (m, k, taps), dd, padding=pad).permute(2, 1, 0)
     assert rel_err(out[0], want.float()) < 2e-5
+
+
+def test_keep_mask_kernel_statistics_and_repeatability(G):
+    """glowtts_keep_mask: Bernoulli(1 - p) bytes from Philox4x32-7 — right rate, no structure across bytes of a group, the same
+    mask for the same seed, another one for another seed, any length."""
+    call, ptr = G.hip.call, G.hip.ptr
+    n = 8 * 1000 * 1000 + 5
+    for p in (0.05, 0.1, 0.5):
+        a = torch.empty(n, device="cuda", dtype=torch.uint8)
+        b = torch.full((n + 8,), 7, device="cuda", dtype=torch.uint8)
+        call("glowtts_keep_mask", ptr(a), n, 1234567, p)
+        call("glowtts_keep_mask", ptr(b), n, 1234567, p)
+        assert torch.equal(a, b[:n]) and bool((b[n:] == 7).all()), "same seed, same mask; nothing written past n"
+        assert int(a.max()) == 1 and int(a.min()) == 0
+        keep = float(a.float().mean())
+        sigma = (p * (1 - p) / n) ** 0.5
+        assert abs(keep - (1 - p)) < 5 * sigma + 2e-5, (p, keep)
+        by_pos = a[: n - 5].view(-1, 8).float().mean(0)                       # each of the 8 bytes a thread writes
+        assert float((by_pos - (1 - p)).abs().max()) < 6 * sigma * 8 ** 0.5 + 2e-5
+        x = a[: n - 5].view(-1, 8).float() - (1 - p)
+        corr = (x.t() @ x) / x.shape[0] / (p * (1 - p))                      # correlation between byte positions
+        off = corr - torch.diag(torch.diag(corr))
+        assert float(off.abs().max()) < 6e-3 and float((torch.diag(corr) - 1).abs().max()) < 3e-2   # (1e6 samples: sigma 1e-3)
+        c = torch.empty(n, device="cuda", dtype=torch.uint8)
+        call("glowtts_keep_mask", ptr(c), n, 1234568, p)
+        agree = float((a == c).float().mean())
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 2e-3, "another seed: an independent mask"
+    m = G.ops.keep_mask((3, 5, 7), 0.25, "cuda")
+    assert m.shape == (3, 5, 7) and m.dtype == torch.uint8
