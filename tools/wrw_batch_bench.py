@@ -31,9 +31,13 @@ def main():
     for taps in (5, 1):
         for two in (False, True):
             torch.manual_seed(taps)
+            warm = os.environ.get("WRW_BATCH_WARM") == "1"          # the same operands for every problem: they stay in L2 / MALL
             xs = [torch.randn(b, k, t, device="cuda") for _ in range(n)]
             ds = [torch.randn(b, m // 2 if two else m, t, device="cuda") for _ in range(n)]
             d2 = [torch.randn(b, m // 2, t, device="cuda") for _ in range(n)] if two else None
+            if warm:
+                xs, ds = [xs[0]] * n, [ds[0]] * n
+                d2 = [d2[0]] * n if two else None
             ref = [torch.zeros(taps, k, m, device="cuda") for _ in range(n)]
             out = [torch.zeros(taps, k, m, device="cuda") for _ in range(n)]
             rb = [torch.zeros(m, device="cuda") for _ in range(n)]
