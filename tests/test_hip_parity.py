@@ -145,7 +145,7 @@ def test_mas_ties_and_quantised(G):
 
 
 @pytest.mark.parametrize("b,c,tx,ty,mean_only", [(3, 80, 37, 101, False), (2, 80, 160, 800, True), (1, 6, 5, 9, False),
-                                                   (2, 100, 60, 64, False)])
+                                                   (2, 100, 60, 64, False), (2, 12, 3, 403, False)])     # (spans of ~130 frames)
 def test_align_logp_and_expand_vs_oracle(G, b, c, tx, ty, mean_only):
     """csrc/align.hip against the oracle's restatement of models.py:362-376 / 383-393: the (token, frame) log-likelihood
     lattice as one contraction, the spans / frame -> token map the search kernel hands out, and z_m = attn^T x_m as a gather
