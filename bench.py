@@ -175,6 +175,48 @@ def conv_algorithmic_bytes(name, M, K, taps, cols, H):
     return per_col * cols * e + w
 
 
+def batched_wrw_time(tag, dev, n=4, iters=20):
+    """`glowtts_conv_wrw_batch` on n problems of the dominant kernel's shape (distinct random operands per problem, as the layers of a
+    WN stack have), HIP events on the launch stream around `iters` back-to-back launches: microseconds per PROBLEM and the pipe
+    fraction that gives.  The roofline's `frac` stays the single launch measured in the instrumented pass."""
+    import ctypes
+    import re as _re
+
+    from glow_tts_train._hip import call, ptr
+
+    m_, k_, taps_, b_, t_ = (int(v) for v in _re.match(r"\w+\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", tag).groups())
+    xs = [torch.randn(b_, k_, t_, device=dev) for _ in range(n)]
+    ds = [torch.randn(b_, m_, t_, device=dev) for _ in range(n)]
+    dw = [torch.zeros(taps_, k_, m_, device=dev) for _ in range(n)]
+    keep = []
+
+    def parr(ts):
+        a = (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])
+        keep.append(a)
+        return ctypes.addressof(a)
+
+    ax, ad, aw = parr(xs), parr(ds), parr(dw)
+
+    def run():
+        call("glowtts_conv_wrw_batch", n, ax, xs[0].stride(0), ad, ds[0].stride(0), None, 0, 0, None, None, aw, None, b_, k_, m_, t_,
+             taps_, 1, (taps_ - 1) // 2)
+
+    for _ in range(3):
+        run()
+    cur = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(cur)
+    for _ in range(iters):
+        run()
+    e1.record(cur)
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters / n
+    flop = 2.0 * m_ * k_ * taps_ * b_ * t_
+    return {"problems_per_launch": n, "us_per_problem": round(us, 2),
+            "frac_pipe": round(6.0 * flop / (us * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "note": "one glowtts_conv_wrw_batch launch per WN stack in the timed step; alone, back-to-back, distinct operands"}
+
+
 def decoder_alone(model, batch, cfg, n_iter=5):
     """SURVEY.md 8(d) secondary metric and headline (ii): FlowSpecDecoder forward + backward alone, one stream (outside a
     training step's scope nothing is put on side streams), HIP events on that stream around each half, median of
@@ -598,6 +640,10 @@ def main():
                                    "alg_MB": mfma[dom]["alg_MB"],
                                    "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
                                    "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
+                try:        # the form the timed step launches: the four layers' problems of a WN stack in ONE launch (lesson 20)
+                    out["roofline"]["as_launched_in_the_step"] = batched_wrw_time(dom, dev)
+                except Exception as exc:
+                    log(f"batched weight-gradient timing failed ({type(exc).__name__}: {exc})")
             else:
                 fr = mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
