@@ -22,6 +22,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                      mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed PMC
                                         pass (profiles/r03_pmc.json), null when no pass exists for the kernel;
                    with GLOWTTS_CONV_MATH=fp32 the peak is the 157.3 TFLOP/s dense fp32 MFMA figure and all three coincide.
+                   "as_launched_in_the_step": the same kernel timed as the step launches it — the four layers' problems of a WN
+                   stack in one glowtts_conv_wrw_batch launch — microseconds per problem and the pipe fraction that gives
+                   (information beside `frac`, which stays the single launch of the instrumented pass).
                    "traffic" = HBM-side bytes per launch from the PMC passes.  Every MFMA kernel is listed with its
                    algorithmic bytes and FLOPs, its time at each roof and `bound: hbm|mfma` (the 1x1 convolutions are
                    byte-bound: they are reported against 8 TB/s, not as TFLOP/s alone); every streaming kernel with GB/s against
