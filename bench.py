@@ -435,6 +435,7 @@ def main():
     if reducer is not None:
         # time the compute stream spent in reducer.finish() waiting for collectives backward did not hide (HIP events on
         # the compute stream), the timed steps only; max over ranks like the step time
+        per_bucket = reducer.bucket_timings(last_steps=args.steps)       # this rank's (rank 0 prints its own)
         exposed = reducer.exposed_comm_ms()[-args.steps:]
         ex = torch.tensor([sum(exposed) / max(1, len(exposed))], device=dev, dtype=torch.float64)
         if world > 1:
@@ -443,7 +444,10 @@ def main():
                 "rccl_ranks": dist.get_world_size() if reducer.backend == "nccl" else 0,
                 "buckets": len(reducer.buckets), "buckets_launched_during_backward": reducer.launched_in_backward,
                 "grad_MB_per_step": round(4e-6 * sum(b.hi - b.lo for b in reducer.buckets), 1),
-                "exposed_comm_ms_per_step": round(float(ex), 3)}
+                "exposed_comm_ms_per_step": round(float(ex), 3),
+                # rank 0's buckets in launch order: ready -> start = the collective waiting for work queued on the OTHER streams
+                # (every bucket waits on all side streams), start -> end = queueing behind earlier collectives + the wire
+                "per_bucket": per_bucket}
     frames = world * B * T_mel * args.steps
     ms_per_step = 1e3 * dt / args.steps
 
@@ -477,6 +481,11 @@ def main():
     default_math = convops.conv_math_name()
     other_math = "fp32" if default_math != "fp32" else "bf16x6+wrw"
     out["config"]["conv_math"] = default_math
+    # N > 1 (the driver's SCALE runs): `value` only.  The legs below are one-GPU diagnostics that the N=1 line carries; with
+    # several ranks they would run on rank 0 alone while the others tear their communicator down (BENCH_EXTRA_LEGS=1 forces them).
+    extra_legs = world == 1 or os.environ.get("BENCH_EXTRA_LEGS") == "1"
+    if not extra_legs:
+        args.no_split_math = args.no_roofline = True
     if not args.no_split_math and mode == "eager":
         previous = convops.set_conv_math(other_math)
         key = "native_fp32" if other_math == "fp32" else "split_math"
@@ -730,6 +739,9 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()                     # all ranks leave together: nobody tears RCCL down under a peer still working
         dist.destroy_process_group()
 
 

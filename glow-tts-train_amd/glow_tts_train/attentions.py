@@ -60,7 +60,7 @@ class Encoder(nn.Module):
             sizes = [b * nh * t * t, b * hch * t, b * self.filter_channels * t, b * hch * t]
             keep = None
             if p > 0.0:
-                keep = ops.keep_mask((len(layers) * sum(sizes),), p, x.device)
+                keep = ops.keep_mask((len(layers) * sum(sizes),), p, x.device, "encoder.layers")
             pos = 0
             for group, attn, ffn, norm1, norm2 in layers:
                 drops = None

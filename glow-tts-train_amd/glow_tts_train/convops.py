@@ -16,7 +16,7 @@ import torch.distributed as _dist
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import _hip
+from . import _hip, ops
 from ._hip import call, conv_bind_planes, conv_math, f32, ptr, scratch_zeros
 
 # parameters whose .grad was written directly by a backward (no AccumulateGrad node runs for them); a data-parallel
@@ -296,7 +296,10 @@ class ChanLayerNormFn(Function):
     the element-wise neighbours of a norm ride in its kernels (csrc/norm.hip) — no launch, no tensor of their own."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, relu_in=False, relu_out=False, p_drop=0.0):
+    def forward(ctx, x, res, gamma, beta, eps, relu_in=False, relu_out=False, p_drop=0.0, site="ln"):
+        if relu_in and res is not None:
+            # the kernel gates dx by x > 0 and has no separate residual gradient in this form (ADVICE r3); no caller needs it
+            raise RuntimeError("LayerNorm: relu_in together with a residual input is not supported")
         x = f32(x.contiguous())
         res = None if res is None else f32(res.contiguous())
         B, C, T = x.shape
@@ -304,7 +307,7 @@ class ChanLayerNormFn(Function):
         stats = torch.empty(B, 2, T, device=x.device, dtype=torch.float32)
         keep, scale = None, 1.0
         if p_drop > 0.0:
-            keep = torch.empty(B, C, T, device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p_drop)
+            keep = ops.keep_mask((B, C, T), p_drop, x.device, site)
             scale = 1.0 / (1.0 - p_drop)
         call("glowtts_chan_layernorm_fwd_act", ptr(x), ptr(res), None, None, 1.0, ptr(gamma.detach().contiguous()),
              ptr(beta.detach().contiguous()), ptr(y), ptr(stats), int(relu_in), int(relu_out), ptr(keep), scale, B, C, T, float(eps))
@@ -330,7 +333,7 @@ class ChanLayerNormFn(Function):
              ptr(y), ptr(dy), int(relu_in), int(relu_out), ptr(keep), scale, ptr(dx), None, ptr(sink.buf(0)), ptr(sink.buf(1)),
              B, C, T)
         dg, db = sink.results()
-        return dx, (dx if res is not None else None), dg, db, None, None, None, None
+        return dx, (dx if res is not None else None), dg, db, None, None, None, None, None
 
 
 class EmbedFn(Function):
@@ -646,7 +649,7 @@ class WNFn(Function):
             if drop_pre is not None and tuple(drop_pre.shape) == (n_layers, B, 2 * H, T) and drop_pre.is_contiguous():
                 drop_all = drop_pre                     # drawn by the caller (one generator launch for all coupling blocks)
             else:
-                drop_all = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
+                drop_all = ops.keep_mask((n_layers, B, 2 * H, T), p_drop, dev, "wn")   # keep = 1
         ctx.native = False
         if cond is None and _hip.timing_off() and _WN_NATIVE != "off" and all(params[3 * j + 2] is not None for j in range(2 * n_layers)):
             # the whole launch sequence of the stack in one native call (csrc/wn_stack.hip): four allocations, one ctypes
@@ -1038,7 +1041,7 @@ class FlowBlockFn(Function):
             logdet = new(B)
             winv = new(n_split * n_split + 1)
             if p_drop > 0.0 and (drop is None or tuple(drop.shape) != (n_layers, B, 2 * H, T) or not drop.is_contiguous()):
-                drop = torch.empty(n_layers, B, 2 * H, T, device=dev, dtype=torch.uint8).bernoulli_(1.0 - p_drop)
+                drop = ops.keep_mask((n_layers, B, 2 * H, T), p_drop, dev, f"decoder.block.{cfg[7] if len(cfg) > 7 else 0}")
             if p_drop <= 0.0:
                 drop = None
             tab = bplan.table(params, n_layers)

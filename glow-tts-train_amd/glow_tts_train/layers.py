@@ -34,11 +34,12 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
-    def forward(self, x, res=None, relu_in=False, relu_out=False, p_drop=0.0):
+    def forward(self, x, res=None, relu_in=False, relu_out=False, p_drop=0.0, site="ln"):
         """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in).
-        relu_in / relu_out / p_drop: the ReLU before and the ReLU / dropout after the norm, inside its kernels (3-D input)."""
+        relu_in / relu_out / p_drop: the ReLU before and the ReLU / dropout after the norm, inside its kernels (3-D input);
+        `site` names the dropout's keep-mask (ops.keep_mask).  relu_in with a residual input is not supported (raises)."""
         if x.dim() == 3:                               # (a CPU tensor raises in the operator: no fallback)
-            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, relu_in, relu_out, p_drop)
+            return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, relu_in, relu_out, p_drop, site)
         if relu_in or relu_out or p_drop:
             raise RuntimeError("LayerNorm: the fused ReLU / dropout forms need a (B, C, T) tensor")
         # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
@@ -69,9 +70,9 @@ class ConvReluNorm(nn.Module):
         h = x
         drop = self.relu_drop[1]
         p = float(drop.p) if (self.training and drop.p > 0.0) else 0.0
-        for conv, norm in zip(self.conv_layers, self.norm_layers):
+        for i, (conv, norm) in enumerate(zip(self.conv_layers, self.norm_layers)):
             # conv(h * mask): the mask is folded into the conv; LayerNorm -> ReLU -> Dropout: ONE kernel (csrc/norm.hip)
-            h = norm(convops.conv1d(conv, h, m2, mask_in=True), relu_out=True, p_drop=p)
+            h = norm(convops.conv1d(conv, h, m2, mask_in=True), relu_out=True, p_drop=p, site=f"encoder.pre.{i}")
         return (x + convops.conv1d(self.proj, h)) * x_mask
 
 

@@ -46,9 +46,9 @@ class DurationPredictor(nn.Module):
     def forward(self, x, x_mask):
         m2 = ops.mask2d(x_mask)
         p = float(self.drop.p) if (self.training and self.drop.p > 0.0) else 0.0
-        for conv, norm in ((self.conv_1, self.norm_1), (self.conv_2, self.norm_2)):
+        for i, (conv, norm) in enumerate(((self.conv_1, self.norm_1), (self.conv_2, self.norm_2))):
             # conv -> ReLU -> LayerNorm -> Dropout: the ReLU and the dropout ride in the norm's kernels (csrc/norm.hip)
-            x = norm(convops.conv1d(conv, x, m2, mask_in=True), relu_in=True, p_drop=p)
+            x = norm(convops.conv1d(conv, x, m2, mask_in=True), relu_in=True, p_drop=p, site=f"encoder.proj_w.{i}")
         return convops.conv1d(self.proj, x, m2, mask_in=True, mask_out=True)
 
 
@@ -191,7 +191,7 @@ class FlowSpecDecoder(nn.Module):
                             and f.wn.p_dropout == blocks[0].wn.p_dropout and f.wn.training for f in blocks)):
                 wn0 = blocks[0].wn
                 masks = ops.keep_mask((len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2)),
-                                      float(wn0.p_dropout), x.device)
+                                      float(wn0.p_dropout), x.device, "decoder.wn")
                 for k, f in enumerate(blocks):
                     f.wn._drop_pre = masks[k]
             i = 0

@@ -36,22 +36,58 @@ def mask_len(m2: torch.Tensor) -> torch.Tensor:
 
 _TORCH_MASKS = __import__("os").environ.get("GLOWTTS_KEEP_MASK", "1") == "0"      # tuning / A-B switch: torch's generator
 
+# Dropout decisions are data, not part of the model (reference: F.dropout, layers.py:58,147; attentions.py:67,71,251,379;
+# models.py:45,49).  EVERY keep-mask of the package is drawn by keep_mask() below, which names the site it is drawn for, so a
+# parity test can (a) read the decisions of a step back (`keep_mask_tap`) and feed them to its checker, or (b) make the step
+# use decisions recorded from the reference (`keep_mask_inject`).  Both are None in production.
+#   keep_mask_tap(site, mask, p_drop)                 called with every mask drawn (or injected)
+#   keep_mask_inject(site, shape, p_drop) -> uint8 device tensor of `shape`, or None to draw as usual
+keep_mask_tap = None
+keep_mask_inject = None
 
-def keep_mask(shape, p_drop: float, device) -> torch.Tensor:
+# Seeds of the Philox launches come from a generator of their OWN: drawing them from torch's global CPU generator
+# perturbed the stream DataLoader shuffling and worker seeding use.  It is (re)seeded from torch.initial_seed(), so
+# torch.manual_seed(s) still fixes the masks of the steps that follow it.
+_seed_gen = None
+_seed_gen_from = None
+
+
+def _next_seed() -> int:
+    global _seed_gen, _seed_gen_from
+    base = torch.initial_seed()
+    if _seed_gen is None or _seed_gen_from != base:
+        _seed_gen = torch.Generator(device="cpu")
+        _seed_gen.manual_seed((base * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
+        _seed_gen_from = base
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=_seed_gen).item())
+
+
+def keep_mask(shape, p_drop: float, device, site: str = "") -> torch.Tensor:
     """uint8 dropout keep-mask (1 = keep with probability 1 - p_drop) of `shape`, in ONE launch whatever its size
-    (`glowtts_keep_mask`: Philox4x32-7, two bytes of randomness per decision).  The seed comes from torch's CPU generator, so
-    `torch.manual_seed` makes it repeatable; inside a graph capture the seed would be frozen into the graph, so there the mask
-    is drawn by torch's graph-aware `bernoulli_`."""
+    (`glowtts_keep_mask`: Philox4x32-7, two bytes of randomness per decision, so p is quantised to 1/65536).  The seed comes
+    from a package-private CPU generator seeded from torch.initial_seed(): `torch.manual_seed` makes the masks repeatable and
+    drawing them does not consume the global CPU stream; inside a graph capture the seed would be frozen into the graph, so
+    there the mask is drawn by torch's graph-aware `bernoulli_`.  `site` names what the mask is for (see the hooks above)."""
+    shape = tuple(int(d) for d in shape)
     n = 1
     for d in shape:
-        n *= int(d)
-    out = torch.empty(shape, device=device, dtype=torch.uint8)
-    if n == 0:
-        return out
-    if torch.cuda.is_current_stream_capturing() or _TORCH_MASKS:
-        return out.bernoulli_(1.0 - p_drop)
-    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-    call("glowtts_keep_mask", ptr(out), n, seed, float(p_drop))
+        n *= d
+    out = None
+    if keep_mask_inject is not None:
+        out = keep_mask_inject(site, shape, float(p_drop))
+        if out is not None and (tuple(out.shape) != shape or out.dtype != torch.uint8 or not out.is_cuda
+                                or not out.is_contiguous()):
+            raise RuntimeError(f"keep_mask_inject({site!r}): need a contiguous uint8 device tensor of shape {shape}")
+    if out is None:
+        out = torch.empty(shape, device=device, dtype=torch.uint8)
+        if n == 0:
+            return out
+        if torch.cuda.is_current_stream_capturing() or _TORCH_MASKS:
+            out.bernoulli_(1.0 - p_drop)
+        else:
+            call("glowtts_keep_mask", ptr(out), n, _next_seed(), float(p_drop))
+    if keep_mask_tap is not None:
+        keep_mask_tap(site, out, float(p_drop))
     return out
 
 
@@ -515,7 +551,7 @@ class RelAttnFn(Function):
         share = int((not has_rel) or emb_k.shape[0] == 1)
         drop = None
         if p_drop > 0.0:
-            drop = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.uint8).bernoulli_(1.0 - p_drop)   # keep = 1
+            drop = keep_mask((B, n_heads, T, T), p_drop, q.device, "attn")   # keep = 1
         p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0

@@ -71,7 +71,12 @@ class FlowBlockReducer:
         """`force`: hook the gradients and issue every bucket's collective even in a group of ONE rank (the collective is
         then the identity; it exercises the RCCL launch path, its streams and `finish()` on a single GPU).
         `measure`: record HIP events around the wait in `finish()` — `exposed_comm_ms()` is the time the compute stream
-        spent waiting for collectives that backward did not hide."""
+        spent waiting for collectives that backward did not hide — and, per bucket, three events (`bucket_timings()`):
+        `ready` on the stream whose announcement completed the bucket, `start` on the launch stream once every producer stream
+        has been waited for, `end` on the launch stream after the collective (RCCL only: the launch stream is made to wait for
+        the work, which does not block the host).  ready -> start is what the collective waits for OTHER streams' queued work
+        (every bucket waits on all side streams, the encoder's included), start -> end its queueing behind earlier
+        collectives plus its time on the wire."""
         flat = getattr(optimizer, "_optim", optimizer)
         if not hasattr(flat, "flat_g"):
             raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
@@ -84,6 +89,8 @@ class FlowBlockReducer:
         self._active = self.world > 1 or (bool(force) and dist.is_initialized())
         self._measure = bool(measure)
         self._exposed: typing.List[typing.Tuple[typing.Any, typing.Any]] = []
+        self._bucket_events: typing.List[typing.Tuple[int, bool, typing.Any, typing.Any, typing.Any]] = []
+        self._in_finish = False
         self.launched_in_backward = 0          # buckets whose collective was issued before finish() in the last step
         named = list(model.named_parameters())
         by_id = {id(p): (o, p.numel()) for p, o in zip(flat._params, flat.offsets)}
@@ -138,6 +145,10 @@ class FlowBlockReducer:
             # announcement that completes it arrives in the context of only ONE of them.  The collective is therefore issued
             # from a launch stream that first waits for all of them — the compute streams themselves never wait.
             comm = _hip.side_stream(view.device, "comm")
+            ev = None
+            if self._measure:
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                ev[0].record(torch.cuda.current_stream(view.device))
             comm.wait_stream(torch.cuda.current_stream(view.device))
             for s in _hip.all_side_streams(view.device):
                 if s is not comm:
@@ -145,12 +156,20 @@ class FlowBlockReducer:
             ctx = torch.cuda.stream(comm)
         else:
             ctx = contextlib.nullcontext()
+            ev = None
         with ctx:
+            if ev is not None:
+                ev[1].record(comm)
             if self._use_avg:
                 work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             else:
                 view.div_(self.world)
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if ev is not None:
+                if self.backend == "nccl":
+                    work.wait()                      # the LAUNCH stream waits for the collective (no host block): `end` is its end
+                ev[2].record(comm)
+                self._bucket_events.append((i, not self._in_finish, *ev))
         self._works.append(work)
         self._launched[i] = True
 
@@ -180,9 +199,11 @@ class FlowBlockReducer:
         slice is the zeros left by zero_grad), then makes the current stream wait for every collective."""
         if self._active:
             self.launched_in_backward = sum(self._launched)
+            self._in_finish = True
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
+            self._in_finish = False
             cuda = self.flat.flat_g.is_cuda
             if cuda and self._measure:
                 cur = torch.cuda.current_stream(self.flat.flat_g.device)
@@ -216,6 +237,29 @@ class FlowBlockReducer:
         if reset:
             self._exposed.clear()
         return out
+
+    def bucket_timings(self, last_steps: typing.Optional[int] = None, reset: bool = True) -> typing.List[dict]:
+        """Per bucket, means over the recorded steps (`measure=True`; synchronises): MB, the fraction of steps in which it was
+        launched during backward, `ready_to_start_ms` and `start_to_end_ms` (None on a backend whose work cannot be waited for
+        on a stream: gloo).  See __init__ for what the three events bracket."""
+        torch.cuda.synchronize()
+        ev = self._bucket_events
+        if last_steps is not None:
+            ev = ev[-last_steps * len(self.buckets):]
+        rows = []
+        for i, b in enumerate(self.buckets):
+            mine = [e for e in ev if e[0] == i]
+            if not mine:
+                continue
+            r2s = [e[2].elapsed_time(e[3]) for e in mine]
+            s2e = [e[3].elapsed_time(e[4]) for e in mine] if self.backend == "nccl" else None
+            rows.append({"key": b.key, "MB": round(4e-6 * (b.hi - b.lo), 2),
+                         "launched_during_backward": round(sum(1 for e in mine if e[1]) / len(mine), 2),
+                         "ready_to_start_ms": round(sum(r2s) / len(r2s), 3),
+                         "start_to_end_ms": None if s2e is None else round(sum(s2e) / len(s2e), 3)})
+        if reset:
+            self._bucket_events.clear()
+        return rows
 
     def remove_hooks(self):
         for h in self._hooks:

@@ -169,13 +169,47 @@ def gate(a: Tensor, b: Tensor, h: int) -> Tensor:
     return torch.tanh(s[:, :h]) * torch.sigmoid(s[:, h:])
 
 
+class KeepMasks:
+    """Injected dropout decisions.  The reference draws its Bernoulli(1 - p) keep decisions from torch's generator inside
+    `F.dropout` (layers.py:58,147; attentions.py:67,71,251,379; models.py:45,49); which generator draws them is not part of
+    the algorithm, so the oracle takes them as DATA: `site -> (keep {0,1} tensor, p)`, and applies exactly what
+    `F.dropout(x, p, training=True)` computes with those decisions, x * keep / (1 - p).  A site that has no entry is not
+    dropped (p = 0).  Site names (the order is the reference's call order within one forward):
+        encoder.pre.{i}                    ConvReluNorm: after LayerNorm -> ReLU of layer i            (B, H, T_text)
+        encoder.encoder.{i}.attn           MultiHeadAttention: p_attn after the softmax               (B, heads, T, T)
+        encoder.encoder.{i}.y1 / .y2       Encoder: the attention / FFN branch before the residual add  (B, H, T)
+        encoder.encoder.{i}.ffn            FFN: after the activation, before conv_2                    (B, filter, T)
+        encoder.proj_w.{i}                 DurationPredictor: after norm_{i+1}                         (B, filter_dp, T)
+        decoder.flows.{f}.wn.{l}           WN: the in-layer's output before the gate                   (B, 2H, T')
+    `pinned by`: tests/golden/e2e_dropout_train.npz — the real reference run with F.dropout patched to record its masks."""
+
+    def __init__(self, masks=None):
+        self.masks = dict(masks or {})
+        self.used = set()
+
+    def __call__(self, x: Tensor, site: str) -> Tensor:
+        ent = self.masks.get(site)
+        if ent is None:
+            return x
+        keep, p = ent
+        assert tuple(keep.shape) == tuple(x.shape), (site, tuple(keep.shape), tuple(x.shape))
+        self.used.add(site)
+        return x * (keep.to(x.dtype) * (1.0 / (1.0 - p)))
+
+
+def _no_drop(x: Tensor, site: str) -> Tensor:
+    return x
+
+
 def wn(sd: SD, prefix: str, x: Tensor, mask: Tensor, g: Optional[Tensor], hidden: int, n_layers: int,
-       dilation_rate: int) -> Tensor:
-    """layers.py:138-162 — gated dilated conv stack with residual/skip 1x1s (dropout = 0 in the oracle)."""
+       dilation_rate: int, drop=None) -> Tensor:
+    """layers.py:138-162 — gated dilated conv stack with residual/skip 1x1s; `drop`: KeepMasks (dropout on x_in, :147)."""
+    drop = drop or _no_drop
     out = torch.zeros_like(x)
     g_all = conv1d(sd, prefix + ".cond_layer", g) if g is not None else None
     for i in range(n_layers):
         x_in = conv1d(sd, f"{prefix}.in_layers.{i}", x, dilation=dilation_rate ** i)
+        x_in = drop(x_in, f"{prefix}.{i}")
         if g_all is not None:
             g_l = g_all[:, 2 * hidden * i: 2 * hidden * (i + 1)]
         else:
@@ -191,12 +225,12 @@ def wn(sd: SD, prefix: str, x: Tensor, mask: Tensor, g: Optional[Tensor], hidden
 
 
 def coupling(sd: SD, prefix: str, x: Tensor, mask: Tensor, g: Optional[Tensor], hp: HParams, hidden: int,
-             reverse: bool = False):
+             reverse: bool = False, drop=None):
     """attentions.py:119-142 — affine coupling; z_0 = x_0 passes through, (m, logs) = end(WN(start(x_0)))."""
     c = x.shape[1]
     x0, x1 = x[:, : c // 2], x[:, c // 2:]
     h = conv1d(sd, prefix + ".start", x0) * mask
-    h = wn(sd, prefix + ".wn", h, mask, g, hidden, hp.n_block_layers, hp.dilation_rate)
+    h = wn(sd, prefix + ".wn", h, mask, g, hidden, hp.n_block_layers, hp.dilation_rate, drop)
     out = conv1d(sd, prefix + ".end", h)
     m, logs = out[:, : c // 2], out[:, c // 2:]
     if hp.sigmoid_scale:
@@ -209,7 +243,7 @@ def coupling(sd: SD, prefix: str, x: Tensor, mask: Tensor, g: Optional[Tensor], 
 
 
 def flow_decoder(sd: SD, x: Tensor, mask: Tensor, g: Optional[Tensor], hp: HParams, reverse: bool = False,
-                 prefix: str = "decoder"):
+                 prefix: str = "decoder", drop=None):
     """models.py:193-211 — squeeze -> n_blocks x [ActNorm, InvConvNear, CouplingBlock] -> unsqueeze."""
     hidden = hp.hidden_channels
     if hp.n_sqz > 1:
@@ -224,7 +258,7 @@ def flow_decoder(sd: SD, x: Tensor, mask: Tensor, g: Optional[Tensor], hp: HPara
         elif kind == 1:
             x, ld = invconv(x, mask, sd[p + ".weight"], hp.n_split, reverse)
         else:
-            x, ld = coupling(sd, p, x, mask, g, hp, hidden, reverse)
+            x, ld = coupling(sd, p, x, mask, g, hp, hidden, reverse, drop)
         if not reverse:
             logdet_tot = logdet_tot + ld
     if hp.n_sqz > 1:
@@ -237,7 +271,7 @@ def flow_decoder(sd: SD, x: Tensor, mask: Tensor, g: Optional[Tensor], hp: HPara
 # ---------------------------------------------------------------------------------------------------------
 def rel_attention(q: Tensor, k: Tensor, v: Tensor, attn_mask: Optional[Tensor], n_heads: int,
                   emb_rel_k: Optional[Tensor], emb_rel_v: Optional[Tensor], window: Optional[int],
-                  block_length: Optional[int]):
+                  block_length: Optional[int], drop=None, site: str = ""):
     """attentions.py:214-264 (+ helpers :266-333) stated by index instead of the pad/reshape skew:
         scores[b,h,i,j] = q_i.k_j/sqrt(d) + [|j-i|<=w] q_i.Ek[j-i+w]/sqrt(d)
         masked_fill(mask==0, -1e4); optional band |j-i|<=block_length kept, rest set to -1e4
@@ -263,6 +297,8 @@ def rel_attention(q: Tensor, k: Tensor, v: Tensor, attn_mask: Optional[Tensor], 
             band = (rel.abs() <= block_length).to(scores.dtype)
             scores = scores * band + -1e4 * (1 - band)
     p = F.softmax(scores, dim=-1)
+    if drop is not None:
+        p = drop(p, site)                                   # attentions.py:251 — dropout on p_attn; the dropped p is returned
     out = torch.matmul(p, vh)
     if window is not None:
         # rel_w[b,h,i,r] = p[b,h,i,i+r-w] (0 outside the sequence)
@@ -279,7 +315,7 @@ def rel_attention(q: Tensor, k: Tensor, v: Tensor, attn_mask: Optional[Tensor], 
     return out, p
 
 
-def multi_head_attention(sd: SD, prefix: str, x: Tensor, attn_mask: Tensor, hp: HParams):
+def multi_head_attention(sd: SD, prefix: str, x: Tensor, attn_mask: Tensor, hp: HParams, drop=None, site: str = ""):
     """attentions.py:204-212 — 1x1 q/k/v projections, relative attention, 1x1 output projection."""
     q = conv1d(sd, prefix + ".conv_q", x)
     k = conv1d(sd, prefix + ".conv_k", x)
@@ -287,61 +323,68 @@ def multi_head_attention(sd: SD, prefix: str, x: Tensor, attn_mask: Tensor, hp: 
     ek = sd.get(prefix + ".emb_rel_k")
     ev = sd.get(prefix + ".emb_rel_v")
     o, p = rel_attention(q, k, v, attn_mask, hp.n_heads, ek, ev, hp.window_size if ek is not None else None,
-                         hp.block_length)
+                         hp.block_length, drop, site)
     return conv1d(sd, prefix + ".conv_o", o), p
 
 
-def ffn(sd: SD, prefix: str, x: Tensor, mask: Tensor) -> Tensor:
-    """attentions.py:373-381 — conv(k) -> relu -> conv(k), masked before each conv and at the end."""
+def ffn(sd: SD, prefix: str, x: Tensor, mask: Tensor, drop=None, site: str = "") -> Tensor:
+    """attentions.py:373-381 — conv(k) -> relu -> dropout -> conv(k), masked before each conv and at the end."""
     h = torch.relu(conv1d(sd, prefix + ".conv_1", x * mask))
+    if drop is not None:
+        h = drop(h, site)
     return conv1d(sd, prefix + ".conv_2", h * mask) * mask
 
 
-def encoder_stack(sd: SD, prefix: str, x: Tensor, mask: Tensor, hp: HParams) -> Tensor:
-    """attentions.py:62-74 — post-LN transformer layers."""
+def encoder_stack(sd: SD, prefix: str, x: Tensor, mask: Tensor, hp: HParams, drop=None) -> Tensor:
+    """attentions.py:62-74 — post-LN transformer layers (dropout on each branch before its residual add, :67,71)."""
+    drop = drop or _no_drop
     attn_mask = mask.unsqueeze(2) * mask.unsqueeze(-1)
     for i in range(hp.n_layers_enc):
         x = x * mask
-        y, _ = multi_head_attention(sd, f"{prefix}.attn_layers.{i}", x, attn_mask, hp)
+        y, _ = multi_head_attention(sd, f"{prefix}.attn_layers.{i}", x, attn_mask, hp, drop, f"{prefix}.{i}.attn")
+        y = drop(y, f"{prefix}.{i}.y1")
         x = channel_layer_norm(x + y, sd[f"{prefix}.norm_layers_1.{i}.gamma"], sd[f"{prefix}.norm_layers_1.{i}.beta"])
-        y = ffn(sd, f"{prefix}.ffn_layers.{i}", x, mask)
+        y = ffn(sd, f"{prefix}.ffn_layers.{i}", x, mask, drop, f"{prefix}.{i}.ffn")
+        y = drop(y, f"{prefix}.{i}.y2")
         x = channel_layer_norm(x + y, sd[f"{prefix}.norm_layers_2.{i}.gamma"], sd[f"{prefix}.norm_layers_2.{i}.beta"])
     return x * mask
 
 
-def prenet(sd: SD, prefix: str, x: Tensor, mask: Tensor, n_layers: int = 3) -> Tensor:
-    """layers.py:73-80 — 3 x [conv5(x*mask) -> LN -> relu] then residual 1x1 projection, masked."""
+def prenet(sd: SD, prefix: str, x: Tensor, mask: Tensor, n_layers: int = 3, drop=None) -> Tensor:
+    """layers.py:73-80 — 3 x [conv5(x*mask) -> LN -> relu -> dropout] then residual 1x1 projection, masked."""
+    drop = drop or _no_drop
     h = x
     for i in range(n_layers):
         h = conv1d(sd, f"{prefix}.conv_layers.{i}", h * mask)
         h = channel_layer_norm(h, sd[f"{prefix}.norm_layers.{i}.gamma"], sd[f"{prefix}.norm_layers.{i}.beta"])
-        h = torch.relu(h)
+        h = drop(torch.relu(h), f"{prefix}.{i}")
     return (x + conv1d(sd, prefix + ".proj", h)) * mask
 
 
-def duration_predictor(sd: SD, prefix: str, x: Tensor, mask: Tensor) -> Tensor:
-    """models.py:41-51."""
+def duration_predictor(sd: SD, prefix: str, x: Tensor, mask: Tensor, drop=None) -> Tensor:
+    """models.py:41-51 — 2 x [conv(x*mask) -> relu -> LN -> dropout], 1x1 projection."""
+    drop = drop or _no_drop
     h = torch.relu(conv1d(sd, prefix + ".conv_1", x * mask))
-    h = channel_layer_norm(h, sd[prefix + ".norm_1.gamma"], sd[prefix + ".norm_1.beta"])
+    h = drop(channel_layer_norm(h, sd[prefix + ".norm_1.gamma"], sd[prefix + ".norm_1.beta"]), prefix + ".0")
     h = torch.relu(conv1d(sd, prefix + ".conv_2", h * mask))
-    h = channel_layer_norm(h, sd[prefix + ".norm_2.gamma"], sd[prefix + ".norm_2.beta"])
+    h = drop(channel_layer_norm(h, sd[prefix + ".norm_2.gamma"], sd[prefix + ".norm_2.beta"]), prefix + ".1")
     return conv1d(sd, prefix + ".proj", h * mask) * mask
 
 
-def text_encoder(sd: SD, x_ids: Tensor, x_lengths: Tensor, g: Optional[Tensor], hp: HParams):
+def text_encoder(sd: SD, x_ids: Tensor, x_lengths: Tensor, g: Optional[Tensor], hp: HParams, drop=None):
     """models.py:120-142."""
     h = F.embedding(x_ids, sd["encoder.emb.weight"]) * math.sqrt(hp.hidden_channels)
     h = h.transpose(1, 2)
     mask = sequence_mask(x_lengths, h.shape[2]).unsqueeze(1).to(h.dtype)
     if hp.prenet:
-        h = prenet(sd, "encoder.pre", h, mask)
-    h = encoder_stack(sd, "encoder.encoder", h, mask, hp)
+        h = prenet(sd, "encoder.pre", h, mask, drop=drop)
+    h = encoder_stack(sd, "encoder.encoder", h, mask, hp, drop)
     x_dp = h.detach()
     if g is not None:
         x_dp = torch.cat([x_dp, g.expand(-1, -1, h.shape[-1])], 1)
     x_m = conv1d(sd, "encoder.proj_m", h) * mask
     x_logs = torch.zeros_like(x_m) if hp.mean_only else conv1d(sd, "encoder.proj_s", h) * mask
-    logw = duration_predictor(sd, "encoder.proj_w", x_dp, mask)
+    logw = duration_predictor(sd, "encoder.proj_w", x_dp, mask, drop)
     return x_m, x_logs, logw, mask
 
 
@@ -430,16 +473,17 @@ def align_logp(x_m: Tensor, x_logs: Tensor, z: Tensor) -> Tensor:
 
 
 def generator_forward(sd: SD, hp: HParams, x_ids: Tensor, x_lengths: Tensor, y: Tensor, y_lengths: Tensor,
-                      speaker_ids: Optional[Tensor] = None, attn_override: Optional[Tensor] = None):
-    """models.py:310-337,361-399 (gen=False).  `attn_override` lets a test inject a fixed alignment."""
+                      speaker_ids: Optional[Tensor] = None, attn_override: Optional[Tensor] = None, drop=None):
+    """models.py:310-337,361-399 (gen=False).  `attn_override` lets a test inject a fixed alignment, `drop` (KeepMasks)
+    the dropout decisions of a training-mode forward."""
     g = speaker_embedding(sd, speaker_ids)
-    x_m, x_logs, logw, x_mask = text_encoder(sd, x_ids, x_lengths, g, hp)
+    x_m, x_logs, logw, x_mask = text_encoder(sd, x_ids, x_lengths, g, hp, drop)
     t_max = (y.shape[2] // hp.n_sqz) * hp.n_sqz                      # preprocess, models.py:401-406
     y = y[:, :, :t_max]
     y_lengths = (y_lengths // hp.n_sqz) * hp.n_sqz
     z_mask = sequence_mask(y_lengths, t_max).unsqueeze(1).to(x_mask.dtype)
     attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
-    z, logdet = flow_decoder(sd, y, z_mask, g, hp, reverse=False)
+    z, logdet = flow_decoder(sd, y, z_mask, g, hp, reverse=False, drop=drop)
     with torch.no_grad():
         if attn_override is None:
             logp = align_logp(x_m, x_logs, z)
@@ -619,14 +663,17 @@ def init_state_dict(hp: HParams, seed: int = 1234) -> SD:
     return sd
 
 
-def train_step(sd: SD, hp: HParams, opt: AdamNoam, batch, grad_clip: float = 5.0):
+def train_step(sd: SD, hp: HParams, opt: AdamNoam, batch, grad_clip: float = 5.0, drop=None, attn_out=None):
     """train.py:106-151 on CPU: forward, mle + duration loss, backward, clamp, Adam/Noam.  `sd` leaves must have
-    requires_grad=True.  Returns (loss, mel_frames)."""
+    requires_grad=True.  `drop`: KeepMasks of a training-mode step; `attn_out`: a list that receives the alignment.
+    Returns (loss, mel_frames)."""
     x_ids, x_lengths, y, y_lengths, spk = batch
     for p in sd.values():
         p.grad = None
     (z, z_m, z_logs, logdet, z_mask), _, (attn, logw, logw_) = generator_forward(sd, hp, x_ids, x_lengths, y,
-                                                                                 y_lengths, spk)
+                                                                                 y_lengths, spk, drop=drop)
+    if attn_out is not None:
+        attn_out.append(attn.detach())
     loss = mle_loss(z, z_m, z_logs, logdet, z_mask) + duration_loss(logw, logw_, x_lengths)
     loss.backward()
     grads = {k: p.grad for k, p in sd.items() if p.grad is not None}

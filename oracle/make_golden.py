@@ -15,6 +15,7 @@ How the reference is made importable here:
 Usage:  make -C oracle ref && python oracle/make_golden.py          (writes tests/golden/*.npz)
         python oracle/make_golden.py attention-long                  (only mha_c192_t240_w4 / mha_c64_t256_w4)
         python oracle/make_golden.py host                            (only the collate / table / config / checkpoint fixtures)
+        python oracle/make_golden.py dropout                         (only e2e_dropout_train: a step with recorded dropout masks)
 
 This script must be run in its own process: it imports the reference under the package name `glow_tts_train`,
 which is also the name of this repo's drop-in package.
@@ -423,6 +424,80 @@ def gen_e2e(R):
              noise_scale=np.float64(0.667))
 
 
+def dropout_site_names(n_pre, n_enc, n_dp, n_blocks, n_block_layers):
+    """The reference's F.dropout call order within ONE training forward (models.py:120-142 -> layers.py:73-80, attentions.py:62-74,
+    :251, :379, models.py:41-51; then models.py:193-211 -> layers.py:147), as the oracle's KeepMasks site names."""
+    names = [f"encoder.pre.{i}" for i in range(n_pre)]
+    for i in range(n_enc):
+        names += [f"encoder.encoder.{i}.attn", f"encoder.encoder.{i}.y1", f"encoder.encoder.{i}.ffn", f"encoder.encoder.{i}.y2"]
+    names += [f"encoder.proj_w.{i}" for i in range(n_dp)]
+    for blk in range(n_blocks):
+        names += [f"decoder.flows.{3 * blk + 2}.wn.{l}" for l in range(n_block_layers)]
+    return names
+
+
+def gen_e2e_dropout(R):
+    """Round 4: the training step WITH dropout (the state bench.py times).  torch.nn.functional.dropout is patched for the run:
+    it draws its keep decisions from a seeded generator, applies what F.dropout applies (x * keep / (1 - p)) and records
+    (keep, p) in call order — the decisions become data, so the oracle and the HIP path can be fed the same ones."""
+    import torch.nn.functional as TF
+
+    U = R.utils
+    torch.manual_seed(1234)
+    model = R.models.FlowGenerator(
+        n_vocab=148, hidden_channels=32, filter_channels=64, filter_channels_dp=32, out_channels=80,
+        kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1, n_blocks_dec=2, kernel_size_dec=5,
+        dilation_rate=1, n_block_layers=2, p_dropout_dec=0.05, n_speakers=0, gin_channels=0,
+        n_split=4, n_sqz=2, sigmoid_scale=False, window_size=4, block_length=None,
+        mean_only=True, hidden_channels_enc=32, hidden_channels_dec=32, prenet=True)
+    with torch.no_grad():
+        for f in model.decoder.flows:
+            if hasattr(f, "end"):
+                f.end.weight.copy_(0.05 * torch.randn_like(f.end.weight))
+                f.end.bias.copy_(0.05 * torch.randn_like(f.end.bias))
+            if hasattr(f, "logs") and hasattr(f, "bias"):
+                f.logs.copy_(0.1 * torch.randn_like(f.logs))
+                f.bias.copy_(0.1 * torch.randn_like(f.bias))
+        model.encoder.pre.proj.weight.copy_(0.05 * torch.randn_like(model.encoder.pre.proj.weight))
+    model.train()
+    x, xl, y, yl = e2e_inputs()
+    arrs = dict(x=npy(x), x_lengths=npy(xl), y=npy(y), y_lengths=npy(yl))
+    arrs.update(sd_dict(model))
+
+    gen = torch.Generator().manual_seed(4321)
+    record = []
+    orig = TF.dropout
+
+    def recording_dropout(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return inp
+        keep = (torch.rand(inp.shape, generator=gen) >= p)
+        record.append((keep, float(p)))
+        return inp * keep.to(inp.dtype) / (1.0 - p)
+
+    TF.dropout = recording_dropout
+    try:
+        (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = model(x, xl, y, yl)
+        l_mle = U.mle_loss(z, z_m, z_logs, logdet, z_mask)
+        l_len = U.duration_loss(logw, logw_, xl)
+        (l_mle + l_len).backward()
+    finally:
+        TF.dropout = orig
+    names = dropout_site_names(3, 2, 2, 2, 2)
+    assert len(record) == len(names), (len(record), len(names))
+    ps = {"encoder.pre": 0.5, "encoder.encoder": 0.1, "encoder.proj_w": 0.1, "decoder.flows": 0.05}
+    for n, (keep, p) in zip(names, record):
+        assert abs(p - ps[".".join(n.split(".")[:2])]) < 1e-12, (n, p)
+        arrs["keep." + n] = npy(keep).astype(np.uint8)
+        arrs["p." + n] = np.float64(p)
+    assert arrs["keep.encoder.encoder.0.attn"].shape == (3, 2, 9, 9) and arrs["keep.decoder.flows.5.wn.1"].shape == (3, 64, 20)
+    arrs.update(z=npy(z), z_m=npy(z_m), z_logs=npy(z_logs), logdet=npy(logdet), z_mask=npy(z_mask),
+                x_m=npy(x_m), x_logs=npy(x_logs), x_mask=npy(x_mask), attn=npy(attn).astype(np.int8),
+                logw=npy(logw), logw_=npy(logw_), l_mle=npy(l_mle), l_length=npy(l_len))
+    arrs.update(grads_dict(model))
+    save("e2e_dropout_train", **arrs)
+
+
 def gen_losses(R):
     U = R.utils
     torch.manual_seed(1234)
@@ -571,6 +646,9 @@ def main():
     if sys.argv[1:] == ["attention-long"]:  # only the two long-sequence attention fixtures (round 2)
         gen_attention(R, only_long=True)
         return
+    if sys.argv[1:] == ["dropout"]:         # only the training step with recorded dropout decisions (round 4)
+        gen_e2e_dropout(R)
+        return
     gen_host(R)
     gen_mas(R)
     gen_flows(R)
@@ -578,6 +656,7 @@ def main():
     gen_attention(R)
     gen_losses(R)
     gen_e2e(R)
+    gen_e2e_dropout(R)
     tot = sum(os.path.getsize(p) for p in glob.glob(os.path.join(OUT, "*.npz")))
     print("total fixture bytes:", tot)
 

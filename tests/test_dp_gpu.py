@@ -322,3 +322,50 @@ def test_clip_clamps_a_replaced_gradient_on_device():
     assert float(norm) == pytest.approx((81.0 * victim.numel() + 0.25 * n_rest) ** 0.5, rel=1e-4)
     opt.step()                                            # folds the foreign gradient back into the flat buffer
     assert opt._optim.grads_in_place()
+
+
+# ============================================================ the driver's SCALE command, rehearsed
+def _run_scale_command(n, tmp_path, extra_env=None):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N --steps 3 --warmup 1` — the exact launch line of the driver's scaling bench — as a CHILD process, with the
+    collectives staged by gloo because the ranks share this box's one card (BENCH_DIST_BACKEND=gloo: a rehearsal of the
+    N > 1 control flow, never a measurement).  Returns (returncode, stdout, stderr)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    (tmp_path / f"scale_{n}.stderr").write_text(r.stderr)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_scale_command_control_flow(n, tmp_path):
+    """What the driver will run first on an 8-GPU node, here with N ranks on one card: the launcher exits 0 (every rank
+    leaves — rank != 0 does not tear the group down under a rank still working), stdout carries exactly ONE JSON line with
+    n_gpus = N, the whole-job frame count, weak scaling, the 10 real buckets of the configs[1] model of which >= 7 are
+    launched during backward, the per-bucket timing rows, one core share per rank, and no one-GPU diagnostic legs."""
+    import json
+
+    rc, out, err = _run_scale_command(n, tmp_path)
+    assert rc == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["metric"] == "mel_frames_per_sec" and rec["higher_is_better"] is True and rec["dtype"] == "f32"
+    assert rec["config"]["global_batch"] == 32 * n and rec["config"]["parallelism"] == f"dp{n}"
+    assert "configs[1]" in rec["config"]["workload"]
+    assert abs(rec["value"] - n * 32 * 800 / (rec["ms_per_step"] * 1e-3)) <= 1e-6 * rec["value"]
+    comm = rec["comm"]
+    assert comm["buckets"] == 10 and comm["buckets_launched_during_backward"] >= 7, comm
+    assert comm["backend"] == "gloo" and comm["rccl_ranks"] == 0
+    assert abs(comm["grad_MB_per_step"] - 114.5) < 1.0
+    assert len(comm["per_bucket"]) == 10 and all(b["ready_to_start_ms"] >= 0 for b in comm["per_bucket"])
+    assert rec["host_cores_per_rank"] is not None and rec["host_cores_per_rank"] >= 1
+    assert "roofline" not in rec and "native_fp32" not in rec and "cpu_baseline" not in rec
+    assert np.isfinite(rec["config"]["final_loss"])

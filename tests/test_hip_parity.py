@@ -464,6 +464,45 @@ def test_e2e_train_golden(G, tag):
 
 
 @pytest.mark.usefixtures("conv_mode")
+def test_e2e_train_golden_with_recorded_dropout(G):
+    """The training step WITH dropout against the REFERENCE: tests/golden/e2e_dropout_train.npz is the reference's own run
+    with its F.dropout decisions recorded (pre-net 0.5, encoder 0.1 at four sites per layer, duration predictor 0.1, WN 0.05);
+    the package is made to use the same decisions (ops.keep_mask_inject) and must reproduce all 11 outputs, both losses and
+    every parameter gradient — every dropout path of the step (LayerNorm `_act` kernels, attention keep bytes, the encoder
+    layer executor's four masks, the gated conv epilogue and conv_gate_bwd) at the fixtures' tolerances."""
+    from helpers import MaskInject
+
+    g = load_golden("e2e_dropout_train")
+    kw = dict(n_vocab=148, hidden_channels=32, filter_channels=64, filter_channels_dp=32, out_channels=80,
+              kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1, n_blocks_dec=2, kernel_size_dec=5,
+              dilation_rate=1, n_block_layers=2, p_dropout_dec=0.05, n_speakers=0, gin_channels=0, n_split=4, n_sqz=2,
+              sigmoid_scale=False, window_size=4, block_length=None, mean_only=True, hidden_channels_enc=32,
+              hidden_channels_dec=32, prenet=True)
+    model = load_sd(G.models.FlowGenerator(**kw), g).train()
+    sites = {k[5:]: (v, float(g["p." + k[5:]])) for k, v in g.items() if k.startswith("keep.")}
+    x, xl, y, yl = dev(g["x"]), dev(g["x_lengths"]), dev(g["y"]), dev(g["y_lengths"])
+    model.zero_grad()
+    with MaskInject(G.ops, sites, n_blocks=2, n_block_layers=2, n_enc=2) as inj:
+        (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = model(x, xl, y, yl)
+    assert inj.served == set(sites), sorted(set(sites) - inj.served)      # every dropout site of the step took its decisions
+    outs = dict(z=z, z_m=z_m, z_logs=z_logs, logdet=logdet, z_mask=z_mask, x_m=x_m, x_logs=x_logs, x_mask=x_mask,
+                logw=logw, logw_=logw_)
+    for name, t in outs.items():
+        assert rel_err(t, g[name]) < REL, f"{name}: rel err {rel_err(t, g[name]):.3e}"
+        assert_close(t, g[name], what=name, rtol=5e-4, atol=1e-4)
+    assert (attn.cpu().numpy().astype(np.int8) == g["attn"]).all(), "alignment differs from the reference"
+    l_mle = G.utils.mle_loss(z, z_m, z_logs, logdet, z_mask)
+    l_len = G.utils.duration_loss(logw, logw_, xl)
+    assert_close(l_mle, g["l_mle"], what="l_mle", **TIGHT)
+    assert_close(l_len, g["l_length"], what="l_length", **TIGHT)
+    (l_mle + l_len).backward()
+    named = dict(model.named_parameters())
+    for k, want in split_prefix(g, "grad.").items():
+        assert named[k].grad is not None, k
+        assert_close(named[k].grad, want, what="grad " + k, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.usefixtures("conv_mode")
 @pytest.mark.parametrize("tag", ["base", "spk"])
 def test_e2e_generate_golden(G, tag):
     gt = load_golden(f"e2e_{tag}_train")

@@ -285,6 +285,42 @@ def test_e2e_train(tag):
         assert_close(params[k], want, what="after3 " + k, rtol=1e-4, atol=1e-6)
 
 
+def keep_masks_from_golden(g):
+    """KeepMasks from a fixture's `keep.<site>` / `p.<site>` arrays (oracle/make_golden.py gen_e2e_dropout)."""
+    return O.KeepMasks({k[5:]: (T(v), float(g["p." + k[5:]])) for k, v in g.items() if k.startswith("keep.")})
+
+
+def test_e2e_train_with_recorded_dropout():
+    """The training step WITH dropout (the state bench.py times): the reference's own run with its F.dropout decisions
+    recorded; the oracle fed the same decisions reproduces all 11 outputs, both losses and every parameter gradient —
+    pins every dropout SITE of the oracle (pre-net 0.5, encoder 0.1 x 4 per layer, duration predictor, WN 0.05)."""
+    g = load_golden("e2e_dropout_train")
+    hp = _e2e_hp("base")
+    sd = split_prefix(g, "sd.", requires_grad=True)
+    drop = keep_masks_from_golden(g)
+    assert len(drop.masks) == 3 + 2 * 4 + 2 + 2 * 2
+    x, xl, y, yl = T(g["x"]), T(g["x_lengths"]), T(g["y"]), T(g["y_lengths"])
+    (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = O.generator_forward(
+        sd, hp, x, xl, y, yl, None, drop=drop)
+    assert drop.used == set(drop.masks), sorted(set(drop.masks) - drop.used)
+    for name, t in dict(z=z, z_m=z_m, z_logs=z_logs, logdet=logdet, z_mask=z_mask, x_m=x_m, x_logs=x_logs,
+                        x_mask=x_mask, logw=logw, logw_=logw_).items():
+        assert_close(t, g[name], what=name, rtol=1e-4, atol=5e-5)
+    assert (attn.numpy().astype(np.int8) == g["attn"]).all(), "MAS alignment differs"
+    l_mle = O.mle_loss(z, z_m, z_logs, logdet, z_mask)
+    l_len = O.duration_loss(logw, logw_, xl)
+    assert_close(l_mle, g["l_mle"], what="l_mle", **TOL)
+    assert_close(l_len, g["l_length"], what="l_length", **TOL)
+    (l_mle + l_len).backward()
+    for k, want in split_prefix(g, "grad.").items():
+        assert sd[k].grad is not None, k
+        assert_close(sd[k].grad, want, what="grad " + k, rtol=5e-4, atol=5e-5)
+    # and the masks matter: without them the outputs differ by far more than the tolerance
+    with torch.no_grad():
+        z0 = O.generator_forward(sd, hp, x, xl, y, yl, None)[0][0]
+    assert float((z0 - T(g["z"])).abs().max()) > 1e-2
+
+
 @pytest.mark.parametrize("tag", ["base", "spk"])
 def test_e2e_generate(tag):
     gt = load_golden(f"e2e_{tag}_train")
