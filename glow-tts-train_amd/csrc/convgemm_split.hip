@@ -21,6 +21,7 @@
 //   activations: split while they are stored to LDS; plane image [g/2][frame][40 bf16]: a row holds the 32 channels of
 //               a group pair in the A operand's order (pitch 80 B, the conflict-free pitch of the fp32 image), so one
 //               ds_read_b128 per plane is a B operand.
+#include <atomic>
 #include "convgemm_common.hpp"
 #include "split_planes.hpp"
 
@@ -724,8 +725,11 @@ struct PlaneBinding {
     int ns = 0;
 };
 static thread_local PlaneBinding t_bound;
-static int g_conv_math = 0;       // planes for the forward-type kernels (0 = native fp32)
-static int g_conv_math_wrw = 0;   // planes for the weight-gradient kernel
+// The library's ONE piece of mutable process-wide state (include/glowtts_hip.h, conventions): read by launches made from any
+// thread (autograd's backward thread included) while another may call the setter, hence atomic; a launch takes the value
+// in force when it is queued.
+static std::atomic<int> g_conv_math{0};       // planes for the forward-type kernels (0 = native fp32)
+static std::atomic<int> g_conv_math_wrw{0};   // planes for the weight-gradient kernel
 
 static bool find_planes(const float *wp, int ns, const unsigned short **out, long *stride) {
     const PlaneBinding &b = t_bound;
@@ -863,7 +867,7 @@ static int dispatch_wrw_split_ns(ConvWrwParams &p, hipStream_t s) {
 
 // called by the frame-packed weight-gradient entries (dilation 1, 'same' padding, 16-byte rows already checked)
 int conv_wrw_split_dispatch(ConvWrwParams &p, hipStream_t s) {
-    const int ns = g_conv_math_wrw;
+    const int ns = g_conv_math_wrw.load(std::memory_order_relaxed);
     if (ns != 0)                                   // 5-tap convolutions: the frame-major / transposed-read kernel (convwrw_tr.hip)
         if (int rc = conv_wrw_tr_dispatch(p, ns, s); rc >= 0) return rc;
     if (ns == 3) return dispatch_wrw_split_ns<3>(p, s);
@@ -886,7 +890,7 @@ int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_
 
 // called first by dispatch_convgemm: -1 = not handled here (mode off, weights not registered, shape not instantiated)
 int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, int nct, bool pipe_ok, hipStream_t s) {
-    const int ns = g_conv_math;
+    const int ns = g_conv_math.load(std::memory_order_relaxed);
     if (ns == 0 || !pipe_ok) return -1;
     const unsigned short *pl = nullptr;
     long st = 0;
@@ -901,17 +905,17 @@ int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, int nct, bool pipe
 using namespace glowtts;
 
 extern "C" int glowtts_conv_math(int nsplit) {
-    if (nsplit < 0) return g_conv_math | (g_conv_math_wrw << 2);
+    if (nsplit < 0) return g_conv_math.load() | (g_conv_math_wrw.load() << 2);
     GLOWTTS_CHECK_ARG(nsplit <= 15, "glowtts_conv_math: mode %d (0 = native fp32, 1 = bf16, 2 = bf16x3, 3 = bf16x6; "
                       "+ 4 x the same code for the weight-gradient kernel)", nsplit);
-    g_conv_math = nsplit & 3;
-    g_conv_math_wrw = (nsplit >> 2) & 3;
+    g_conv_math.store(nsplit & 3);
+    g_conv_math_wrw.store((nsplit >> 2) & 3);
     return 0;
 }
 
 extern "C" int glowtts_conv_split_weights(const float *wp, long n, unsigned short *planes, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(wp && planes && n > 0, "glowtts_conv_split_weights: bad arguments");
-    const int ns = g_conv_math;
+    const int ns = g_conv_math.load(std::memory_order_relaxed);
     if (ns == 0) return 0;
     long grid = (n + 255) / 256;
     if (grid > 2048) grid = 2048;
@@ -924,7 +928,7 @@ extern "C" int glowtts_conv_bind_planes(const float *wp, long n, const unsigned 
     t_bound.wp = wp;
     t_bound.n = wp ? n : 0;
     t_bound.planes = wp ? planes : nullptr;
-    t_bound.ns = wp ? g_conv_math : 0;           // the planes were written for the mode in force now
+    t_bound.ns = wp ? g_conv_math.load(std::memory_order_relaxed) : 0;           // the planes were written for the mode in force now
     return 0;
 }
 

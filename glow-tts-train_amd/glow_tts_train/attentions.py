@@ -38,6 +38,8 @@ class Encoder(nn.Module):
             FFN(hidden_channels, hidden_channels, filter_channels, kernel_size, p_dropout=p_dropout)
             for _ in range(n_layers))
         self.norm_layers_2 = nn.ModuleList(LayerNorm(hidden_channels) for _ in range(n_layers))
+        for i, (attn, ffn) in enumerate(zip(self.attn_layers, self.ffn_layers)):       # names of their dropout keep-masks
+            attn._site, ffn._site = f"encoder.encoder.{i}.attn", f"encoder.encoder.{i}.ffn"
 
     def _native_layers(self, x):
         """[(ConvGroup, attn, ffn, norm1, norm2), ...] when EVERY layer can run as one native call each way, else None."""
@@ -76,10 +78,15 @@ class Encoder(nn.Module):
                 x = _enc_layer_apply(x, m2, drops, cfg, (group, attn, ffn, norm1, norm2), *live)
             return x * x_mask
         pair_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
-        for attn, norm1, ffn, norm2 in zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2):
+        p = float(self.p_dropout) if self.training else 0.0
+        for i, (attn, norm1, ffn, norm2) in enumerate(zip(self.attn_layers, self.norm_layers_1, self.ffn_layers, self.norm_layers_2)):
             x = x * x_mask
-            x = norm1(x, res=self.drop(attn(x, x, pair_mask)))       # LN(x + y): residual add fused into the norm kernel
-            x = norm2(x, res=self.drop(ffn(x, x_mask)))
+            y = attn(x, x, pair_mask)
+            y = ops.dropout(y, p, f"encoder.encoder.{i}.y1") if x.is_cuda else self.drop(y)
+            x = norm1(x, res=y)                                      # LN(x + y): residual add fused into the norm kernel
+            y = ffn(x, x_mask)
+            y = ops.dropout(y, p, f"encoder.encoder.{i}.y2") if x.is_cuda else self.drop(y)
+            x = norm2(x, res=y)
         return x * x_mask
 
 
@@ -186,7 +193,7 @@ class MultiHeadAttention(nn.Module):
             ek = self.emb_rel_k if self.window_size is not None else None
             ev = self.emb_rel_v if self.window_size is not None else None
             return _rel_attn_apply(query, key, value, ek, ev, m2, self.n_heads, self.window_size or 0,
-                                   self.block_length, p_drop, bool(self.bf16_mma))
+                                   self.block_length, p_drop, bool(self.bf16_mma), getattr(self, "_site", "attn"))
         if query.is_cuda and not getattr(MultiHeadAttention, "_warned_general", False):
             MultiHeadAttention._warned_general = True
             import logging
@@ -224,7 +231,11 @@ class MultiHeadAttention(nn.Module):
                 pos = torch.arange(t_s, device=q.device)
                 band = ((pos[None, :] - pos[:, None]).abs() <= self.block_length).to(scores.dtype)
                 scores = scores * band + -1e4 * (1 - band)
-        p_attn = self.drop(F.softmax(scores, dim=-1))
+        p_attn = F.softmax(scores, dim=-1)
+        if self.training and self.p_dropout > 0 and p_attn.is_cuda:
+            p_attn = ops.dropout(p_attn, float(self.p_dropout), getattr(self, "_site", "attn"))
+        else:
+            p_attn = self.drop(p_attn)
         out = torch.matmul(p_attn, v)
         if w is not None:
             # weights on the 2w+1 diagonals around the main one: pw[..., i, r] = p[i, i + r - w]
@@ -251,4 +262,6 @@ class FFN(nn.Module):
         m2 = ops.mask2d(x_mask)
         h = convops.conv1d(self.conv_1, x, m2, mask_in=True)                       # conv_1(x * mask)
         h = h * torch.sigmoid(1.702 * h) if self.activation == "gelu" else torch.relu(h)
-        return convops.conv1d(self.conv_2, self.drop(h), m2, mask_in=True, mask_out=True)   # conv_2(h * mask) * mask
+        if self.training and self.p_dropout > 0 and h.is_cuda:
+            h = ops.dropout(h, float(self.p_dropout), getattr(self, "_site", "ffn"))
+        return convops.conv1d(self.conv_2, h, m2, mask_in=True, mask_out=True)   # conv_2(h * mask) * mask

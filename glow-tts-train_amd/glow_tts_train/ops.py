@@ -62,6 +62,24 @@ def _next_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=_seed_gen).item())
 
 
+def seed_keep_masks(seed: int) -> None:
+    """Restart the keep-mask seed sequence from `seed` (what a change of torch.initial_seed() does implicitly): two runs that
+    call this with the same value draw the same masks, whatever was drawn before."""
+    global _seed_gen, _seed_gen_from
+    _seed_gen = torch.Generator(device="cpu")
+    _seed_gen.manual_seed((int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
+    _seed_gen_from = torch.initial_seed()
+
+
+def dropout(x: torch.Tensor, p_drop: float, site: str = "") -> torch.Tensor:
+    """F.dropout(x, p, training=True) with the package's keep-masks (the per-operator paths of the text encoder; the executors
+    apply their masks inside kernels): x * keep / (1 - p), differentiable through torch's multiply."""
+    if p_drop <= 0.0:
+        return x
+    keep = keep_mask(tuple(x.shape), p_drop, x.device, site)
+    return x * (keep.to(x.dtype) * (1.0 / (1.0 - p_drop)))
+
+
 def keep_mask(shape, p_drop: float, device, site: str = "") -> torch.Tensor:
     """uint8 dropout keep-mask (1 = keep with probability 1 - p_drop) of `shape`, in ONE launch whatever its size
     (`glowtts_keep_mask`: Philox4x32-7, two bytes of randomness per decision, so p is quantised to 1/65536).  The seed comes
@@ -541,7 +559,7 @@ class RelAttnFn(Function):
     `bf16_mma`: the contractions on the bf16 matrix pipe with fp32 accumulation (tensors and softmax stay fp32)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, emb_k, emb_v, m2, n_heads, window, block_length, p_drop, bf16_mma=False):
+    def forward(ctx, q, k, v, emb_k, emb_v, m2, n_heads, window, block_length, p_drop, bf16_mma=False, site="attn"):
         q, k, v = f32(_c(q)), f32(_c(k)), f32(_c(v))
         B, C, T = q.shape
         dk = C // n_heads
@@ -551,7 +569,7 @@ class RelAttnFn(Function):
         share = int((not has_rel) or emb_k.shape[0] == 1)
         drop = None
         if p_drop > 0.0:
-            drop = keep_mask((B, n_heads, T, T), p_drop, q.device, "attn")   # keep = 1
+            drop = keep_mask((B, n_heads, T, T), p_drop, q.device, site)   # keep = 1
         p_attn = torch.empty(B, n_heads, T, T, device=q.device, dtype=torch.float32)
         out = torch.empty_like(q)
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
@@ -581,7 +599,7 @@ class RelAttnFn(Function):
         call("glowtts_rel_attn_bwd_ex", ptr(dout), ptr(q), ptr(k), ptr(v), ptr(ek), ptr(ev), ptr(m2), ptr(drop), scale,
              ptr(p_attn), ptr(ds), ptr(dq), ptr(dk_), ptr(dv), ptr(dek), ptr(dev), B, n_heads, T, dk, window, share, blk,
              bf16_mma)
-        return dq, dk_, dv, dek, dev, None, None, None, None, None, None
+        return dq, dk_, dv, dek, dev, None, None, None, None, None, None, None
 
 
 def library_loaded() -> bool:

@@ -7,9 +7,21 @@
  *
  * Conventions (all functions):
  *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
- *     no allocation, no ownership transfer; re-entrant from autograd's backward threads.  The only process-wide state
- *     is the arithmetic mode of glowtts_conv_math (an explicit setter), per-device high-water marks of kernel LDS limits
- *     and per-thread event rings / plane bindings;
+ *     no allocation, no ownership transfer; re-entrant from autograd's backward threads.  State the library keeps:
+ *       process-wide, mutable : the arithmetic mode of glowtts_conv_math (an explicit setter; atomic — a launch uses the
+ *                               mode in force when it is queued, so flip it between steps, not while a backward runs);
+ *       process-wide, latched : the tuning switches below, read from the environment ONCE at the first launch that
+ *                               consults them (they select between kernels with identical results; defaults in brackets):
+ *                                 GLOWTTS_WRW_TR      [unset] 0 = 5-tap weight gradient on the frame-packed kernel, 1 = 64x32
+ *                                                     tiles in the 16x16x32 form            (csrc/convwrw_tr.hip)
+ *                                 GLOWTTS_WRW_TR_MT   [4]     2 = 64x32 tiles (32x32x16 form) instead of 64x64
+ *                                 GLOWTTS_WRW_TR3     [1]     0 = 3-tap weight gradients on the frame-packed kernel
+ *                                 GLOWTTS_WRW_TR_PRIO [2]     which wave group of the 5-tap weight gradient runs at raised priority
+ *                                 GLOWTTS_WRW_BATCH   [1]     0 = one weight-gradient launch per WN layer (csrc/wn_stack.hip)
+ *                                 GLOWTTS_WN_FUSED    [1]     0 = WN forward as one gated-conv + one res/skip launch per layer
+ *                                                     instead of the layer-resident kernel    (csrc/wn_fused.hip)
+ *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
+ *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
  *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)
  *     holding 0/1 (the reference's (B,1,T) float mask viewed flat); log-determinants are fp32 (B);
  *   - `stream` is a hipStream_t (pass PyTorch's current stream): launches are asynchronous and ordered on it,

@@ -132,6 +132,9 @@ class MaskInject:
         elif site == "encoder.layers":
             m = torch.cat([self._get(f"encoder.encoder.{i}.{n}", p).reshape(-1) for i in range(self.n_enc)
                            for n in ("attn", "y1", "ffn", "y2")])
+        elif site.startswith("decoder.block."):          # one block's (layers, B, 2H, T') drawn by the block itself
+            k = int(site.rsplit(".", 1)[1])
+            m = torch.stack([self._get(f"decoder.flows.{3 * k + 2}.wn.{l}", p) for l in range(self.n_block_layers)])
         elif site in self.sites:
             m = self._get(site, p)
         else:

@@ -57,7 +57,7 @@ def _record_margin(test, arith, **fields):
 
 @pytest.fixture(scope="module")
 def G():
-    from glow_tts_train import _hip, convops, models, optimize, utils
+    from glow_tts_train import _hip, convops, models, ops, optimize, utils
 
     _hip.load()
 
@@ -65,7 +65,7 @@ def G():
         pass
 
     ns = NS()
-    ns.hip, ns.convops, ns.models, ns.optimize, ns.utils = _hip, convops, models, optimize, utils
+    ns.hip, ns.convops, ns.models, ns.optimize, ns.utils, ns.ops = _hip, convops, models, optimize, utils, ops
     return ns
 
 
@@ -189,6 +189,7 @@ def test_decoder_fwd_bwd_vs_oracle_full_config2(G, conv_mode, dropout):
     s = torch.randn(b)
 
     yd = y.cuda().requires_grad_(True)
+    G.ops.seed_keep_masks(98)                    # same keep-masks in both arithmetics: the oracle's side is computed once
     with MaskTap(G.ops) as tap:
         z, logdet = model.decoder(yd, mask.cuda())
         ((z * r.cuda()).sum() + (logdet * s.cuda()).sum()).backward()
@@ -236,7 +237,7 @@ def test_train_step_vs_oracle_full_size(G, conv_mode, name, b, tx, ty, blocks, s
     x, xl, y, yl, spk = _ragged_batch(b, tx, ty, seed=12, speakers=speakers)
     opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=192, warmup_steps=4000, lr=1.0)
     cu = lambda t: None if t is None else t.cuda()
-    torch.manual_seed(99)                        # same keep-masks in both arithmetics: the oracle's side is computed once
+    G.ops.seed_keep_masks(99)                    # same keep-masks in both arithmetics: the oracle's side is computed once
     attn_hip = []
     hook = model.register_forward_hook(lambda _m, _i, out: attn_hip.append(out[2][0].detach()))
     with MaskTap(G.ops) as tap:

@@ -481,7 +481,9 @@ def test_e2e_train_golden_with_recorded_dropout(G):
     model = load_sd(G.models.FlowGenerator(**kw), g).train()
     sites = {k[5:]: (v, float(g["p." + k[5:]])) for k, v in g.items() if k.startswith("keep.")}
     x, xl, y, yl = dev(g["x"]), dev(g["x_lengths"]), dev(g["y"]), dev(g["y_lengths"])
-    model.zero_grad()
+    opt = G.optimize.Adam(model.parameters(), scheduler="noam", dim_model=32, warmup_steps=4000, lr=1.0,
+                          betas=(0.9, 0.98), eps=1e-9)              # flat gradient buffers: the executors' in-place gradient path
+    opt.zero_grad()
     with MaskInject(G.ops, sites, n_blocks=2, n_block_layers=2, n_enc=2) as inj:
         (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = model(x, xl, y, yl)
     assert inj.served == set(sites), sorted(set(sites) - inj.served)      # every dropout site of the step took its decisions
