@@ -739,6 +739,10 @@ static bool find_planes(const float *wp, int ns, const unsigned short **out, lon
     return true;
 }
 
+// wn_fused.hip: the planes bound to the calling thread for packed weights at `wp`, and the forward-type arithmetic code
+bool conv_find_planes(const float *wp, int ns, const unsigned short **out, long *stride) { return find_planes(wp, ns, out, stride); }
+int conv_math_forward() { return g_conv_math.load(std::memory_order_relaxed); }
+
 template <int NS, int RTW, int NCT, int EPI, int TAPS, int IOB = 0, int NSA = NS>
 static int launch_split(ConvGemmParams &p, const unsigned short *planes, long stride, hipStream_t s) {
     constexpr int WGR = 64 * RTW, NT = 16 * NCT;

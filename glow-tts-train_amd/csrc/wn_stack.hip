@@ -36,6 +36,11 @@ static hipEvent_t next_event() {
     return e;
 }
 
+// wn_fused.hip: the whole stack's forward as one kernel; -1 = not applicable
+int wn_fused_dispatch(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask, const unsigned char *drop,
+                      float drop_scale, float *xs, float *acts, float *ts, float *skip, int B, int H, int T, int taps, int dil_rate,
+                      hipStream_t s);
+
 // everything queued on `from` so far happens before whatever is queued on `to` next
 static int order_after(hipStream_t from, hipStream_t to) {
     if (from == to) return 0;
@@ -80,6 +85,12 @@ extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, c
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_fwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_fwd: bad shape");
     const long BHT = (long)B * H * T;
+    if (!io && !cond) {        // the layer-resident kernel (csrc/wn_fused.hip): fp32 tensors, bf16x6 arithmetic, H = 192, 5 taps
+        const int rc = wn_fused_dispatch(layers, n_layers, static_cast<const float *>(x), mask, drop, drop_scale, static_cast<float *>(xs),
+                                         static_cast<float *>(acts), static_cast<float *>(ts), static_cast<float *>(skip), B, H, T, taps,
+                                         dil_rate, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     long dil = 1;
     for (int i = 0; i < n_layers; ++i, dil *= dil_rate) {
         const glowtts_wn_layer &L = layers[i];

@@ -143,7 +143,7 @@ class EncLayer(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
-                           "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns"])
+                           "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -174,6 +174,8 @@ def load() -> ctypes.CDLL:
     lib.glowtts_abi_version.argtypes = []
     lib.glowtts_conv_math.restype = _I
     lib.glowtts_conv_math.argtypes = [_I]
+    lib.glowtts_wn_fused.restype = _I
+    lib.glowtts_wn_fused.argtypes = [_I]
     lib.glowtts_conv_bind_planes.restype = _I
     lib.glowtts_conv_bind_planes.argtypes = [_P, _L, _P]
     lib.glowtts_conv_bind_planes_ns.restype = _I
@@ -248,6 +250,17 @@ def conv_math(mode=None) -> int:
         if lib.glowtts_conv_math(code) != 0:
             raise RuntimeError(lib.glowtts_last_error().decode())
     return before
+
+
+def wn_fused(enable: Optional[bool] = None) -> bool:
+    """The layer-resident WN forward kernel (include/glowtts_hip.h: glowtts_wn_fused): True / False switches it, None only
+    queries.  Returns the setting in force BEFORE the call."""
+    return bool(load().glowtts_wn_fused(-1 if enable is None else int(bool(enable))))
+
+
+def wn_fused_launches() -> int:
+    """Launches of the layer-resident WN forward kernel so far in this process."""
+    return int(load().glowtts_wn_fused(-2))
 
 
 def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] = None):

@@ -45,30 +45,23 @@ _TORCH_MASKS = __import__("os").environ.get("GLOWTTS_KEEP_MASK", "1") == "0"    
 keep_mask_tap = None
 keep_mask_inject = None
 
-# Seeds of the Philox launches come from a generator of their OWN: drawing them from torch's global CPU generator
-# perturbed the stream DataLoader shuffling and worker seeding use.  It is (re)seeded from torch.initial_seed(), so
-# torch.manual_seed(s) still fixes the masks of the steps that follow it.
-_seed_gen = None
-_seed_gen_from = None
-
-
-def _next_seed() -> int:
-    global _seed_gen, _seed_gen_from
-    base = torch.initial_seed()
-    if _seed_gen is None or _seed_gen_from != base:
-        _seed_gen = torch.Generator(device="cpu")
-        _seed_gen.manual_seed((base * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
-        _seed_gen_from = base
-    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=_seed_gen).item())
+# Seeds of the Philox launches are drawn the way torch's own CUDA dropout draws them: from the device's default CUDA generator
+# — (its seed, its Philox offset), the offset then advanced — NOT from the global CPU generator (that perturbed the
+# stream DataLoader shuffling and worker seeding use).  torch.manual_seed(s) resets that generator's seed and offset, so it
+# fixes the masks of the steps that follow it, again and again for the same s.
+def _next_seed(device) -> int:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + 4)                              # (Philox offsets move in fours)
+    return (seed * 0x9E3779B97F4A7C15 + off * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) % (2 ** 62)
 
 
 def seed_keep_masks(seed: int) -> None:
-    """Restart the keep-mask seed sequence from `seed` (what a change of torch.initial_seed() does implicitly): two runs that
-    call this with the same value draw the same masks, whatever was drawn before."""
-    global _seed_gen, _seed_gen_from
-    _seed_gen = torch.Generator(device="cpu")
-    _seed_gen.manual_seed((int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) % (2 ** 63))
-    _seed_gen_from = torch.initial_seed()
+    """Restart the keep-mask sequence of the current device from `seed` (= torch.cuda.manual_seed: the masks follow the device's
+    default generator): two runs that call this with the same value draw the same masks, whatever was drawn before."""
+    torch.cuda.manual_seed(int(seed))
 
 
 def dropout(x: torch.Tensor, p_drop: float, site: str = "") -> torch.Tensor:
@@ -83,8 +76,8 @@ def dropout(x: torch.Tensor, p_drop: float, site: str = "") -> torch.Tensor:
 def keep_mask(shape, p_drop: float, device, site: str = "") -> torch.Tensor:
     """uint8 dropout keep-mask (1 = keep with probability 1 - p_drop) of `shape`, in ONE launch whatever its size
     (`glowtts_keep_mask`: Philox4x32-7, two bytes of randomness per decision, so p is quantised to 1/65536).  The seed comes
-    from a package-private CPU generator seeded from torch.initial_seed(): `torch.manual_seed` makes the masks repeatable and
-    drawing them does not consume the global CPU stream; inside a graph capture the seed would be frozen into the graph, so
+    from the device's default CUDA generator (seed + Philox offset, as torch's own dropout): `torch.manual_seed` makes the masks
+    repeatable and drawing them does not consume the global CPU stream; inside a graph capture the seed would be frozen into the graph, so
     there the mask is drawn by torch's graph-aware `bernoulli_`.  `site` names what the mask is for (see the hooks above)."""
     shape = tuple(int(d) for d in shape)
     n = 1
@@ -103,7 +96,7 @@ def keep_mask(shape, p_drop: float, device, site: str = "") -> torch.Tensor:
         if torch.cuda.is_current_stream_capturing() or _TORCH_MASKS:
             out.bernoulli_(1.0 - p_drop)
         else:
-            call("glowtts_keep_mask", ptr(out), n, _next_seed(), float(p_drop))
+            call("glowtts_keep_mask", ptr(out), n, _next_seed(device), float(p_drop))
     if keep_mask_tap is not None:
         keep_mask_tap(site, out, float(p_drop))
     return out

@@ -1337,6 +1337,75 @@ def test_wn_stack_shapes_vs_oracle(G, b, h, t, k, nl, dil, prealloc):
         assert_close(p.grad, want, what=f"grad {name}", rtol=1e-3, atol=1e-4 * max(1.0, float(want.abs().max())))
 
 
+@pytest.mark.parametrize("b,t,nl,p_drop", [
+    (3, 100, 4, 0.05),     # two frame tiles per utterance, ragged lengths, dropout
+    (2, 52, 4, 0.0),       # exactly one tile
+    (2, 56, 4, 0.05),      # a second tile of 4 frames
+    (1, 400, 4, 0.05),     # the config-2 frame count: 8 tiles
+    (2, 60, 3, 0.0),       # three layers
+    (2, 24, 1, 0.05),      # one layer (all rows are skip rows)
+    (4, 212, 2, 0.05),     # two layers, five tiles
+])
+def test_wn_layer_resident_forward_matches_per_layer_path_and_oracle(G, b, t, nl, p_drop):
+    """csrc/wn_fused.hip (the forward of a whole WN stack in one kernel: reference layers.py:138-162) against the per-layer launch
+    sequence it replaces — same keep-masks, `glowtts_wn_fused` flipped — and against the oracle: the stack's output, and through
+    the backward every tensor the kernel leaves behind for it (x_{l+1}, acts, tanh / sigmoid): dx and all parameter gradients."""
+    from glow_tts_train import convops
+    from oracle import glow_oracle as O
+
+    h, k = 192, 5
+    before_math = convops.set_conv_math("bf16x6+wrw")
+    before_fused = G.hip.wn_fused(None)
+    try:
+        torch.manual_seed(4000 + 13 * b + t + nl)
+        wn = G.layers.WN(2 * h, h, kernel_size=k, dilation_rate=1, n_layers=nl, p_dropout=p_drop).cuda().train()
+        with torch.no_grad():
+            for p in wn.parameters():
+                if p.dim() == 1:
+                    p.normal_(0, 0.05)               # non-zero biases
+        x0 = torch.randn(b, h, t)
+        lens = torch.randint(max(1, t // 2), t + 1, (b,))
+        lens[0] = t
+        mask = (torch.arange(t)[None] < lens[:, None]).float()[:, None]
+        r = torch.randn(b, h, t)
+        keep = G.ops.keep_mask((nl, b, 2 * h, t), p_drop, "cuda", "test") if p_drop > 0 else None
+
+        def run(fused):
+            G.hip.wn_fused(fused)
+            for p in wn.parameters():
+                p.grad = torch.zeros_like(p)
+            x = (x0 * mask).cuda().requires_grad_(True)
+            wn._drop_pre = keep
+            y = wn(x, mask.cuda())
+            (y * r.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in wn.named_parameters()}
+
+        n0 = G.hip.wn_fused_launches()
+        y1, dx1, g1 = run(True)
+        n1 = G.hip.wn_fused_launches()
+        y0, dx0, g0 = run(False)
+        assert n1 == n0 + 1 and G.hip.wn_fused_launches() == n1, "the layer-resident kernel ran exactly when it was switched on"
+        assert_close(y1, y0, what="y fused vs per-layer", rtol=1e-5, atol=2e-6 * max(1.0, float(y0.abs().max())))
+        assert_close(dx1, dx0, what="dx fused vs per-layer", rtol=1e-4, atol=1e-5 * max(1.0, float(dx0.abs().max())))
+        for n in g0:
+            assert_close(g1[n], g0[n], what=f"grad {n} fused vs per-layer", rtol=1e-4, atol=1e-5 * max(1.0, float(g0[n].abs().max())))
+
+        sd = {"wn." + k_: v.detach().cpu().clone().requires_grad_(True) for k_, v in wn.state_dict().items()}
+        xo = (x0 * mask).clone().requires_grad_(True)
+        drop = O.KeepMasks({f"wn.{l}": (keep[l].cpu(), p_drop) for l in range(nl)} if keep is not None else {})
+        yo = O.wn(sd, "wn", xo, mask, None, h, nl, 1, drop)
+        (yo * r).sum().backward()
+        assert_close(y1, yo, what="y", rtol=2e-4, atol=2e-5 * max(1.0, float(yo.abs().max())))
+        assert_close(dx1, xo.grad, what="dx", rtol=5e-4, atol=5e-5 * max(1.0, float(xo.grad.abs().max())))
+        for name, p in wn.named_parameters():
+            want = sd["wn." + name].grad
+            assert_close(g1[name], want, what=f"grad {name}", rtol=1e-3, atol=1e-4 * max(1.0, float(want.abs().max())))
+    finally:
+        G.hip.wn_fused(before_fused)
+        convops.set_conv_math(before_math)
+
+
 def test_multi_stream_step_matches_single_stream_step(G):
     """train_batch overlaps the text encoder, the weight-gradient kernels and the dx chain on three streams.  Three optimisation
     steps with the overlap must leave the same parameters as three steps with everything on one stream (GLOWTTS_SIDE_STREAM=0);
