@@ -53,9 +53,11 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // The gate of the fused conv epilogues: hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the libm
-// routines — absolute error <= 3e-7 on values in [-1, 1], a third of the epilogue's instructions.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// routines — absolute error <= 3e-7 on values in [-1, 1], a third of the epilogue's instructions.  (Round 4: the reciprocal
+// IS v_rcp_f32 now — `__frcp_rn` compiled to the correctly-rounded division sequence, v_div_scale / v_div_fmas / v_div_fixup
+// around the v_rcp_f32: ~10 instructions per reciprocal, 40 % of the gate phase of csrc/wn_fused.hip.)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 
 // 16-byte (V = 4) or scalar (V = 1) access along the contiguous T axis.

@@ -17,11 +17,11 @@
 //                    convgemm_split) — holds the x planes while the in-conv runs, the `acts` planes while the res/skip conv runs;
 //                    X32 = x in fp32 [64 frames][196] (the residual update's operand; R1 is overwritten by `acts`);
 //                    row masks and the two bias vectors.
-//   waves          : 8 (512 threads, two per SIMD).  In-conv: wave w owns hidden channels 24w .. 24w+23 as three MIXED row tiles
-//                    (rows 0-7 tanh rows of 8 channels, rows 8-15 the sigmoid rows of the same channels): the pair of a gate
-//                    meets in lanes l / l + 32 of one register -> v_permlane32_swap, no LDS exchange.  Res/skip conv: wave w owns
-//                    residual rows 24w .. 24w+23 and skip rows 24w .. 24w+23 (tile 0: residual, tile 1: 8 + 8, tile 2: skip);
-//                    the skip accumulators PERSIST across the layers — the skip sum is never stored until the end.
+//   waves          : 12 (768 threads, three per SIMD).  Wave w owns hidden channels 16w .. 16w+15: in the in-conv the tanh row tile and
+//                    the sigmoid row tile of those channels — the two halves of a gate are the same register of the same lane, no
+//                    exchange; in the res/skip conv the residual row tile and the skip row tile.  The skip accumulators PERSIST
+//                    across the layers — the skip sum is never stored until the end.  (First form: 8 waves x 24 channels as mixed
+//                    tanh / sigmoid tiles with a lane exchange — its gate phase took 17.7 us per layer, this one's N.)
 //   weights        : never touch LDS: each wave's A tiles are its own, loaded from L2 with range-checked buffer loads into a
 //                    two-slot register ring one 32-deep step ahead (convgemm_split's k relabelling).
 //
@@ -62,13 +62,17 @@ __device__ __forceinline__ void lds_stores_done() { asm volatile("s_waitcnt lgkm
 __device__ __forceinline__ int row_pos(int c) { const int kk = c & 15; return (kk >> 2) * 8 + ((c >> 4) & 1) * 4 + (kk & 3); }
 
 #ifdef GLOWTTS_TRACE
-#define WNF_TRACE(i) do { if (threadIdx.x == 0) g_trace[(blockIdx.x & 8191) * 16 + (i)] = wall_clock64(); } while (0)
+// 32 words per workgroup: 0 start, 1 prologue done; layer l at 2 + 6 l: in-conv start / end, gate end, res-skip start / end, update end;
+// 26 end; 27 / 28 shader cycle counter around layer 0's in-conv; 29 XCC id
+#define WNF_TRACE(i) do { if (threadIdx.x == 0) g_trace[(blockIdx.x & 4095) * 32 + (i)] = wall_clock64(); } while (0)
+#define WNF_CYCLES(i) do { if (threadIdx.x == 0) g_trace[(blockIdx.x & 4095) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WNF_TRACE(i) do { } while (0)
+#define WNF_CYCLES(i) do { } while (0)
 #endif
 }  // namespace wnf
 
-__global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
+__global__ __launch_bounds__(768, 3) void wn_fused_kernel(WnFusedParams p) {
     using namespace wnf;
     extern __shared__ __align__(16) float smem[];
     unsigned short *Pl = reinterpret_cast<unsigned short *>(smem);         // [3][GP][XR][RP]
@@ -87,7 +91,12 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
     const long HT = (long)H * T;
 
     WNF_TRACE(0);
+#ifdef GLOWTTS_TRACE
+    if (threadIdx.x == 0) g_trace[(blockIdx.x & 4095) * 32 + 29] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+#endif
     // ------------------------------------------------------------------------------------------------ prologue: x_0 -> R1, X32
+    // pieces of 4 channels x 4 frames (four 16-byte loads; a frame of the piece is one 8-byte LDS store per plane): 6 group pairs
+    // x 20 frame quads (17 used) x 8 channel quads = 960 slots; 16 lanes = 8 channel quads x 2 frame quads 4 frames apart
     {
         const char *xb8 = reinterpret_cast<const char *>(p.x + (long)b * HT);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xb8), 0, (int)(HT * 4), 0x00020000);
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
         int hi_[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int hi = (tid >> 5) + 16 * r;
+            const int hi = (tid >> 5) + 24 * r;                          // 24 half-wave slots per round: 30 (group pair, quad group)s
             hi_[r] = hi;
             const int gp = hi / 5, fq = (hi - gp * 5) * 4 + fql;
             const int t = fs + fq * 4;
@@ -134,26 +143,23 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
     }
 
     // ---- per-lane constants -------------------------------------------------------------------------------------------
-    // in-conv A rows: tile j, lane row lrow: lrow < 8 -> tanh row of channel 24 w + 8 j + lrow, else the sigmoid row of channel
-    // 24 w + 8 j + lrow - 8
-    int wvo_in[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int chn = 24 * wave + 8 * j + (lrow & 7);
-        const int row = lrow < 8 ? chn : H + chn;
-        wvo_in[j] = (row * 16 + lk * 4) * 2;
-    }
+    // wave w owns hidden channels 16 w .. 16 w + 15: in-conv row tiles T (tanh rows 16 w + lrow) and S (sigmoid rows H + 16 w + lrow)
+    // — the two halves of a gate are the same register of the same lane; res/skip row tiles R (residual rows) and K (skip rows)
+    const int cw = 16 * wave;
+    const int wvo_t = ((cw + lrow) * 16 + lk * 4) * 2, wvo_s = wvo_t + H * 32;
     constexpr int WTAP_IN = G * 2 * H * 32, WGRP_IN = 2 * H * 32, WBYTES_IN = TAPS * WTAP_IN;      // bytes of one plane
     const char *xdb = reinterpret_cast<const char *>(Pl) + lrow * (RP * 2) + lk * 16;
+    const int T4 = T * 4, HT4 = (int)(HT * 4);
 
-    f32x4 racc[3][NCT];                                  // res/skip accumulators: tile 1 lanes >= 32 and tile 2 persist (skip)
+    f32x4 racc[2][NCT];                                  // res/skip accumulators: [0] residual rows, [1] skip rows — PERSISTS
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < NCT; ++c) racc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    i32x4 a[2][3][3];                                    // weight ring: [slot][row tile][plane]
+    i32x4 a[2][2][3];                                    // weight ring: [slot][row tile][plane]
     i32x4 bv[2][3];                                      // B operands: [slot][plane]
+
 
     for (int l = 0; l < p.n_layers; ++l) {
         const bool last = l == p.n_layers - 1;
@@ -176,11 +182,11 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
             const int so0 = tap * WTAP_IN + 2 * gp * WGRP_IN;
             const int so1 = so0 + WGRP_IN;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_in[pl], wvo_in[j], so0, 0));
-                    const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_in[pl], wvo_in[j], so1, 0));
+                    const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_in[pl], j ? wvo_s : wvo_t, so0, 0));
+                    const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_in[pl], j ? wvo_s : wvo_t, so1, 0));
                     a[slot][j][pl] = i32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
         };
@@ -190,25 +196,25 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
                 bv[slot][pl] = *reinterpret_cast<const i32x4 *>(xdb + pl * PLANE_B + (gp * XR + row0) * (RP * 2));
         };
 
-        // ------------------------------------------------------------------------------------------ in-conv: 30 steps of 72 MFMAs
-        f32x4 acc[3][NCT];
+        // ------------------------------------------------------------------------------------------ in-conv: 30 steps of 48 MFMAs
+        f32x4 acc[2][NCT];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         wload_in(0, 0);
         wload_in(1, 1);
+        if (l == 0) WNF_TRACE(1);
         __syncthreads();                                 // B4 of the previous layer / the prologue's stores
-        WNF_TRACE(1);
+        WNF_TRACE(2 + 6 * l);
+        if (l == 0) WNF_CYCLES(27);
         // this layer's biases (read behind B1 / B3; the previous layer's last readers are behind the barrier above)
         if (tid < 2 * H) Bi[tid] = bin[tid];
         else if (tid - 2 * H < Mrs) Br[tid - 2 * H] = brs[tid - 2 * H];
-        if (tid < Mrs - (512 - 2 * H)) Br[tid + 512 - 2 * H] = brs[tid + 512 - 2 * H];
         bfetch(0, 0, 0);
         for (int it = 0; it < GP / 2; ++it) {
 #pragma unroll
             for (int i = 0; i < 2 * TAPS; ++i) {
-                const int gp = 2 * it + i / TAPS, tap = i % TAPS;
 #pragma unroll
                 for (int cc = 0; cc < NCT; ++cc) {
                     const int q = i * NCT + cc;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int k = 0; k < 6; ++k)
                             acc[j][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -227,117 +233,97 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
                                 __builtin_bit_cast(bf16x8, bv[q & 1][product_b(3, k)]), acc[j][cc], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                (void)gp; (void)tap;
                 wload_in(it * 2 * TAPS + i + 2, i & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        WNF_TRACE(2);
+        WNF_TRACE(3 + 6 * l);
+        if (l == 0) WNF_CYCLES(28);
         __syncthreads();                                 // B1: every wave is through with the x planes
+        if (l == 1) WNF_TRACE(30);                       // (layer 1's release of B1: splits "B1 wait" from the gate phase)
+        // (Measured: letting a wave that leaves the MFMA loop early run its gate arithmetic beside the other waves' MFMAs — planes
+        //  held in registers until this barrier — is SLOWER: 385 us per stack against 300; the element-wise instructions of the
+        //  SIMD's oldest wave take issue slots from the younger waves' MFMA streams, with or without s_setprio on the loops.)
 
-        // ------------------------------------------------------------------------------------------ gate -> ts, acts, acts planes
-        {
-            const long slab2 = ((long)l * p.B + b) * 2 * HT;              // (l, b) slab of ts / drop, in elements
-            const __amdgpu_buffer_rsrc_t ts_rs = __builtin_amdgcn_make_buffer_rsrc(p.ts + slab2, 0, (int)(2 * HT * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t ac_rs = __builtin_amdgcn_make_buffer_rsrc(p.acts + slab2 / 2, 0, (int)(HT * 4), 0x00020000);
-            const __amdgpu_buffer_rsrc_t dr_rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned char *>(p.drop ? p.drop + slab2 : reinterpret_cast<const unsigned char *>(p.x)), 0,
-                p.drop ? (int)(2 * HT) : 0, 0x00020000);
-            // (laundered lane ids: the address arithmetic of this phase must not be hoisted out of the layer loop — hoisted, its
-            //  ~150 per-lane offsets were spilled to scratch in front of the first MFMA loop)
-            int lrow = lrow_, lk = lk_;
-            asm volatile("" : "+v"(lrow), "+v"(lk));
-            const int chl = 4 * (lk & 1) + 2 * (lk >> 1);                 // this lane's channel pair inside a tile's 8 channels
-            // keep bytes of EVERY frame of the compute window inside the utterance (the margins feed the next layers); a tile's 16
-            // loads are issued one tile ahead of their use
-            unsigned kt[3][NCT][2], ks[3][NCT][2];
-            auto keep_load = [&](int j) {
-#pragma unroll
-                for (int cc = 0; cc < NCT; ++cc)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int t = fs + 2 + 16 * cc + lrow;
-                        const int ot = (t >= 0 && t < T) ? (24 * wave + 8 * j + chl + e) * T + t : 0x7fffffff;
-                        kt[j][cc][e] = __builtin_amdgcn_raw_buffer_load_b8(dr_rs, ot, 0, 0);
-                        ks[j][cc][e] = __builtin_amdgcn_raw_buffer_load_b8(dr_rs, ot == 0x7fffffff ? ot : ot + (int)HT, 0, 0);
-                    }
-            };
-            if (p.drop) keep_load(0);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (p.drop && j + 1 < 3) keep_load(j + 1);
-                const int ch0 = 24 * wave + 8 * j + chl;
-                const f32x2 bt = *reinterpret_cast<const f32x2 *>(Bi + ch0), bs = *reinterpret_cast<const f32x2 *>(Bi + H + ch0);
-                const int ppos = ((ch0 >> 5) * XR) * RP + row_pos(ch0);
-#pragma unroll
-                for (int cc = 0; cc < NCT; ++cc) {
-                    const int r = 2 + 16 * cc + lrow, t = fs + r;
-                    const bool own = t >= t0 && t < t0 + NT && t < T;
-                    // lanes l < 32 keep their tanh registers 0, 1 and receive the sigmoid registers 0, 1 of lane l + 32; lanes
-                    // l >= 32 keep their sigmoid registers 2, 3 and receive the tanh registers 2, 3 of lane l - 32
-                    float pt[2], ps[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const float mine_lo = acc[j][cc][e], mine_hi = acc[j][cc][e + 2];
-                        const float send = lane < 32 ? mine_hi : mine_lo;
-                        const float got = __shfl_xor(send, 32, 64);
-                        pt[e] = lane < 32 ? mine_lo : got;
-                        ps[e] = lane < 32 ? got : mine_hi;
-                    }
-                    float th[2], sg[2], av[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        float vt = pt[e] + bt[e], vs = ps[e] + bs[e];
-                        if (p.drop) {
-                            vt = (kt[j][cc][e] & 0xffu) ? vt * p.drop_scale : 0.f;
-                            vs = (ks[j][cc][e] & 0xffu) ? vs * p.drop_scale : 0.f;
-                        }
-                        th[e] = fast_tanh(vt);
-                        sg[e] = fast_sigmoid(vs);
-                        av[e] = th[e] * sg[e];
-                        const int ot4 = own ? ((ch0 + e) * T + t) * 4 : 0x7fffffff;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(th[e]), ts_rs, ot4, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sg[e]), ts_rs, own ? ot4 + (int)(HT * 4) : 0x7fffffff, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av[e]), ac_rs, ot4, 0, 0);
-                    }
-                    unsigned o[3];
-                    split_planes2<3>(av[0], av[1], o);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        *reinterpret_cast<unsigned *>(Pl + pl * PLANE16 + ppos + r * RP) = o[pl];
-                }
-            }
-        }
-
-        // ------------------------------------------------------------------------------------------ res/skip conv: 6 steps
-        int wvo_rs[3];
-        {
-            const int r0 = 24 * wave + lrow;                                            // tile 0: residual rows
-            const int r1 = lrow < 8 ? 24 * wave + 16 + lrow : (last ? 0 : H) + 24 * wave + 16 + (lrow - 8);
-            const int r2 = (last ? 0 : H) + 24 * wave + lrow;                           // tile 2: skip rows
-            const int oob = G * Mrs * 32;
-            wvo_rs[0] = last ? oob : (r0 * 16 + lk * 4) * 2;
-            wvo_rs[1] = (last && lrow < 8) ? oob : (r1 * 16 + lk * 4) * 2;
-            wvo_rs[2] = (r2 * 16 + lk * 4) * 2;
-        }
+        const int wvo_r = last ? G * Mrs * 32 : wvo_t;                      // residual rows 16 w + lrow (none in the last layer)
+        const int wvo_k = last ? wvo_t : wvo_t + H * 32;                    // skip rows (H +) 16 w + lrow
         const int wgrp_rs = Mrs * 32;
         auto wload_rs = [&](int s, int slot) {
             s = s < GP ? s : GP - 1;                     // (beyond the last step: that step again, unused)
             const int so0 = 2 * s * wgrp_rs;
             const int so1 = so0 + wgrp_rs;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_rs[pl], wvo_rs[j], so0, 0));
-                    const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_rs[pl], wvo_rs[j], so1, 0));
+                    const i32x2 lo = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_rs[pl], j ? wvo_k : wvo_r, so0, 0));
+                    const i32x2 hi = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(wr_rs[pl], j ? wvo_k : wvo_r, so1, 0));
                     a[slot][j][pl] = i32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
         };
-        wload_rs(0, 0);
-        wload_rs(1, 1);
-        WNF_TRACE(3);
+
+        // ------------------------------------------------------------------------------------------ gate -> ts, acts, acts planes
+        // lane: channels ch .. ch + 3 (registers), frame r of every column tile.  One byte offset per column tile (out of range for
+        // frames this workgroup does not own); the register's row and the sigmoid half ride in the scalar offset.
+        {
+            int lrow = lrow_, lk = lk_;                  // (laundered: this phase's address arithmetic must not be hoisted out of
+            asm volatile("" : "+v"(lrow), "+v"(lk));     //  the layer loop and spilled in front of the first MFMA loop)
+            const long slab2 = ((long)l * p.B + b) * 2 * HT;              // (l, b) slab of ts / drop, in elements
+            const __amdgpu_buffer_rsrc_t ts_rs = __builtin_amdgcn_make_buffer_rsrc(p.ts + slab2, 0, 2 * HT4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ac_rs = __builtin_amdgcn_make_buffer_rsrc(p.acts + slab2 / 2, 0, HT4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dr_rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned char *>(p.drop ? p.drop + slab2 : reinterpret_cast<const unsigned char *>(p.x)), 0,
+                p.drop ? (int)(2 * HT) : 0, 0x00020000);
+            const int ch = cw + 4 * lk;
+            const int tl = fs + 2 + lrow;                                 // frame of column tile 0
+            const int ppos = ((ch >> 5) * XR + 2 + lrow) * RP + row_pos(ch);
+            unsigned kt[NCT][4], ks[NCT][4];
+            if (p.drop) {                                // keep bytes of EVERY frame of the window inside the utterance (the margins
+#pragma unroll                                           // feed the next layers), all 32 loads in flight before the first use
+                for (int cc = 0; cc < NCT; ++cc) {
+                    const int t = tl + 16 * cc;
+                    const int ok = (t >= 0 && t < T) ? ch * T + t : 0x7fffffff;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        kt[cc][g] = __builtin_amdgcn_raw_buffer_load_b8(dr_rs, ok, g * T, 0);
+                        ks[cc][g] = __builtin_amdgcn_raw_buffer_load_b8(dr_rs, ok, g * T + (int)HT, 0);
+                    }
+                }
+            }
+            const f32x4 bt = *reinterpret_cast<const f32x4 *>(Bi + ch), bs = *reinterpret_cast<const f32x4 *>(Bi + H + ch);
+#pragma unroll
+            for (int cc = 0; cc < NCT; ++cc) {
+                const int t = tl + 16 * cc;
+                const int vo = (t >= t0 && t < t0 + NT && t < T) ? (ch * T + t) * 4 : 0x7fffffff;
+                float av[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float vt = acc[0][cc][g] + bt[g], vs = acc[1][cc][g] + bs[g];
+                    if (p.drop) {
+                        vt = (kt[cc][g] & 0xffu) ? vt * p.drop_scale : 0.f;
+                        vs = (ks[cc][g] & 0xffu) ? vs * p.drop_scale : 0.f;
+                    }
+                    const float th = fast_tanh(vt), sg = fast_sigmoid(vs);
+                    av[g] = th * sg;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(th), ts_rs, vo, g * T4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sg), ts_rs, vo, g * T4 + HT4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av[g]), ac_rs, vo, g * T4, 0);
+                }
+                unsigned oa[3], ob[3];
+                split_planes2<3>(av[0], av[1], oa);
+                split_planes2<3>(av[2], av[3], ob);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) lds_store8(Pl + pl * PLANE16 + ppos + 16 * cc * RP, oa[pl], ob[pl]);
+            }
+            wload_rs(0, 0);                              // in flight across the barrier (issued earlier they cost the gate phase
+            wload_rs(1, 1);                              // 48 registers it does not have at three waves per SIMD)
+            lds_stores_done();
+        }
+
+        // ------------------------------------------------------------------------------------------ res/skip conv: 6 steps
+        WNF_TRACE(4 + 6 * l);
         __syncthreads();                                 // B2: the acts planes are complete
+        WNF_TRACE(5 + 6 * l);
         bfetch(0, 2, 0);
 #pragma unroll
         for (int s = 0; s < GP; ++s) {
@@ -347,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
                 if (q + 1 < GP * NCT) bfetch((q + 1) / NCT, 2 + ((q + 1) % NCT) * 16, (q + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)          // (the last layer has no residual rows: their weights read as zeros — a uniform
+                for (int j = 0; j < 2; ++j)          // (the last layer has no residual rows: their weights read as zeros — a uniform
 #pragma unroll                                        //  branch around MFMAs would keep the LDS reads from moving ahead, lesson 19)
                     for (int k = 0; k < 6; ++k)
                         racc[j][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -358,82 +344,73 @@ __global__ __launch_bounds__(512, 2) void wn_fused_kernel(WnFusedParams p) {
             wload_rs(s + 2, s & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        WNF_TRACE(4);
+        WNF_TRACE(6 + 6 * l);
         __syncthreads();                                 // B3: every wave is through with the acts planes
 
         // ------------------------------------------------------------------------------------------ residual update, skip biases
         {
-            const __amdgpu_buffer_rsrc_t xs_rs = __builtin_amdgcn_make_buffer_rsrc(
-                last ? p.skip + (long)b * HT : p.xs + ((long)l * p.B + b) * HT, 0, (int)(HT * 4), 0x00020000);
             int lrow = lrow_, lk = lk_;
             asm volatile("" : "+v"(lrow), "+v"(lk));
+            const __amdgpu_buffer_rsrc_t xs_rs = __builtin_amdgcn_make_buffer_rsrc(
+                last ? p.skip + (long)b * HT : p.xs + ((long)l * p.B + b) * HT, 0, HT4, 0x00020000);
+            const int ch = cw + 4 * lk;
+            const int tl = fs + 2 + lrow;
+            const f32x4 bk = *reinterpret_cast<const f32x4 *>(Br + (last ? 0 : H) + ch);
             if (!last) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j == 1 && lane >= 32) continue;
-                    const int ch = 24 * wave + 16 * j + 4 * lk;
-                    const f32x4 bb = *reinterpret_cast<const f32x4 *>(Br + ch);
-                    const int ppos = ((ch >> 5) * XR) * RP + row_pos(ch);
-#pragma unroll
-                    for (int cc = 0; cc < NCT; ++cc) {
-                        const int r = 2 + 16 * cc + lrow, t = fs + r;
-                        const bool own = t >= t0 && t < t0 + NT && t < T;
-                        const float m = Ms[r];
-                        f32x4 xo = *reinterpret_cast<const f32x4 *>(X32 + (r - 2) * XP + ch);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) xo[g] = (xo[g] + racc[j][cc][g] + bb[g]) * m;
-                        *reinterpret_cast<f32x4 *>(X32 + (r - 2) * XP + ch) = xo;
-                        unsigned oa[3], ob[3];
-                        split_planes2<3>(xo[0], xo[1], oa);
-                        split_planes2<3>(xo[2], xo[3], ob);
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) lds_store8(Pl + pl * PLANE16 + ppos + r * RP, oa[pl], ob[pl]);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float xv = xo[g];      // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT stored element 0 four times)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xs_rs, own ? ((ch + g) * T + t) * 4 : 0x7fffffff, 0, 0);
-                        }
-                        racc[j][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-                lds_stores_done();
-            }
-            // skip rows: tile 1 lanes >= 32 (channels 24 w + 16 + 4 (lk - 2) + reg) and tile 2 (channels 24 w + 4 lk + reg)
-#pragma unroll
-            for (int j = 1; j < 3; ++j) {
-                if (j == 1 && lane < 32) continue;
-                const int ch = j == 1 ? 24 * wave + 16 + 4 * (lk - 2) : 24 * wave + 4 * lk;
-                const f32x4 bb = *reinterpret_cast<const f32x4 *>(Br + (last ? 0 : H) + ch);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(Br + ch);
+                const int ppos = ((ch >> 5) * XR + 2 + lrow) * RP + row_pos(ch);
 #pragma unroll
                 for (int cc = 0; cc < NCT; ++cc) {
+                    const int t = tl + 16 * cc;
+                    const int vo = (t >= t0 && t < t0 + NT && t < T) ? (ch * T + t) * 4 : 0x7fffffff;
+                    const float m = Ms[2 + 16 * cc + lrow];
+                    f32x4 xo = *reinterpret_cast<const f32x4 *>(X32 + (16 * cc + lrow) * XP + ch);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) racc[j][cc][g] += bb[g];
-                    if (last) {                          // WN's final `output * x_mask` (layers.py:161-162)
-                        const int r = 2 + 16 * cc + lrow, t = fs + r;
-                        const bool own = t >= t0 && t < t0 + NT && t < T;
-                        const float m = Ms[r];
+                    for (int g = 0; g < 4; ++g) xo[g] = (xo[g] + racc[0][cc][g] + bb[g]) * m;
+                    *reinterpret_cast<f32x4 *>(X32 + (16 * cc + lrow) * XP + ch) = xo;
+                    unsigned oa[3], ob[3];
+                    split_planes2<3>(xo[0], xo[1], oa);
+                    split_planes2<3>(xo[2], xo[3], ob);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(racc[j][cc][g] * m), xs_rs,
-                                                                  own ? ((ch + g) * T + t) * 4 : 0x7fffffff, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl) lds_store8(Pl + pl * PLANE16 + ppos + 16 * cc * RP, oa[pl], ob[pl]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float xv = xo[g];          // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT stored element 0 four times)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xv), xs_rs, vo, g * T4, 0);
                     }
+                    racc[0][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) racc[1][cc][g] += bk[g];
+                }
+                lds_stores_done();
+            } else {                                     // WN's final `output * x_mask` (layers.py:161-162)
+#pragma unroll
+                for (int cc = 0; cc < NCT; ++cc) {
+                    const int t = tl + 16 * cc;
+                    const int vo = (t >= t0 && t < t0 + NT && t < T) ? (ch * T + t) * 4 : 0x7fffffff;
+                    const float m = Ms[2 + 16 * cc + lrow];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((racc[1][cc][g] + bk[g]) * m), xs_rs, vo, g * T4, 0);
                 }
             }
         }
-        WNF_TRACE(5 + (l & 1));
+        WNF_TRACE(7 + 6 * l);
         // (B4 is the barrier at the top of the next layer's in-conv)
     }
-    WNF_TRACE(10);
+    WNF_TRACE(26);
 }
 
-// on unless GLOWTTS_WN_FUSED=0 (read once) or glowtts_wn_fused(0) said otherwise
+// OFF unless GLOWTTS_WN_FUSED=1 (read once) or glowtts_wn_fused(1) said otherwise: measured at config 2 the kernel is at parity
+// with the per-layer launches (300 us per stack either way, 15.55 vs 15.56 ms per step — DESIGN.md 4i), and its 8 x B grid
+// only fills the chip when 8 B is close to a multiple of 256
 static std::atomic<int> g_wn_fused{-1};
 static std::atomic<int> g_wn_fused_launches{0};
 static bool wn_fused_enabled() {
     int v = g_wn_fused.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("GLOWTTS_WN_FUSED");
-        v = !(e && e[0] == '0');
+        v = e && e[0] == '1';
         g_wn_fused.store(v, std::memory_order_relaxed);
     }
     return v != 0;
@@ -470,7 +447,7 @@ int wn_fused_dispatch(const glowtts_wn_layer *layers, int n_layers, const float 
     static LdsLimit attr_max_e;
     if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&wn_fused_kernel), wnf::LDS_BYTES, "glowtts_wn_fwd (fused)")) return rc_;
     g_wn_fused_launches.fetch_add(1, std::memory_order_relaxed);
-    hipLaunchKernelGGL(wn_fused_kernel, dim3((unsigned)(p.ntiles * B)), dim3(512), wnf::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(wn_fused_kernel, dim3((unsigned)(p.ntiles * B)), dim3(768), wnf::LDS_BYTES, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_wn_fwd (fused)");
 }
 

@@ -88,7 +88,15 @@ class TextEncoder(nn.Module):
         enc_planes = os.environ.get("GLOWTTS_ENC_PLANES", "1") != "0"
         self._conv_groups = [convops.ConvGroup(grp, planes=enc_planes) for grp in layered if grp] + ([convops.ConvGroup(rest)] if rest else [])
 
+    # GLOWTTS_CHECK_IDS=1: verify every batch's phoneme ids lie in [0, n_vocab) before the gather (one device -> host sync per
+    # step; the reference's nn.Embedding asserts on the device, the gather kernel here clamps — ADVICE r3)
+    _check_ids = os.environ.get("GLOWTTS_CHECK_IDS", "0") == "1"
+
     def forward(self, x, x_lengths, g=None):
+        if self._check_ids and x.numel():
+            lo, hi = int(x.min()), int(x.max())
+            if lo < 0 or hi >= self.n_vocab:
+                raise RuntimeError(f"TextEncoder: phoneme id out of range: [{lo}, {hi}] not inside [0, {self.n_vocab})")
         for grp in self._conv_groups:
             grp.begin()
         # [b, h, t]: gather straight into the transposed layout, scaled; segment-sum backward (csrc/train_ops.hip); a CPU tensor

@@ -157,7 +157,10 @@ class FlatAdam(torch.optim.Optimizer):
         if missing:
             import warnings
             warnings.warn(f"FlatAdam.load_state_dict: no state for parameters {missing[:8]}{'...' if len(missing) > 8 else ''} "
-                          "(never updated when the file was written): their moments start at zero")
+                          "(never updated when the file was written): their moments start at zero.  All parameters share ONE "
+                          "device step counter here, so these parameters' bias correction continues at the file's step N — "
+                          "torch.optim.Adam would restart theirs at step 1 (their first updates are ~1 / (1 - beta1^N) times "
+                          "smaller than the reference's)")
         steps = []
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self._params, self.offsets)):

@@ -19,7 +19,7 @@
  *                                 GLOWTTS_WRW_TR3     [1]     0 = 3-tap weight gradients on the frame-packed kernel
  *                                 GLOWTTS_WRW_TR_PRIO [2]     which wave group of the 5-tap weight gradient runs at raised priority
  *                                 GLOWTTS_WRW_BATCH   [1]     0 = one weight-gradient launch per WN layer (csrc/wn_stack.hip)
- *                                 GLOWTTS_WN_FUSED    [1]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
+ *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
  *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)
@@ -229,11 +229,12 @@ int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b
  *     runs native.  The weight-gradient kernel needs no planes (both its operands are activations). */
 int glowtts_conv_math(int mode);
 
-/* The forward of a WN stack as ONE layer-resident kernel (csrc/wn_fused.hip; reference layers.py:138-162): taken by
- * glowtts_wn_fwd / glowtts_flow_block_fwd whenever it applies — fp32 tensors, no conditioning input, H = 192, 5 taps,
- * dilation 1, <= 4 layers, T % 4 == 0, arithmetic mode bf16x6 with the stack's planes bound — and otherwise, or when switched
- * off, the per-layer launch sequence runs; results agree to fp32 round-off (same six-product arithmetic, another summation
- * order).  enable: 1 / 0 sets the process-wide switch (initially on unless GLOWTTS_WN_FUSED=0), -1 only queries; returns the
+/* The forward of a WN stack as ONE layer-resident kernel (csrc/wn_fused.hip; reference layers.py:138-162): when switched on,
+ * taken by glowtts_wn_fwd / glowtts_flow_block_fwd whenever it applies — fp32 tensors, no conditioning input, H = 192, 5 taps,
+ * dilation 1, <= 4 layers, T % 4 == 0, arithmetic mode bf16x6 with the stack's planes bound — and otherwise the per-layer launch
+ * sequence runs; results agree to fp32 round-off (same six-product arithmetic, another summation order).  Initially OFF (at
+ * the benchmark's shape it is at parity with the per-layer launches) unless GLOWTTS_WN_FUSED=1.
+ * enable: 1 / 0 sets the process-wide switch, -1 only queries; returns the
  * setting in force BEFORE the call.  enable = -2 returns the number of launches of the kernel so far in this process (tests
  * use it to see that the kernel, not the fallback, ran). */
 int glowtts_wn_fused(int enable);

@@ -2,7 +2,7 @@
 """A/B of host-side switches in ONE process (boxes differ by several percent): alternating blocks of training steps.
 Usage: python tools/ab_flags.py NAME=VALUE_A,VALUE_B [steps_per_block] [blocks]
   NAME in: enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
-  whole-layer executors vs the per-operator path), io (fp32|all|hidden)"""
+  whole-layer executors vs the per-operator path), io (fp32|all|hidden), fused (0|1: layer-resident WN forward kernel)"""
 import os
 import sys
 import time
@@ -31,6 +31,9 @@ def apply(v):
         convops._WN_NATIVE = v
     elif name == "io":
         model.decoder.io_bf16 = False if v == "fp32" else v
+    elif name == "fused":                                   # layer-resident WN forward kernel (csrc/wn_fused.hip) on / off
+        from glow_tts_train import _hip
+        _hip.wn_fused(v == "1")
     elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
         global CHAIN
         CHAIN = v == "1"
