@@ -15,7 +15,7 @@
 // relative-value term); phase 2 becomes the softmax backward dS = P (dP - sum_j P dP) * keep/scale; B2 = K, E2 = E_k
 // give dQ; dS is written to HBM for the second half (attn_dkv_kernel: dV = dO Pd, dK = Q dS, contraction over
 // queries) and for the two small embedding-gradient reductions (attn_relgrad_kernel).
-// Limits: T <= 256, d_k % 16 == 0, d_k <= 128, window <= 7.
+// Limits: T <= 512 (T > 256: the LONG form below), d_k % 16 == 0, d_k <= 128, window <= 7.
 #include "common.hpp"
 
 namespace glowtts {
@@ -149,7 +149,14 @@ __device__ unsigned long long g_attn_trace[1024 * 8];
 // accumulator registers per lane instead of 64, and every loop over the strip shorter by 3/8.
 // DTC: head width / 16 when it is compiled in (6: the model's d_k = 96 — MFMA loops without a uniform branch per d tile, which
 // is what lets the compiler put a k-step's LDS reads ahead of the previous step's MFMAs), 0 = any width <= 128.
-template <int MODE, bool BF, int NT, int DTC>
+// LONG (round 4; 256 < T <= 512, NT = 32): the score strip still lives in registers (128 per lane; one wave per SIMD has 512), but
+// the probability strip no longer fits LDS (64 x 516 floats).  Phase 2 leaves its results IN the strip registers; phase 4 moves
+// them through a per-wave [16 queries][64 keys] LDS chunk, one key tile at a time (same wave writes and reads: no barrier); the
+// band P[i][i + r - w] the relative-value term needs is collected in a per-wave [16][16] table while phase 2 passes the
+// diagonal tiles; the backward (MODE 1) reads its probabilities from HBM into registers instead of an LDS strip.
+constexpr int kCP = 68;    // LDS pitch of a wave's [16][64] probability chunk (LONG)
+
+template <int MODE, bool BF, int NT, int DTC, bool LONG = false>
 __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     extern __shared__ __align__(16) float smem[];
     const int dk = DTC ? DTC * 16 : p.dk, T = p.T, w = p.w, TP = p.TP;
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     const int EP = dk + 4, E2P = dk + 16;
     float *As = smem;                         // [dk][kAP]
     float *Bs = As + dk * kAP;                // [dk][kBP]
-    float *Ps = Bs + dk * kBP;                // [64][TP]
-    float *E1s = Ps + 64 * TP;                // [16][EP]     E1[r][d]
+    float *Ps = Bs + dk * kBP;                // [64][TP]   (LONG: [4 waves][16][kCP] chunks, then [4][16][16] band tables)
+    float *E1s = Ps + (LONG ? 4 * 16 * kCP + 4 * 16 * 16 : 64 * TP);   // [16][EP]     E1[r][d]
     float *E2s = E1s + 16 * EP;               // [16][E2P]    E2[r][d]
     float *Rs = E2s + 16 * E2P;               // [4 waves][16][17]
     unsigned char *Ks = reinterpret_cast<unsigned char *>(Rs + 4 * 16 * 17);   // [64][TP] dropout keep bytes of the strip
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             }
         }
     }
-    if (MODE == 1) {
+    if (MODE == 1 && !LONG) {
         const float *pg = p.p + pbase + (long)q0 * T;
         const int ncol = ntile * 16;                       // columns the strip uses: zeros beyond T and below row nrow
         if ((T & 3) == 0 && rows16(pg)) {
@@ -378,10 +385,22 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
     const float cb_last = lastok ? 0.f : -3.0e38f;
     const int co_last = lastok ? 0 : 0x40000000;
     const int bl = p.block_len < 0 ? (1 << 20) : p.block_len;
-    float *pw = Ps + wave * 16 * TP;
+    float *pw = LONG ? Ps + wave * 16 * kCP : Ps + wave * 16 * TP;        // LONG: this wave's [16][kCP] chunk
+    float *bandw = Ps + 4 * 16 * kCP + wave * 256;                        // LONG: this wave's [16][16] band table
+    const int tqd = (q0 >> 4) + waveu;                                    // the column tile of this wave's diagonal
     const unsigned char *kw = Ks + wave * 16 * TP;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
         (MODE == 0 ? p.p : p.ds) + pbase, 0, T * T * 4, 0x00020000);
+    f32x4 Pr[(LONG && MODE == 1) ? NT : 1];                                // LONG backward: the probabilities of the strip
+    if constexpr (LONG && MODE == 1) {
+        const __amdgpu_buffer_rsrc_t pin = __builtin_amdgcn_make_buffer_rsrc(p.p + pbase, 0, T * T * 4, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                Pr[t][reg] = t < ntile ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                             pin, voff[reg] + t * 64 + (t == ntile - 1 ? co_last : 0), 0, 0)) : 0.f;
+    }
     if (MODE == 0) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -415,7 +434,15 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                     float pv = S[t][reg] * inv;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), prs, voff[reg] + t * 64 + (t == ntile - 1 ? co_last : 0), 0, 0);
                     if (has_drop) pv = kw[il * TP + t * 16 + lcol] ? pv * p.drop_scale : 0.f;
-                    pw[il * TP + t * 16 + lcol] = pv;
+                    if constexpr (LONG) {
+                        S[t][reg] = pv;
+                        if (t >= tqd - 1 && t <= tqd + 1) {               // (uniform) the band of the relative-value term
+                            const int r = t * 16 + lcol - ig[reg] + w;
+                            if ((unsigned)r <= (unsigned)(2 * w)) bandw[il * 16 + r] = pv;
+                        }
+                    } else {
+                        pw[il * TP + t * 16 + lcol] = pv;
+                    }
                 }
             }
         }
@@ -430,7 +457,8 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                     float dp = S[t][reg];
                     if (has_drop) dp = kw[il * TP + t * 16 + lcol] ? dp * p.drop_scale : 0.f;
                     S[t][reg] = dp;
-                    dot += pw[il * TP + t * 16 + lcol] * dp;           // (staged as zero beyond T in either direction)
+                    const float pr = LONG ? Pr[LONG ? t : 0][reg] : pw[il * TP + t * 16 + lcol];
+                    dot += pr * dp;                                    // (staged / loaded as zero beyond T in either direction)
                 }
             }
             dot = group16_sum(dot);
@@ -438,9 +466,18 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             for (int t = 0; t < NT; ++t) {
                 if (t < ntile) {
                     const bool keep = (mi[reg] * mkc[t] != 0.f) && (abs(t * 16 + lcol - ig[reg]) <= bl);
-                    const float dsv = keep ? pw[il * TP + t * 16 + lcol] * (S[t][reg] - dot) * p.scale : 0.f;
+                    const float pr = LONG ? Pr[LONG ? t : 0][reg] : pw[il * TP + t * 16 + lcol];
+                    const float dsv = keep ? pr * (S[t][reg] - dot) * p.scale : 0.f;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dsv), prs, voff[reg] + t * 64 + (t == ntile - 1 ? co_last : 0), 0, 0);
-                    pw[il * TP + t * 16 + lcol] = dsv;
+                    if constexpr (LONG) {
+                        S[t][reg] = dsv;
+                        if (t >= tqd - 1 && t <= tqd + 1) {
+                            const int r = t * 16 + lcol - ig[reg] + w;
+                            if ((unsigned)r <= (unsigned)(2 * w)) bandw[il * 16 + r] = dsv;
+                        }
+                    } else {
+                        pw[il * TP + t * 16 + lcol] = dsv;
+                    }
                 }
             }
         }
@@ -452,12 +489,11 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < DA; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    for (int jt = 0; jt < njt; ++jt) {
-        if (jt + 1 < njt) prefetch(B2g, (jt + 1) * 64);
+    auto pv_tile = [&](int jt, const float *arow) {              // O += P[:, 64-key tile jt] V[tile jt]^T; arow: this lane's A row
         const int jmax = min(64, ((T - jt * 64 + 15) >> 4) << 4);     // keys of this tile that exist in the P strip
         if constexpr (BF) {
             for (int kk = 0; kk < jmax; kk += 16) {
-                const bf16x4_s av = bf4_row(pw + lcol * TP + jt * 64 + kk + 4 * lk);
+                const bf16x4_s av = bf4_row(arow + kk + 4 * lk);
 #pragma unroll
                 for (int dt = 0; dt < DA; ++dt)
                     if (DTC || dt < DT) O[dt] = mma_bf16(av, bf4_row(Bs + (dt * 16 + lcol) * kBP + kk + 4 * lk), O[dt]);
@@ -465,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
         } else {
 #pragma unroll 4
             for (int kk = 0; kk < jmax; kk += 4) {
-                const float av = pw[lcol * TP + jt * 64 + kk + lk];
+                const float av = arow[kk + lk];
 #pragma unroll
                 for (int dt = 0; dt < DA; ++dt) {
                     if (DTC || dt < DT) {
@@ -475,10 +511,38 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                 }
             }
         }
-        if (jt + 1 < njt) {
-            __syncthreads();
-            commit(B2g, (jt + 1) * 64);
-            __syncthreads();
+    };
+    if constexpr (LONG) {
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            if (jt < njt) {
+                if (jt + 1 < njt) prefetch(B2g, (jt + 1) * 64);
+                // this wave's [16 queries][64 keys] piece of the strip, from its registers (the reads of the previous piece are
+                // in order before these writes: one wave, one LDS queue)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (jt * 4 + ct < NT)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) pw[(lk * 4 + reg) * kCP + ct * 16 + lcol] = S[jt * 4 + ct][reg];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                pv_tile(jt, pw + lcol * kCP);
+                if (jt + 1 < njt) {
+                    __syncthreads();
+                    commit(B2g, (jt + 1) * 64);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        for (int jt = 0; jt < njt; ++jt) {
+            if (jt + 1 < njt) prefetch(B2g, (jt + 1) * 64);
+            pv_tile(jt, pw + lcol * TP + jt * 64);
+            if (jt + 1 < njt) {
+                __syncthreads();
+                commit(B2g, (jt + 1) * 64);
+                __syncthreads();
+            }
         }
     }
     if (rel) {
@@ -488,7 +552,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int r = 4 * lk + jj, j = iq + r - w;
-                pv[jj] = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+                pv[jj] = (r <= 2 * w && j >= 0 && j < T) ? (LONG ? bandw[lcol * 16 + (r & 15)] : pw[lcol * TP + j]) : 0.f;
             }
             const bf16x4_s av = bf4(pv[0], pv[1], pv[2], pv[3]);
 #pragma unroll
@@ -498,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
             for (int kk = 0; kk < 2 * w + 1; kk += 4) {
                 const int r = kk + lk;
                 const int j = iq + r - w;
-                const float av = (r <= 2 * w && j >= 0 && j < T) ? pw[lcol * TP + j] : 0.f;
+                const float av = (r <= 2 * w && j >= 0 && j < T) ? (LONG ? bandw[lcol * 16 + (r & 15)] : pw[lcol * TP + j]) : 0.f;
 #pragma unroll
                 for (int dt = 0; dt < DA; ++dt) {
                     if (DTC || dt < DT) {
@@ -746,31 +810,34 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
 
 static int attn_check(const char *name, int B, int H, int T, int dk, int w) {
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && dk > 0, "%s: bad shape", name);
-    GLOWTTS_CHECK_ARG(T <= 256, "%s: T=%d exceeds the 256-token limit of this build", name, T);
+    GLOWTTS_CHECK_ARG(T <= 512, "%s: T=%d exceeds the 512-token limit of this build", name, T);
     GLOWTTS_CHECK_ARG(dk % 16 == 0 && dk <= 128, "%s: head width %d must be a multiple of 16 and <= 128", name, dk);
     GLOWTTS_CHECK_ARG(w <= 7, "%s: window %d > 7", name, w);
     return 0;
 }
 
-static size_t attn_lds(int dk, int TP) {
-    return ((size_t)dk * kAP + (size_t)dk * kBP + (size_t)64 * TP + (size_t)16 * (dk + 4) + (size_t)16 * (dk + 16) + 4 * 16 * 17) *
+static size_t attn_lds(int dk, int TP, bool lng) {
+    const size_t strip = lng ? (size_t)4 * 16 * kCP + 4 * 16 * 16 : (size_t)64 * TP;
+    return ((size_t)dk * kAP + (size_t)dk * kBP + strip + (size_t)16 * (dk + 4) + (size_t)16 * (dk + 16) + 4 * 16 * 17) *
                sizeof(float) + (size_t)64 * TP;        // + the keep bytes of the strip
 }
 
-template <int MODE, bool BF, int NT, int DTC>
+template <int MODE, bool BF, int NT, int DTC, bool LONG = false>
 static int attn_launch_nt(AttnParams &p, hipStream_t s) {
     p.TP = ((p.T + 15) / 16) * 16 + 4;
-    const size_t lds = attn_lds(p.dk, p.TP);
+    const size_t lds = attn_lds(p.dk, p.TP, LONG);
     GLOWTTS_CHECK_ARG(lds <= 160 * 1024, "glowtts_rel_attn: needs %zu B of LDS", lds);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE, BF, NT, DTC>), lds, "glowtts_rel_attn")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&attn_qblock_kernel<MODE, BF, NT, DTC, LONG>), lds, "glowtts_rel_attn")) return rc_;
     dim3 grid((p.T + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL((attn_qblock_kernel<MODE, BF, NT, DTC>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((attn_qblock_kernel<MODE, BF, NT, DTC, LONG>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_rel_attn");
 }
 
 template <int MODE, bool BF>
 static int attn_launch(AttnParams &p, hipStream_t s) {
+    if (p.T > 256)           // the strip in registers only (round 4): 256 < T <= 512
+        return p.dk == 96 ? attn_launch_nt<MODE, BF, 32, 6, true>(p, s) : attn_launch_nt<MODE, BF, 32, 0, true>(p, s);
     if (p.dk == 96) return p.T <= 160 ? attn_launch_nt<MODE, BF, 10, 6>(p, s) : attn_launch_nt<MODE, BF, 16, 6>(p, s);
     return p.T <= 160 ? attn_launch_nt<MODE, BF, 10, 0>(p, s) : attn_launch_nt<MODE, BF, 16, 0>(p, s);
 }

@@ -225,6 +225,9 @@ def gen_wn_gate_squeeze(R):
 ATTENTION_LONG = [
     ("mha_c192_t240_w4", 240, (240, 151), 4, None, 192),
     ("mha_c64_t256_w4", 256, (256, 199), 4, None, 64),
+    # round 4: beyond 256 tokens (the attention kernel's LONG form: 256 < T <= 512)
+    ("mha_c192_t300_w4", 300, (300, 217), 4, None, 192),
+    ("mha_c64_t512_w4", 512, (512, 399), 4, None, 64),
 ]
 
 

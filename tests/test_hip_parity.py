@@ -367,7 +367,7 @@ def test_gate_and_squeeze_golden(G):
 
 MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4",     # d_k = 8: torch path
              "mha_c32_t70_w4", "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4",     # MFMA kernel
-             "mha_c192_t240_w4", "mha_c64_t256_w4"]      # ... at config 5's text length and at the kernel's size limit
+             "mha_c192_t240_w4", "mha_c64_t256_w4", "mha_c192_t300_w4", "mha_c64_t512_w4"]      # ... at config 5's text length and at the kernel's size limit
 
 
 @pytest.mark.parametrize("name", MHA_CASES)

@@ -16,13 +16,15 @@ from oracle import glow_oracle as O
 TOL = dict(rtol=2e-5, atol=2e-5)
 
 
-def _grad_check(sd, golden, what):
+def _grad_check(sd, golden, what, atol_of_max=0.0):
+    """`atol_of_max`: extra absolute tolerance as a fraction of the gradient tensor's largest element — for sums of thousands of
+    fp32 terms (the bias gradients of the 300- and 512-token attention fixtures), whose low bits depend on the summation order."""
     gg = split_prefix(golden, "grad.")
     assert gg, "fixture holds no grads"
     for k, want in gg.items():
         got = sd[k].grad
         assert got is not None, f"{what}: no grad for {k}"
-        assert_close(got, want, what=f"{what} grad {k}", rtol=1e-4, atol=2e-5)
+        assert_close(got, want, what=f"{what} grad {k}", rtol=1e-4, atol=2e-5 + atol_of_max * float(np.abs(want).max()))
 
 
 # ------------------------------------------------------------------------------------------------ MAS
@@ -158,7 +160,7 @@ def test_coupling(name, sig, gin, k, dil):
     assert_close(x.grad, g["dx"], what="dx", rtol=1e-4, atol=2e-5)
     if gin:
         assert_close(gc.grad, g["dg"], what="dg", rtol=1e-4, atol=2e-5)
-    _grad_check({kk[2:]: v for kk, v in sd.items()}, g, name)
+    _grad_check({kk[2:]: v for kk, v in sd.items()}, g, name, atol_of_max=2e-4 if g["x"].shape[2] > 256 else 0.0)
     with torch.no_grad():
         xr, _ = O.coupling(sd, "f", z.detach(), mask, gc, hp, 16, reverse=True)
     assert_close(xr, g["x_rev"], what="x_rev", rtol=1e-4, atol=2e-5)
@@ -198,7 +200,7 @@ def test_gate_and_squeeze():
 # ------------------------------------------------------------------------------------------------ attention
 MHA_CASES = ["mha_t12_w4", "mha_t4_w4", "mha_t5_w4", "mha_t12_w4_blk3", "mha_t12_nowin", "mha_t70_w4", "mha_c32_t70_w4",
              "mha_c32_t12_w4_blk3", "mha_c32_t5_w4", "mha_c32_t40_nowin", "mha_c192_t160_w4",
-             "mha_c192_t240_w4", "mha_c64_t256_w4"]
+             "mha_c192_t240_w4", "mha_c64_t256_w4", "mha_c192_t300_w4", "mha_c64_t512_w4"]
 
 
 @pytest.mark.parametrize("name", MHA_CASES)
@@ -217,7 +219,7 @@ def test_attention(name):
     assert_close(p, g["p_attn"], what="p_attn", **TOL)
     (y * T(g["r"])).sum().backward()
     assert_close(x.grad, g["dx"], what="dx", rtol=1e-4, atol=2e-5)
-    _grad_check({kk[2:]: v for kk, v in sd.items()}, g, name)
+    _grad_check({kk[2:]: v for kk, v in sd.items()}, g, name, atol_of_max=2e-4 if g["x"].shape[2] > 256 else 0.0)
 
 
 # ------------------------------------------------------------------------------------------------ losses
