@@ -33,7 +33,8 @@ from helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 REL = 1e-3
-GRAD_TOL = 5e-3          # of the tensor's largest element (see the module docstring; tightened from the measured margins)
+GRAD_TOL = 2e-3          # of the tensor's largest element: 2x the worst measured (rounds 3-4 ran with 5e-3; the worst tensor of any
+                         # case sat at 0.21 of that — configs[4], bf16x6 — and at 0.09 at configs[1]: profiles/r04_parity_margins.json)
 MAX_ALIGN_DIFF = 5e-3    # fraction of valid frames whose aligned token may differ from the oracle's
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

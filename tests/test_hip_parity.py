@@ -833,7 +833,8 @@ def test_conv_grads_accumulate_in_place_when_grad_exists(G):
 
 
 def test_wn_dropout_path_matches_manual_mask(G):
-    """Training-mode dropout inside WN (layers.py:147): reproduce the keep-masks from the seed and check fwd + bwd."""
+    """Training-mode dropout inside WN (layers.py:147): the stack's own keep-masks (read back through ops.keep_mask_tap) applied
+    by hand to the oracle's convolutions; forward and backward agree."""
     from oracle import glow_oracle as O
 
     torch.manual_seed(3)
@@ -843,12 +844,15 @@ def test_wn_dropout_path_matches_manual_mask(G):
     mask = torch.ones(b, 1, t, device="cuda")
     mask[1, :, 30:] = 0
     r = torch.randn(b, H, t, device="cuda")
-    torch.manual_seed(99)
-    out = wn(x, mask)
+    taken = []
+    G.ops.keep_mask_tap = lambda site, m, pd: taken.append(m.clone())
+    try:
+        out = wn(x, mask)
+    finally:
+        G.ops.keep_mask_tap = None
     (out * r).sum().backward()
-    # manual: same RNG stream, same order
-    torch.manual_seed(99)
-    keeps = list(torch.empty(L, b, 2 * H, t, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p).float())  # one generator call
+    assert len(taken) == 1 and taken[0].shape == (L, b, 2 * H, t)        # one generator call for the stack
+    keeps = list(taken[0].float())
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in wn.state_dict().items()}
     xo = x.detach().cpu().clone().requires_grad_(True)
     cur, skip = xo, 0
@@ -870,33 +874,35 @@ def test_wn_dropout_path_matches_manual_mask(G):
         assert_close(named[k].grad, vref.grad, what="grad " + k, rtol=5e-4, atol=5e-4)
 
 
-def test_attention_dropout_matches_manual_mask(G):
-    """Training-mode attention dropout (attentions.py:251): same keep-mask reproduced from the seed, torch reference."""
+@pytest.mark.parametrize("t,lens", [(50, (50, 31, 7)), (300, (300, 211, 64))], ids=["t50", "t300-long-form"])
+def test_attention_dropout_matches_manual_mask(G, t, lens):
+    """Training-mode attention dropout (attentions.py:251): the kernel's keep-mask read back (ops.keep_mask_tap) and handed to the
+    index-based torch composition (ops.keep_mask_inject) — outputs and every gradient agree."""
     torch.manual_seed(5)
-    ch, t, b, p = 64, 50, 3, 0.25
+    ch, b, p = 64, 3, 0.25
     f = G.attentions.MultiHeadAttention(ch, ch, 2, window_size=4, p_dropout=p).cuda().train()
     x = torch.randn(b, ch, t, device="cuda", requires_grad=True)
-    lens = torch.tensor([50, 31, 7], device="cuda")
+    lens = torch.tensor(lens, device="cuda")
     mask = (torch.arange(t, device="cuda")[None, :] < lens[:, None]).float().unsqueeze(1)
     pair = mask.unsqueeze(2) * mask.unsqueeze(-1)
     r = torch.randn(b, ch, t, device="cuda")
-    torch.manual_seed(77)
-    y = f(x, x, pair)
+    taken = []
+    G.ops.keep_mask_tap = lambda site, m, pd: taken.append((site, m.clone(), pd))
+    try:
+        y = f(x, x, pair)
+    finally:
+        G.ops.keep_mask_tap = None
+    assert len(taken) == 1 and taken[0][1].shape == (b, 2, t, t) and taken[0][2] == p
     (y * r).sum().backward()
     got = [x.grad.clone()] + [p_.grad.clone() for p_ in f.parameters()]
-    # reference: the general torch path with nn.Dropout replaced by the same keep mask
-    torch.manual_seed(77)
-    keep = torch.empty(b, 2, t, t, device="cuda", dtype=torch.uint8).bernoulli_(1.0 - p).float() / (1 - p)
     x.grad = None
     f.zero_grad()
-
-    class FixedDrop(torch.nn.Module):
-        def forward(self, pa):
-            return pa * keep
-
-    f.drop = FixedDrop()
-    q, k, v = f.conv_q(x), f.conv_k(x), f.conv_v(x)
-    o, _ = f._attention_general(q, k, v, pair)
+    G.ops.keep_mask_inject = lambda site, shape, pd: taken[0][1]
+    try:
+        q, k, v = f.conv_q(x), f.conv_k(x), f.conv_v(x)
+        o, _ = f._attention_general(q, k, v, pair)
+    finally:
+        G.ops.keep_mask_inject = None
     y2 = f.conv_o(o)
     (y2 * r).sum().backward()
     want = [x.grad] + [p_.grad for p_ in f.parameters()]
@@ -906,7 +912,9 @@ def test_attention_dropout_matches_manual_mask(G):
 
 
 @pytest.mark.parametrize("t,ch,win,blk", [(160, 192, 4, None), (256, 64, 7, None), (200, 32, 4, 20), (33, 256, 2, None),
-                                          (240, 192, 4, None), (256, 192, 7, None)])      # config 5 / the T limit at H=192
+                                          (240, 192, 4, None), (256, 192, 7, None),      # config 5 / the short form's limit
+                                          (257, 192, 4, None), (300, 192, 7, 30), (384, 64, 4, None), (500, 32, 2, None),
+                                          (512, 192, 7, None)])                          # the LONG form: 256 < T <= 512
 def test_attention_kernel_vs_general_path(G, t, ch, win, blk):
     torch.manual_seed(t)
     b = 2
@@ -1148,22 +1156,21 @@ def _torch_encoder(enc, x, x_mask, keep, p):
     pair = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     ln = lambda v, n: F.layer_norm(v.transpose(1, 2), (hch,), n.gamma, n.beta, n.eps).transpose(1, 2)      # noqa: E731
     for attn, n1, ffn, n2 in zip(enc.attn_layers, enc.norm_layers_1, enc.ffn_layers, enc.norm_layers_2):
+        from glow_tts_train import ops as _ops
+
         ks = []
+        raw_attn = None if keep is None else keep[pos: pos + sizes[0]].view(b, nh, t, t).contiguous()
         for n, shape in zip(sizes, [(b, nh, t, t), (b, hch, t), (b, enc.filter_channels, t), (b, hch, t)]):
             ks.append(None if keep is None else keep[pos: pos + n].view(shape).float() * scale)
             pos += n
         x = x * x_mask
         q, k, v = (F.conv1d(x, c.weight, c.bias) for c in (attn.conv_q, attn.conv_k, attn.conv_v))
-        class _Keep(torch.nn.Module):
-            def forward(self, pr, _k=ks[0]):
-                return pr if _k is None else pr * _k
-
-        old = attn.drop
-        attn.drop = _Keep()
+        # the general path draws its p_attn keep-mask through ops.keep_mask: hand it the executor's decisions
+        _ops.keep_mask_inject = (lambda site, shape, pd, _m=raw_attn: _m) if raw_attn is not None else None
         try:
             y, _ = attn._attention_general(q, k, v, pair)
         finally:
-            attn.drop = old
+            _ops.keep_mask_inject = None
         y = F.conv1d(y, attn.conv_o.weight, attn.conv_o.bias)
         x = ln(x + (y if ks[1] is None else y * ks[1]), n1)
         pad = ffn.kernel_size // 2
