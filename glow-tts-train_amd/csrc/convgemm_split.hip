@@ -653,6 +653,109 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
     };
 
     GLOWTTS_TRACE_POINT_Z(0);
+    // ---- round 4: the 1x1 weight gradient, software-pipelined -------------------------------------------------------------
+    // What bounded this kernel (tools/trace_conv.py wrw1: 26.6 us per launch, MFMA pipe 28 % busy): per 80-frame chunk a
+    // workgroup spent 1.9 us in its 72 MFMAs per wave and then 1.2 us — behind a barrier, pipe idle — splitting the NEXT chunk's
+    // fp32 values into bf16 planes (~235 vector instructions per wave).  Here the split of chunk c + 1 is cut into 11 units
+    // (6 of the x rows a lane owns, 5 of the d rows it stages) that are placed BETWEEN the MFMA groups of chunk c: a group of 6
+    // MFMAs occupies the matrix pipe for 96 cycles, one unit issues in ~90.  The planes wait in registers; behind the barrier only
+    // the 15 LDS stores per thread remain.  The loads of chunk c + 2 are issued once the units have consumed chunk c + 1's
+    // registers.  B operands are fetched per 16-row tile (24 registers instead of 96) to make room.  Same arithmetic, same order.
+    if constexpr (AG) {
+        if (!masked && p.ds_pitch == 0) {                    // (ds_pitch: unused by this kernel otherwise — 1 = GLOWTTS_WRW1_PIPE=0, A/B switch)
+            constexpr int NU = 2 * NSTEP + ND;               // split units per chunk
+            static_assert(NU <= NSTEP * MT, "one unit per MFMA group");
+            int apl_n[NSTEP][NS][4];
+            unsigned dpl[ND][NS][2];
+            auto unit = [&](int u) {
+                if (u < 2 * NSTEP) {
+                    const int g = u >> 1, h = u & 1;
+                    const f32x4 v = araw[g][h];
+                    unsigned o01[NS], o23[NS];
+                    split_planes2<NS>(v[0], v[1], o01);
+                    split_planes2<NS>(v[2], v[3], o23);
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) { apl_n[g][pl][2 * h] = (int)o01[pl]; apl_n[g][pl][2 * h + 1] = (int)o23[pl]; }
+                } else if (u - 2 * NSTEP < ND) {
+                    const int i = u - 2 * NSTEP;
+                    const f32x4 v = dreg[i];
+                    if (do_bias && tid + i * 256 < D4) bsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                    unsigned o01[NS], o23[NS];
+                    split_planes2<NS>(v[0], v[1], o01);
+                    split_planes2<NS>(v[2], v[3], o23);
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl) { dpl[i][pl][0] = o01[pl]; dpl[i][pl][1] = o23[pl]; }
+                }
+            };
+            auto commit_planes = [&]() {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    const int idx = tid + i * 256;
+                    const int q = idx % (CT / 4), r = idx / (CT / 4);
+                    if (idx < D4)
+#pragma unroll
+                        for (int pl = 0; pl < NS; ++pl) lds_store8(Dh + pl * DPLANE + r * DP16 + q * 4, (int)dpl[i][pl][0], (int)dpl[i][pl][1]);
+                }
+#pragma unroll
+                for (int g = 0; g < NSTEP; ++g)
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) apl[g][pl][e] = apl_n[g][pl][e];
+            };
+            if (nchunks > 0) {
+                load_chunk(0);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) unit(u);
+                commit_planes();
+                if (nchunks > 1) load_chunk(1);
+            }
+            lds_stores_done();
+            __syncthreads();
+            GLOWTTS_TRACE_POINT_Z(1);
+            for (int c = 0; c < nchunks; ++c) {
+                const bool more = c + 1 < nchunks;
+                i32x4 bt[2][NS];
+                auto fetch_t = [&](int q, int sl) {          // q = g * MT + i
+                    const int g = q / MT, i = q - g * MT;
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl)
+                        bt[sl][pl] = *reinterpret_cast<const i32x4 *>(db_ + pl * DPLANE + i * 16 * DP16 + g * 32);
+                };
+                fetch_t(0, 0);
+#pragma unroll
+                for (int q = 0; q < NSTEP * MT; ++q) {
+                    const int g = q / MT, i = q - g * MT;
+                    if (q + 1 < NSTEP * MT) fetch_t(q + 1, (q + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    i32x4 av[NS];
+#pragma unroll
+                    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) av[pl][e] = apl[g][pl][e];
+#pragma unroll
+                    for (int k = 0; k < n_products(NS); ++k)
+                        acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, av[product_a(NS, k)]),
+                            __builtin_bit_cast(bf16x8, bt[q & 1][product_b(NS, k)]), acc[0][i], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // one split unit of the NEXT chunk behind each MFMA group but the first (its loads were issued a barrier ago)
+                    if (more && q >= 1 && q - 1 < NU) unit(q - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c + 2 < nchunks) load_chunk(c + 2);      // the units have consumed chunk c + 1's registers
+                if (c == 0) GLOWTTS_TRACE_POINT_Z(2);
+                __syncthreads();                             // every wave is through with this chunk's d image
+                if (more) {
+                    commit_planes();
+                    lds_stores_done();
+                    __syncthreads();
+                }
+                if (c == 0) GLOWTTS_TRACE_POINT_Z(3);
+            }
+            goto wrw_epilogue;
+        }
+    }
     if (nchunks > 0) {
         load_chunk(0);
         store_chunk();
@@ -675,6 +778,7 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
         }
         if (c == 0) GLOWTTS_TRACE_POINT_Z(3);
     }
+wrw_epilogue:
     GLOWTTS_TRACE_POINT_Z(4);
     if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
         float *base = p.dwp + (long)(k0 + wave * 16 + lk * 4) * p.M + m0 + lrow;
@@ -828,6 +932,8 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
+    static const int no_pipe = [] { const char *e = std::getenv("GLOWTTS_WRW1_PIPE"); return (e && e[0] == '0') ? 1 : 0; }();
+    p.ds_pitch = no_pipe;                           // 1x1 kernel: 1 = the unpipelined loop (tuning / A-B switch)
     dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");
