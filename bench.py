@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                      frac_algorithmic = algorithmic FLOPs (2*M*K*taps*columns) / t / 2.5 PFLOP/s dense bf16 peak,
                      frac_pipe        = 6 x that (the MFMA work the pipe really does) = `frac`,
                      mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed PMC
-                                        pass (profiles/r03_pmc.json), null when no pass exists for the kernel;
+                                        pass (profiles/r04_pmc.json), null when no pass exists for the kernel;
                    with GLOWTTS_CONV_MATH=fp32 the peak is the 157.3 TFLOP/s dense fp32 MFMA figure and all three coincide.
                    "as_launched_in_the_step": the same kernel timed as the step launches it — the four layers' problems of a WN
                    stack in one glowtts_conv_wrw_batch launch — microseconds per problem and the pipe fraction that gives
@@ -131,7 +131,7 @@ _PMC_KERNEL = {
 
 def pmc_entry(kernel_tag, math="bf16x6+wrw"):
     """The committed rocprofv3 PMC record of `kernel_tag` (FETCH_SIZE / WRITE_SIZE / MFMA-busy cannot be collected from inside
-    this process): profiles/r03_pmc.json, else r02 — tools/pmc_passes.sh over this same bench command, one counter group per
+    this process): profiles/r04_pmc.json, else r03 / r02 — tools/pmc_passes.sh over this same bench command, one counter group per
     run, combined per kernel (matched by name; the grid size is part of the key) by tools/pmc_combine.py as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950).  {} when no measurement exists."""
     here = os.path.dirname(os.path.abspath(__file__))
@@ -139,7 +139,7 @@ def pmc_entry(kernel_tag, math="bf16x6+wrw"):
     if key is None:
         return {}
     name = key.split(" grid=")[0]
-    for fn in ("r03_pmc.json", "r02_pmc.json"):
+    for fn in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             table = json.load(open(os.path.join(here, "profiles", fn)))
         except Exception:

@@ -932,8 +932,8 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
-    static const int no_pipe = [] { const char *e = std::getenv("GLOWTTS_WRW1_PIPE"); return (e && e[0] == '0') ? 1 : 0; }();
-    p.ds_pitch = no_pipe;                           // 1x1 kernel: 1 = the unpipelined loop (tuning / A-B switch)
+    const char *e_pipe = std::getenv("GLOWTTS_WRW1_PIPE");        // (read per launch: tools/ab_flags.py flips it between blocks of steps)
+    p.ds_pitch = (e_pipe && e_pipe[0] == '0') ? 1 : 0;             // 1x1 kernel: 1 = the unpipelined loop (tuning / A-B switch)
     dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");

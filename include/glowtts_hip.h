@@ -20,7 +20,7 @@
  *                                 GLOWTTS_WRW_TR_PRIO [2]     which wave group of the 5-tap weight gradient runs at raised priority
  *                                 GLOWTTS_WRW_BATCH   [1]     0 = one weight-gradient launch per WN layer (csrc/wn_stack.hip)
  *                                 GLOWTTS_WRW1_PIPE   [1]     0 = 1x1 weight gradient without the software-pipelined plane split
- *                                                     (csrc/convgemm_split.hip)
+ *                                                     (csrc/convgemm_split.hip; this one is read at every launch)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);

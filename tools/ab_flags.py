@@ -34,6 +34,8 @@ def apply(v):
     elif name == "fused":                                   # layer-resident WN forward kernel (csrc/wn_fused.hip) on / off
         from glow_tts_train import _hip
         _hip.wn_fused(v == "1")
+    elif name == "wrw1pipe":                                # software-pipelined 1x1 weight gradient (csrc/convgemm_split.hip) on / off
+        os.environ["GLOWTTS_WRW1_PIPE"] = v
     elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
         global CHAIN
         CHAIN = v == "1"

@@ -59,6 +59,6 @@ print(f"layer 1: wait at B1 {np.median(us(30) - us(3 + 6)):.2f} us, gate phase (
 cyc = (tr[:, 28] - tr[:, 27]).astype(np.float64)
 wall = (tr[:, 3] - tr[:, 2]).astype(np.float64) / 100.0
 print(f"shader clock inside layer 0's in-conv loop: median {np.median(cyc / wall):.0f} cycles/us; loop = {np.median(cyc):.0f} cycles "
-      f"for {30 * 72} MFMAs per wave ({np.median(cyc) / (30 * 72 * 2):.1f} cycles per MFMA per SIMD with two waves per SIMD)")
+      f"for {30 * 48} MFMAs of wave 0 (the oldest of its SIMD's three waves; the SIMD's 4 320 MFMAs end at the B1 release)")
 xcc = tr[:, 29] & 7
 print("workgroups per XCC:", np.bincount(xcc, minlength=8).tolist())
