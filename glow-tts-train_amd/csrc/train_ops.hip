@@ -440,16 +440,30 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long *__restrict__
                                                         float *__restrict__ dw, int B, int T, int H) {
     constexpr int CH = 2048;
     __shared__ int pos[CH];
-    __shared__ int count;
+    __shared__ int wcount[4];
     const int v = blockIdx.x, n = B * T;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};                     // h = tid, tid + 256, ... (H <= 1024)
     for (int c0 = 0; c0 < n; c0 += CH) {
-        if (threadIdx.x == 0) count = 0;
-        __syncthreads();
-        for (int i = c0 + threadIdx.x; i < min(n, c0 + CH); i += 256)
-            if (ids[i] == v) pos[atomicAdd(&count, 1)] = i;
-        __syncthreads();
-        const int m = count;
+        // order-preserving compaction of the positions that hold token v (an LDS atomicAdd here made the summation
+        // order — and with it the last bits of emb.weight.grad — vary from run to run): ballot + prefix inside a wave, wave
+        // counts through LDS, 256 positions per round
+        int m = 0;
+        for (int r0 = c0; r0 < min(n, c0 + CH); r0 += 256) {
+            const int i = r0 + threadIdx.x;
+            const bool hit = i < n && ids[i] == v;
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int base = m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < wave) base += wcount[q];
+                m += wcount[q];
+            }
+            if (hit) pos[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            __syncthreads();
+        }
         for (int j = 0; j < m; ++j) {
             const int i = pos[j], b = i / T, t = i - b * T;
 #pragma unroll

@@ -1023,6 +1023,20 @@ def test_embedding_kernels_vs_torch(G):
     (ref * r).sum().backward()
     assert torch.equal(out, ref.contiguous())
     assert_close(w.grad, w2.grad, what="dweight", rtol=1e-5, atol=1e-4)
+    # the segment sum walks a token's positions in ascending order whatever the scheduling: bit-identical from run to run,
+    # also at the benchmark's size (32 x 160 positions = three 2 048-position chunks per vocabulary entry)
+    for (b_, t_) in ((B, T), (32, 160)):
+        ids_ = torch.randint(0, V, (b_, t_), device="cuda")
+        r_ = torch.randn(b_, H, t_, device="cuda")
+        grads = []
+        for _ in range(3):
+            w3 = w.detach().clone().requires_grad_(True)
+            (convops.EmbedFn.apply(ids_, w3, scale) * r_).sum().backward()
+            grads.append(w3.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        w4 = w.detach().clone().requires_grad_(True)
+        ((torch.nn.functional.embedding(ids_, w4) * scale).transpose(1, 2) * r_).sum().backward()
+        assert_close(grads[0], w4.grad, what="dweight", rtol=1e-5, atol=2e-4)
     # the model's encoder uses it: one launch, no (B, T, H) tensor
     enc = G.models.TextEncoder(V, 80, 192, 768, 256, 2, 1, 3, 0.0, window_size=4, mean_only=True, prenet=True).cuda()
     xl = torch.full((B,), T, device="cuda")
