@@ -28,8 +28,13 @@ def _ones_mask(x: torch.Tensor) -> torch.Tensor:
 class LayerNorm(nn.Module):
     """Normalisation over the CHANNEL axis of (B, C, T) with eps 1e-4 (reference layers.py:10-28)."""
 
+    MAX_CHANNELS = 768          # csrc/norm.hip keeps a frame's channel column in registers (the reference has no limit)
+
     def __init__(self, channels, eps=1e-4):
         super().__init__()
+        if channels > self.MAX_CHANNELS:
+            raise ValueError(f"LayerNorm: {channels} channels exceed the {self.MAX_CHANNELS} the register-resident kernels of this "
+                             "build take (hidden_channels / filter_channels_dp)")
         self.channels, self.eps = channels, eps
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
