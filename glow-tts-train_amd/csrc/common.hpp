@@ -152,4 +152,8 @@ struct LdsLimit {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// A tuning knob read from the environment on EVERY call (tools/ab_flags.py flips such knobs between blocks of steps inside one
+// process): only for launch-geometry experiments; a knob that ships is latched once (include/glowtts_hip.h lists them).
+int env_knob(const char *name, int dflt);
+
 }  // namespace glowtts

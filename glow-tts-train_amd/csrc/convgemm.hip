@@ -894,7 +894,7 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
         const int rows_per = big ? 128 : 64;
         const long wg5 = (long)((p.T + 79) / 80) * p.B * ((p.M + rows_per - 1) / rows_per);
         const int t32 = ((p.T + 31) / 32) * 32;
-        use32 = wg5 < 440 && t32 * 10 <= p.T * 11;
+        use32 = wg5 < env_knob("GLOWTTS_CONV32_WG", 440) && t32 * 10 <= p.T * 11;
     }
     if (int rc = conv_split_dispatch(p, EPI, big, use32 ? 2 : (n5 ? 5 : 4), pipe_ok, s); rc >= 0) return rc;   // bf16-plane arithmetic
     if (use32) {

@@ -500,6 +500,13 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + G::MR - 1) / G::MR);
     const int total = p.B * ((p.T + G::CF - 1) / G::CF);
     int splits = compute_units() / tiles;               // ONE workgroup (8 waves) per CU, one round
+    // A batch of nbatch problems shares the compute units: ONE round of workgroups for the whole batch (4 problems x 18 tiles x 3
+    // splits = 216 workgroups of 75 items each at config 2) instead of one round per problem (4 x 252 workgroups of 16 items):
+    // nbatch times fewer prologues, group reductions and split-K atomics per problem (82 KB per workgroup: 20.7 -> 4.4 MB per
+    // problem) for 16 % of the compute units left to the other streams; 15.08 -> 14.98 ms per step (tools/ab_flags.py
+    // envs=GLOWTTS_WRW5_BSPLIT:0,GLOWTTS_WRW5_BSPLIT:1; two launches of two problems x 7 splits: 15.01).  Read at every launch.
+    if (p.nbatch > 1 && env_knob("GLOWTTS_WRW5_BSPLIT", 1) == 1 && compute_units() >= tiles * p.nbatch)
+        splits = compute_units() / (tiles * p.nbatch);
     if (splits > (total + 1) / 2) splits = (total + 1) / 2;      // a workgroup wants an item for each of its two groups
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;

@@ -1,5 +1,6 @@
 // error.hip — last-error text + ABI version for libglowtts_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -11,6 +12,11 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int env_knob(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
 }
 }  // namespace glowtts
 

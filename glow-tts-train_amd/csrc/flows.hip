@@ -291,6 +291,131 @@ __global__ __launch_bounds__(256) void invconv_bwd_kernel(const float *__restric
     }
 }
 
+// ---- any even n_split (reference layers.py:227 asserts nothing more): run-time N forms for N other than 2 / 4 / 8 ----------
+// The register-resident kernels above are instantiated for the group sizes Glow-TTS configurations use; an InvConvNear with
+// n_split = 6, 10, 16, ... (C % n_split == 0, N <= 32) runs here: one thread per OUTPUT row of a group (its N inputs are read
+// through L1 by the N threads of the group), the matrix in LDS; the matrix gradient by one workgroup per (o, k) entry.
+constexpr int kInvConvMaxN = 32;
+
+__device__ __forceinline__ int invconv_channel_rt(int k, int g, int C, int N) {
+    return (k / (N / 2)) * (C / 2) + g * (N / 2) + (k % (N / 2));
+}
+
+// Gauss-Jordan with partial pivoting in LDS, fp64; thread r owns row r
+__global__ __launch_bounds__(64) void invconv_prepare_generic_kernel(const float *__restrict__ w, float *__restrict__ w_inv,
+                                                                     float *__restrict__ logdet_w, int n) {
+    __shared__ double a[kInvConvMaxN][kInvConvMaxN + 1], inv[kInvConvMaxN][kInvConvMaxN + 1];
+    __shared__ int piv_row;
+    __shared__ double logabs;
+    __shared__ int neg;
+    const int r = threadIdx.x;
+    if (r < n)
+        for (int c = 0; c < n; ++c) { a[r][c] = (double)w[r * n + c]; inv[r][c] = r == c ? 1.0 : 0.0; }
+    if (r == 0) { logabs = 0.0; neg = 0; }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        if (r == 0) {
+            int p = k;
+            double best = fabs(a[k][k]);
+            for (int q = k + 1; q < n; ++q)
+                if (fabs(a[q][k]) > best) { best = fabs(a[q][k]); p = q; }
+            piv_row = p;
+        }
+        __syncthreads();
+        const int p = piv_row;
+        if (p != k && r < n) {                       // thread r swaps COLUMN r of rows k and p
+            const double t0 = a[k][r]; a[k][r] = a[p][r]; a[p][r] = t0;
+            const double t1 = inv[k][r]; inv[k][r] = inv[p][r]; inv[p][r] = t1;
+        }
+        __syncthreads();
+        const double piv = a[k][k];
+        if (r == 0) {
+            logabs += log(fabs(piv));
+            if (piv < 0.0) neg ^= 1;
+            if (p != k) neg ^= 1;
+        }
+        __syncthreads();
+        if (r < n) { a[k][r] /= piv; inv[k][r] /= piv; }      // thread r: column r of the pivot row (a[k][k] read above)
+        __syncthreads();
+        if (r < n && r != k) {
+            const double f = a[r][k];
+            for (int c = 0; c < n; ++c) { a[r][c] -= f * a[k][c]; inv[r][c] -= f * inv[k][c]; }
+        }
+        __syncthreads();
+    }
+    if (r < n)
+        for (int c = 0; c < n; ++c) w_inv[r * n + c] = (float)inv[r][c];
+    if (r == 0) logdet_w[0] = neg ? __builtin_nanf("") : (float)logabs;
+}
+
+// TRANSPOSED = false: z[o] = mask * sum_k W[o][k] x[k] ; TRANSPOSED = true (the input gradient): dx[k] = sum_o W[o][k] (dz[o] mask)
+template <int V, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void invconv_mix_generic_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                                  const float *__restrict__ w, const float *__restrict__ logdet_w,
+                                                                  const float *__restrict__ x_len, float *__restrict__ z,
+                                                                  float *__restrict__ logdet, int B, int C, int T, int N) {
+    __shared__ float ws[kInvConvMaxN * kInvConvMaxN];
+    for (int q = threadIdx.x; q < N * N; q += 256) ws[q] = w[q];
+    __syncthreads();
+    const int TV = T / V, G = C / N;
+    const long n = (long)B * G * N * TV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int tv = (int)(i % TV);
+        long rest = i / TV;
+        const int o = (int)(rest % N);
+        rest /= N;
+        const int g = (int)(rest % G), b = (int)(rest / G);
+        const Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> acc = Vec<V>::zero();
+        for (int k = 0; k < N; ++k) {
+            const Vec<V> xv = Vec<V>::load(x + ((long)b * C + invconv_channel_rt(k, g, C, N)) * T + (long)tv * V);
+            const float wk = TRANSPOSED ? ws[k * N + o] : ws[o * N + k];
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += wk * (TRANSPOSED ? xv[j] * mv[j] : xv[j]);
+        }
+        if (!TRANSPOSED)
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] *= mv[j];
+        acc.store(z + ((long)b * C + invconv_channel_rt(o, g, C, N)) * T + (long)tv * V);
+    }
+    if (logdet != nullptr && blockIdx.x == 0) {
+        const float ld = logdet_w[0] * (float)(C / N);
+        for (int b = threadIdx.x; b < B; b += 256) logdet[b] = ld * x_len[b];
+    }
+}
+
+// dW[o][k] += sum_{b, g, t} (dz[o] mask) x[k]  (+ the log-det term): one workgroup per entry
+template <int V>
+__global__ __launch_bounds__(256) void invconv_dw_generic_kernel(const float *__restrict__ x, const float *__restrict__ mask,
+                                                                 const float *__restrict__ w_inv, const float *__restrict__ dz,
+                                                                 const float *__restrict__ dlogdet, const float *__restrict__ x_len,
+                                                                 float *__restrict__ dw, int B, int C, int T, int N) {
+    __shared__ float red[4];
+    const int o = blockIdx.x / N, k = blockIdx.x % N;
+    const int TV = T / V, G = C / N;
+    const long n = (long)B * G * TV;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const int tv = (int)(i % TV);
+        const long bg = i / TV;
+        const int g = (int)(bg % G), b = (int)(bg / G);
+        const Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        const Vec<V> gz = Vec<V>::load(dz + ((long)b * C + invconv_channel_rt(o, g, C, N)) * T + (long)tv * V);
+        const Vec<V> xv = Vec<V>::load(x + ((long)b * C + invconv_channel_rt(k, g, C, N)) * T + (long)tv * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc += gz[j] * mv[j] * xv[j];
+    }
+    float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) {
+        if (dlogdet != nullptr) {
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += dlogdet[b] * x_len[b];
+            s += w_inv[k * N + o] * (float)(C / N) * t;  // d logdet(W) / dW = W^-T
+        }
+        atomicAdd(dw + o * N + k, s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // ActNorm + InvConvNear fused (consecutive flows 3i, 3i+1 of every block, models.py:176-179): one pass over the tensor
 //   fwd : y = (bias + exp(logs) x) mask ; z = (W y) mask ; logdet[b] = (sum(logs) + logdet_w * C/n) * x_len[b]
@@ -669,8 +794,11 @@ extern "C" int glowtts_actnorm_stats(const float *x, const float *mask, float *s
 
 extern "C" int glowtts_invconv_prepare(const float *w, float *w_inv, float *logdet_w, int n, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(w && w_inv && logdet_w, "glowtts_invconv_prepare: null pointer");
-    GLOWTTS_CHECK_ARG(n >= 1 && n <= 8, "glowtts_invconv_prepare: n_split=%d not in [1,8]", n);
-    hipLaunchKernelGGL(invconv_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
+    GLOWTTS_CHECK_ARG(n >= 1 && n <= kInvConvMaxN, "glowtts_invconv_prepare: n_split=%d not in [1,%d]", n, kInvConvMaxN);
+    if (n <= 8)
+        hipLaunchKernelGGL(invconv_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
+    else
+        hipLaunchKernelGGL(invconv_prepare_generic_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
     GLOWTTS_LAUNCH_CHECK("glowtts_invconv_prepare");
 }
 
@@ -692,12 +820,21 @@ extern "C" int glowtts_invconv_fwd(const float *x, const float *mask, const floa
                                    const float *x_len, float *z, float *logdet, int B, int C, int T, int n_split,
                                    glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && mask && w && z, "glowtts_invconv_fwd: null pointer");
-    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4 || n_split == 8, "glowtts_invconv_fwd: n_split=%d (supported: 2, 4, 8)", n_split);
+    GLOWTTS_CHECK_ARG(n_split >= 2 && n_split % 2 == 0 && n_split <= kInvConvMaxN,
+                      "glowtts_invconv_fwd: n_split=%d (supported: even values up to %d)", n_split, kInvConvMaxN);
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_invconv_fwd: C=%d not divisible by n_split=%d", C, n_split);
     GLOWTTS_CHECK_ARG(!logdet || (logdet_w && x_len), "glowtts_invconv_fwd: logdet requested without logdet_w/x_len");
     if ((long)B * C * T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool v4 = can_vec4(T, {x, mask, z});
+    if (n_split != 2 && n_split != 4 && n_split != 8) {          // run-time N form
+        const long items = (long)B * C * (v4 ? T / 4 : T);
+        int gg = cdiv(items, 256);
+        if (gg > 4096) gg = 4096;
+        if (v4) hipLaunchKernelGGL((invconv_mix_generic_kernel<4, false>), dim3(gg), dim3(256), 0, s, x, mask, w, logdet_w, x_len, z, logdet, B, C, T, n_split);
+        else    hipLaunchKernelGGL((invconv_mix_generic_kernel<1, false>), dim3(gg), dim3(256), 0, s, x, mask, w, logdet_w, x_len, z, logdet, B, C, T, n_split);
+        GLOWTTS_LAUNCH_CHECK("glowtts_invconv_fwd");
+    }
     const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
     dim3 grid(cdiv(n, 256));
     INVCONV_DISPATCH(invconv_fwd_kernel, grid, x, mask, w, logdet_w, x_len, z, logdet, B, C, T);
@@ -708,12 +845,27 @@ extern "C" int glowtts_invconv_bwd(const float *x, const float *mask, const floa
                                    const float *dz, const float *dlogdet, const float *x_len, float *dx, float *dw,
                                    int B, int C, int T, int n_split, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(x && mask && w && dz && dx && dw, "glowtts_invconv_bwd: null pointer");
-    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4 || n_split == 8, "glowtts_invconv_bwd: n_split=%d (supported: 2, 4, 8)", n_split);
+    GLOWTTS_CHECK_ARG(n_split >= 2 && n_split % 2 == 0 && n_split <= kInvConvMaxN,
+                      "glowtts_invconv_bwd: n_split=%d (supported: even values up to %d)", n_split, kInvConvMaxN);
     GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0, "glowtts_invconv_bwd: bad shape");
     GLOWTTS_CHECK_ARG(!dlogdet || (w_inv && x_len), "glowtts_invconv_bwd: dlogdet given without w_inv/x_len");
     if ((long)B * C * T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool v4 = can_vec4(T, {x, mask, dz, dx});
+    if (n_split != 2 && n_split != 4 && n_split != 8) {          // run-time N form: dx = W^T (dz mask), then dW entry by entry
+        const long items = (long)B * C * (v4 ? T / 4 : T);
+        int gg = cdiv(items, 256);
+        if (gg > 4096) gg = 4096;
+        const dim3 gw(n_split * n_split);
+        if (v4) {
+            hipLaunchKernelGGL((invconv_mix_generic_kernel<4, true>), dim3(gg), dim3(256), 0, s, dz, mask, w, nullptr, nullptr, dx, nullptr, B, C, T, n_split);
+            hipLaunchKernelGGL((invconv_dw_generic_kernel<4>), gw, dim3(256), 0, s, x, mask, w_inv, dz, dlogdet, x_len, dw, B, C, T, n_split);
+        } else {
+            hipLaunchKernelGGL((invconv_mix_generic_kernel<1, true>), dim3(gg), dim3(256), 0, s, dz, mask, w, nullptr, nullptr, dx, nullptr, B, C, T, n_split);
+            hipLaunchKernelGGL((invconv_dw_generic_kernel<1>), gw, dim3(256), 0, s, x, mask, w_inv, dz, dlogdet, x_len, dw, B, C, T, n_split);
+        }
+        GLOWTTS_LAUNCH_CHECK("glowtts_invconv_bwd");
+    }
     const long n = (long)B * (C / n_split) * (v4 ? T / 4 : T);
     int g = cdiv(n, 256);
     if (g > 1024) g = 1024;

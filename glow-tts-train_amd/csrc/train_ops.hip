@@ -430,10 +430,12 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long *__restrict__
                                                         float *__restrict__ out, int T, int H, int V) {
     const int b = blockIdx.y, t = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
     if (t >= T) return;
-    long id = ids[(long)b * T + t];
-    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    const float *row = w + id * H;
-    for (int h = wave; h < H; h += 4) out[((long)b * H + h) * T + t] = row[h] * scale;
+    const long id = ids[(long)b * T + t];
+    // an id outside the vocabulary (a bad phoneme map) is a device assert in the reference's nn.Embedding; here its column is
+    // NaN, so the step's loss is NaN instead of a model that trains silently on a clamped id (the backward skips such ids)
+    const bool ok = id >= 0 && id < V;
+    const float *row = w + (ok ? id : 0) * H;
+    for (int h = wave; h < H; h += 4) out[((long)b * H + h) * T + t] = ok ? row[h] * scale : __builtin_nanf("");
 }
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long *__restrict__ ids, const float *__restrict__ dout, float scale,

@@ -21,6 +21,9 @@
  *                                 GLOWTTS_WRW_BATCH   [1]     0 = one weight-gradient launch per WN layer (csrc/wn_stack.hip)
  *                                 GLOWTTS_WRW1_PIPE   [1]     0 = 1x1 weight gradient without the software-pipelined plane split
  *                                                     (csrc/convgemm_split.hip; this one is read at every launch)
+ *                                 GLOWTTS_WRW5_BSPLIT [1]     0 = a batched 5-tap weight-gradient launch sizes its split-K per problem
+ *                                                     (one round of workgroups per problem) instead of sharing the compute units
+ *                                                     between the problems of the batch (csrc/convwrw_tr.hip; read at every launch)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
@@ -102,9 +105,11 @@ int glowtts_actnorm_stats(const float *x, const float *mask, float *sum_x, float
                           glowtts_stream_t stream);
 
 /* ---- InvConvNear (layers.py:238-275) ------------------------------------------------------------------------
- * prepare: one wavefront factorises the n x n weight (n = n_split, even, <= 8) by Gauss-Jordan with partial
- *          pivoting held across lanes: w_inv (n*n) and logdet_w[0] = log(det W) (NaN if det <= 0, as
+ * prepare: one wavefront factorises the n x n weight (n = n_split) by Gauss-Jordan with partial pivoting, fp64 — held
+ *          across lanes for n <= 8, in LDS for n <= 32: w_inv (n*n) and logdet_w[0] = log(det W) (NaN if det <= 0, as
  *          torch.logdet, layers.py:265).  Replaces torch.logdet / torch.inverse (layers.py:258,265,275).
+ * n_split: any even value <= 32 that divides C (layers.py:227,240).  2 / 4 / 8 keep a group's n x n mix in registers; other
+ *          group sizes run on run-time-n kernels (one thread per output row of a group, dW entry by entry).
  * fwd    : per (b, group g, t): z[k_out] = sum_k W[k_out,k] x[k], rows k = h*(n/2)+s <-> channel
  *          h*(C/2) + g*(n/2) + s  (layers.py:247-252, 267-271), times mask;
  *          logdet[b] = logdet_w * (C/n) * x_len[b]   (logdet may be NULL; pass w = w_inv for reverse)

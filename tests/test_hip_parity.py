@@ -76,7 +76,7 @@ def test_library_is_the_hip_one(G):
         G.ops.mask_len(torch.ones(2, 3))          # CPU tensor: no fallback, loud failure
     with pytest.raises(RuntimeError, match="n_split"):
         x = torch.zeros(1, 12, 4, device="cuda")
-        G.ops.invconv_apply(x, torch.ones(1, 4, device="cuda"), torch.eye(6, device="cuda"), 6)
+        G.ops.invconv_apply(x, torch.ones(1, 4, device="cuda"), torch.eye(3, device="cuda"), 3)      # odd: layers.py:227
 
 
 # =============================================================================================== MAS
@@ -276,9 +276,54 @@ def test_actnorm_invconv_fused_vs_separate_and_oracle(G, b, c, t, n_split):
         assert_close(a, bb, what=f"fused vs oracle {n}", rtol=2e-4, atol=5e-5 * max(1.0, scale))
 
 
+@pytest.mark.parametrize("b,c,t,n_split", [(3, 12, 37, 6), (2, 160, 100, 10), (2, 160, 64, 16), (2, 80, 52, 20), (1, 64, 33, 32)])
+def test_invconv_any_even_n_split_vs_oracle(G, b, c, t, n_split):
+    """The reference allows every even n_split that divides the channels (layers.py:227,240); group sizes other than 2 / 4 / 8
+    run on the run-time-N kernels: forward, reverse with the stored inverse, and autograd's gradients against the oracle
+    (layers.py:247-272), through the module the decoder builds."""
+    from oracle import glow_oracle as O
+
+    torch.manual_seed(c * 100 + n_split)
+    x = torch.randn(b, c, t)
+    lens = torch.randint(t // 2, t + 1, (b,))
+    lens[0] = t
+    mask = (torch.arange(t)[None] < lens[:, None]).float()[:, None]
+    f = G.layers.InvConvNear(c, n_split=n_split).cuda()
+    with torch.no_grad():
+        f.weight.add_(0.1 * torch.randn(n_split, n_split, device="cuda"))
+        if torch.det(f.weight) < 0:
+            f.weight[:, 0] = -f.weight[:, 0]
+    r, s = torch.randn(b, c, t), torch.randn(b)
+    xs = x.cuda().requires_grad_(True)
+    z, ld = f(xs, mask.cuda())
+    ((z * r.cuda()).sum() + (ld * s.cuda()).sum()).backward()
+    xo = x.clone().requires_grad_(True)
+    wo = f.weight.detach().cpu().clone().requires_grad_(True)
+    zo, ldo = O.invconv(xo, mask, wo, n_split)
+    ((zo * r).sum() + (ldo * s).sum()).backward()
+    for name, a, bb in (("z", z, zo), ("logdet", ld, ldo), ("dx", xs.grad, xo.grad), ("dw", f.weight.grad, wo.grad)):
+        scale = float(bb.abs().max()) + 1e-6
+        assert_close(a, bb, what=f"n_split={n_split} {name}", rtol=2e-4, atol=5e-5 * max(1.0, scale))
+    f.store_inverse()
+    back, _ = f(z.detach(), mask.cuda(), reverse=True)
+    assert_close(back, (x * mask).cuda(), what=f"n_split={n_split} round trip", rtol=1e-3, atol=1e-4)
+    # and a decoder built with such a group size steps end to end (the blocks then run flow by flow, not as fused block nodes)
+    if c == 160 and n_split == 10:
+        dec = G.models.FlowSpecDecoder(80, 32, 5, 1, 2, 2, p_dropout=0.0, n_split=10, n_sqz=2).cuda().train()
+        y = torch.randn(2, 80, 48, device="cuda", requires_grad=True)
+        ym = torch.ones(2, 1, 48, device="cuda")
+        zz, ldet = dec(y, ym)
+        (zz.square().mean() + ldet.mean()).backward()
+        assert torch.isfinite(zz).all() and torch.isfinite(y.grad).all()
+        dec.store_inverse()
+        with torch.no_grad():
+            yy, _ = dec(zz.detach(), ym, reverse=True)
+        assert_close(yy, y.detach(), what="decoder round trip with n_split=10", rtol=1e-3, atol=1e-3)
+
+
 def test_invconv_prepare_matches_torch(G):
     torch.manual_seed(3)
-    for n in (2, 4, 6, 8):
+    for n in (2, 4, 6, 8, 10, 16, 32):
         w = torch.randn(n, n)
         if torch.det(w) < 0:
             w[:, 0] = -w[:, 0]
@@ -1037,6 +1082,15 @@ def test_embedding_kernels_vs_torch(G):
         w4 = w.detach().clone().requires_grad_(True)
         ((torch.nn.functional.embedding(ids_, w4) * scale).transpose(1, 2) * r_).sum().backward()
         assert_close(grads[0], w4.grad, what="dweight", rtol=1e-5, atol=2e-4)
+    # an id outside the vocabulary (nn.Embedding: device assert) poisons its column instead of training on a clamped id
+    bad = ids.clone()
+    bad[1, 3], bad[2, 5] = V, -1
+    w5 = w.detach().clone().requires_grad_(True)
+    o5 = convops.EmbedFn.apply(bad, w5, scale)
+    assert torch.isnan(o5[1, :, 3]).all() and torch.isnan(o5[2, :, 5]).all()
+    ok = torch.ones(B, T, dtype=torch.bool, device="cuda")
+    ok[1, 3] = ok[2, 5] = False
+    assert torch.equal(o5.transpose(1, 2)[ok], out.detach().transpose(1, 2)[ok])
     # the model's encoder uses it: one launch, no (B, T, H) tensor
     enc = G.models.TextEncoder(V, 80, 192, 768, 256, 2, 1, 3, 0.0, window_size=4, mean_only=True, prenet=True).cuda()
     xl = torch.full((B,), T, device="cuda")

@@ -2,7 +2,8 @@
 """A/B of host-side switches in ONE process (boxes differ by several percent): alternating blocks of training steps.
 Usage: python tools/ab_flags.py NAME=VALUE_A,VALUE_B [steps_per_block] [blocks]
   NAME in: enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
-  whole-layer executors vs the per-operator path), io (fp32|all|hidden), fused (0|1: layer-resident WN forward kernel)"""
+  whole-layer executors vs the per-operator path), io (fp32|all|hidden), fused (0|1: layer-resident WN forward kernel),
+  envs (library knobs that are read on every launch: envs=GLOWTTS_A:0+GLOWTTS_B:4,GLOWTTS_A:1+GLOWTTS_B:2)"""
 import os
 import sys
 import time
@@ -36,6 +37,10 @@ def apply(v):
         _hip.wn_fused(v == "1")
     elif name == "wrw1pipe":                                # software-pipelined 1x1 weight gradient (csrc/convgemm_split.hip) on / off
         os.environ["GLOWTTS_WRW1_PIPE"] = v
+    elif name == "envs":                                    # library knobs read per launch: envs=K1:a+K2:b,K1:c+K2:d
+        for kv in v.split("+"):
+            k, _, val = kv.partition(":")
+            os.environ[k] = val
     elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
         global CHAIN
         CHAIN = v == "1"
