@@ -894,7 +894,11 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
         const int rows_per = big ? 128 : 64;
         const long wg5 = (long)((p.T + 79) / 80) * p.B * ((p.M + rows_per - 1) / rows_per);
         const int t32 = ((p.T + 31) / 32) * 32;
-        use32 = wg5 < env_knob("GLOWTTS_CONV32_WG", 440) && t32 * 10 <= p.T * 11;
+        // (threshold 440 -> 380 in round 4: the FFN's 768 <- 192-channel 3-tap convolutions at T = 160 have 384 tiles of 128 rows
+        // x 80 frames, which the bf16-plane kernel runs in 80-frame form — its 32-frame 128-row form does not exist, and the native
+        // 32-frame kernel that served them took 49 us: 15.00 -> 14.81 ms per step, tools/ab_flags.py envs=GLOWTTS_CONV32_WG:440,..:380;
+        // 190 and 0 measured 14.87 / 14.96 against 14.90)
+        use32 = wg5 < 380 && t32 * 10 <= p.T * 11;
     }
     if (int rc = conv_split_dispatch(p, EPI, big, use32 ? 2 : (n5 ? 5 : 4), pipe_ok, s); rc >= 0) return rc;   // bf16-plane arithmetic
     if (use32) {

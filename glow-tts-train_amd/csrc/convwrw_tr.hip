@@ -524,6 +524,7 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     if (p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
     if (p.taps == 3) {        // the text encoder's FFN convolutions (768 <-> 192 channels, T_text frames)
         static const bool no3 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR3"); return e && e[0] == '0'; }();
+        if (ns == 3 && !no3 && env_knob("GLOWTTS_WRW_TR3_MT", 2) == 4 && p.M % 64 == 0) return launch_wrw_tr<3, 3, 4>(p, s);
         return (ns == 3 && !no3) ? launch_wrw_tr<3, 3, 2, true>(p, s) : -1;
     }
     // 1x1 convolutions stay on the frame-packed kernel: this one is staging-bound there (measured at B=32 / T'=400, 384 <- 192

@@ -133,6 +133,11 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
     for (int i = 1; i < n_layers; ++i) dil *= dil_rate;
     const void *dsk = dskip;
     WN_TRY(order_after(ms, ws));                                    // accumulators were cleared on the main stream
+    // two_source bit 1 (set by glowtts_flow_block_bwd): `dskip` arrives MASKED already — the end conv's backward-data epilogue
+    // multiplied it by the mask — so the last layer's d_rs = dskip mask IS dskip and its res_skip_bwd launch (a 20 MB pass on the
+    // backward's chain, 12 per step) is not queued
+    const bool pre_masked = (two_source & 2) != 0;
+    two_source &= 1;
     if (two_source) {
         // The launch sequence of convops.WNFn._backward_layers in its two-source form, layer by layer: d_rs = [dx_{i+1} mask ;
         // dskip] is never written (gate_bwd and wrw2 read its halves from the two tensors), each weight-gradient kernel goes to
@@ -161,9 +166,11 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
                 float *dxin_i = d_xinf + (long)i * 2 * BHT, *dx_i = dxf + (long)i * BHT;
                 const float *half = last ? nullptr : dxf + (long)(i + 1) * BHT;
                 if (last) {
-                    WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
-                    dskf = d_rsf;
-                    WN_TRY(glowtts_conv_gate_bwd_io(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                    if (!pre_masked) {
+                        WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
+                        dskf = d_rsf;
+                    }
+                    WN_TRY(glowtts_conv_gate_bwd_io(dskf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
                                                     dcond ? dcond + (long)i * B * 2 * H : nullptr, B, H, H, T, 0, stream));
                 } else {
                     WN_TRY(glowtts_conv_gate_bwd_io(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
@@ -177,7 +184,7 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
             }
             WN_TRY(order_after(ms, ws));
             const int nl = n_layers - 1;
-            WN_TRY(glowtts_conv_wrw(bx1[nl], (long)H * T, d_rsf, (long)H * T, nullptr, nullptr, bw1[nl], bb1[nl], B, H, H, T, 1, 1, 0,
+            WN_TRY(glowtts_conv_wrw(bx1[nl], (long)H * T, dskf, (long)H * T, nullptr, nullptr, bw1[nl], bb1[nl], B, H, H, T, 1, 1, 0,
                                     (glowtts_stream_t)ws));
             if (nl > 0)
                 WN_TRY(glowtts_conv_wrw_batch(nl, bx1, (long)H * T, bd1, (long)H * T, bd1b, (long)H * T, H, nullptr, nullptr, bw1, bb1, B, H,
@@ -197,12 +204,14 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
             float *dxin_i = d_xinf + (long)i * 2 * BHT, *dx_i = dxf + (long)i * BHT;
             const float *half = last ? nullptr : dxf + (long)(i + 1) * BHT;       // left the layer above already masked
             if (last) {
-                WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
-                dskf = d_rsf;
+                if (!pre_masked) {
+                    WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
+                    dskf = d_rsf;
+                }
                 WN_TRY(order_after(ms, ws));
-                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, d_rsf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
+                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, dskf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
                                         1, 0, (glowtts_stream_t)ws));
-                WN_TRY(glowtts_conv_gate_bwd_io(d_rsf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
+                WN_TRY(glowtts_conv_gate_bwd_io(dskf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
                                                 dcond ? dcond + (long)i * B * 2 * H : nullptr, B, H, H, T, 0, stream));
             } else {
                 WN_TRY(order_after(ms, ws));
@@ -360,12 +369,15 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain
     WN_TRY(order_after(ms, ws));
     WN_TRY(wrw_any(skip, HT, dout, CT, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, io_h, (glowtts_stream_t)ws));
-    WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0, 0, 0, io_h, io_h,
-                               stream));
+    // (two-source form: dskip leaves this conv masked, which is the last WN layer's d_rs — see glowtts_wn_bwd_io)
+    const int pre_mask = (two_source && !io) ? 1 : 0;
+    WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, pre_mask ? mask : nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0,
+                               pre_mask, 0, io_h, io_h, stream));
     // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block).
     // With bf16 tensors the stack masks its own input gradient: the start conv's weight gradient then needs no mask.
     WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, dcond,
-                             nullptr, nullptr, 0, 0, B, H, T, taps, dil_rate, two_source, io_h, io_h, wgrad_stream, stream));
+                             nullptr, nullptr, 0, 0, B, H, T, taps, dil_rate, two_source ? (1 | (pre_mask << 1)) : 0, io_h, io_h,
+                             wgrad_stream, stream));
     // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
     WN_TRY(order_after(ms, ws));
     WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,

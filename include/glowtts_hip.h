@@ -289,7 +289,10 @@ int glowtts_gate_bwd_ts(const float *ts, const float *dacts, const unsigned char
  *       d_rs, d_xin (n_layers, B,2H,T); packed weight gradients accumulate into layers[i].dwp_* (zeroed by the caller),
  *       bias gradients into layers[i].db_*; the weight-gradient kernels and, if unpack_desc != NULL, the final
  *       glowtts_unpack_weight_grad_multi(unpack_desc, unpack_prefix, n_conv, total_rows) run on wgrad_stream behind
- *       events (NULL: everything on `stream`).  The caller keeps every buffer alive until wgrad_stream has drained. */
+ *       events (NULL: everything on `stream`).  The caller keeps every buffer alive until wgrad_stream has drained.
+ *       two_source: bit 0 = the two-source launch sequence (d_rs = [dx mask ; dskip] is never materialised; fp32 tensors,
+ *       dilation 1, H % 192 == 0, T % 4 == 0); bit 1 (with bit 0) = `dskip` is masked already (glowtts_flow_block_bwd masks it in
+ *       the end conv's backward-data epilogue), so the last layer's dskip * mask pass is not queued. */
 typedef struct glowtts_wn_layer {
     const float *wf_in, *wb_in, *b_in;   /* packed forward / backward-data weights and bias of the k-tap in-conv */
     const float *wf_rs, *wb_rs, *b_rs;   /* ... of the 1x1 res/skip conv (2H rows, H in the last layer) */
