@@ -907,6 +907,10 @@ static int dispatch_split_ns(ConvGemmParams &p, int epi, bool big, int nct, cons
     // convolution) when their ConvGroup's planes are bound — fp32-equivalent form only; with 32-frame tiles where the native
     // dispatch would pick them (T_text = 160: 80-frame tiles leave a quarter of the CUs without a workgroup)
     if constexpr (NS == 3) {
+        // (round 4: the coupling's 1x1 start / end convolutions and their backward-data forms — 80 / 160 / 192 channels, 48 launches
+        // per step on the decoder's chain — were instantiated here as EPI_PLAIN / EPI_ADD with one tap: under rocprofv3 the
+        // bf16-plane forms take what the fp32-MFMA ones do (17.2 / 14.5 us against 16.4 / 15.3 in the step, 8.7 against 8.0 us at
+        // best) and the step does not move (14.89 against 14.92 ms): these launches are their fixed costs.  Not kept.)
         GLOWTTS_SPLIT_CASE(EPI_PLAIN, 1, 3)
         GLOWTTS_SPLIT_CASE(EPI_PLAIN, 2, 3)
         GLOWTTS_SPLIT_CASE(EPI_ADD, 1, 3)

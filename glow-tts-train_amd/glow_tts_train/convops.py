@@ -1091,7 +1091,10 @@ class FlowBlockFn(Function):
         wgrad = _WgradStream(dev)
         if block_index < _WGRAD_MAIN_BLOCKS:
             wgrad.enabled = False                    # the backward's last blocks: their weight gradients stay on the chain's stream
-        two_src = (not io) and wgrad.enabled and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
+        # the two-source launch sequence (d_rs never materialised, batched weight gradients) also where the weight gradients stay
+        # on the chain's stream — the backward's last block, and every block of a one-stream run (rocprofv3 passes then time the
+        # launches the step really makes): 14.83 -> 14.75 ms per step (tools/ab_flags.py, four alternating pairs)
+        two_src = (not io) and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
         dy, dout, dx = flow(B, C, T), new(B, C, T), flow(B, C, T)
         dskip = new(B, H, T)
         d_rs = new(B, H, T) if two_src else new(n_layers, B, 2 * H, T)
