@@ -846,6 +846,7 @@ static bool find_planes(const float *wp, int ns, const unsigned short **out, lon
 // wn_fused.hip: the planes bound to the calling thread for packed weights at `wp`, and the forward-type arithmetic code
 bool conv_find_planes(const float *wp, int ns, const unsigned short **out, long *stride) { return find_planes(wp, ns, out, stride); }
 int conv_math_forward() { return g_conv_math.load(std::memory_order_relaxed); }
+int conv_math_wrw() { return g_conv_math_wrw.load(std::memory_order_relaxed); }       // convwrw1.hip
 
 template <int NS, int RTW, int NCT, int EPI, int TAPS, int IOB = 0, int NSA = NS>
 static int launch_split(ConvGemmParams &p, const unsigned short *planes, long stride, hipStream_t s) {

@@ -137,6 +137,9 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
     // multiplied it by the mask — so the last layer's d_rs = dskip mask IS dskip and its res_skip_bwd launch (a 20 MB pass on the
     // backward's chain, 12 per step) is not queued
     const bool pre_masked = (two_source & 2) != 0;
+    // bit 2 (with bits 0 and 1): the caller queues the stack's 1x1 weight gradients itself (glowtts_flow_block_bwd: one
+    // glowtts_conv_wrw1_multi launch for them and the start / end convs')
+    const bool skip_wrw1 = (two_source & 4) != 0 && pre_masked;
     two_source &= 1;
     if (two_source) {
         // The launch sequence of convops.WNFn._backward_layers in its two-source form, layer by layer: d_rs = [dx_{i+1} mask ;
@@ -184,11 +187,13 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
             }
             WN_TRY(order_after(ms, ws));
             const int nl = n_layers - 1;
-            WN_TRY(glowtts_conv_wrw(bx1[nl], (long)H * T, dskf, (long)H * T, nullptr, nullptr, bw1[nl], bb1[nl], B, H, H, T, 1, 1, 0,
-                                    (glowtts_stream_t)ws));
-            if (nl > 0)
-                WN_TRY(glowtts_conv_wrw_batch(nl, bx1, (long)H * T, bd1, (long)H * T, bd1b, (long)H * T, H, nullptr, nullptr, bw1, bb1, B, H,
-                                              2 * H, T, 1, 1, 0, (glowtts_stream_t)ws));
+            if (!skip_wrw1) {
+                WN_TRY(glowtts_conv_wrw(bx1[nl], (long)H * T, dskf, (long)H * T, nullptr, nullptr, bw1[nl], bb1[nl], B, H, H, T, 1, 1, 0,
+                                        (glowtts_stream_t)ws));
+                if (nl > 0)
+                    WN_TRY(glowtts_conv_wrw_batch(nl, bx1, (long)H * T, bd1, (long)H * T, bd1b, (long)H * T, H, nullptr, nullptr, bw1, bb1, B,
+                                                  H, 2 * H, T, 1, 1, 0, (glowtts_stream_t)ws));
+            }
             WN_TRY(glowtts_conv_wrw_batch(n_layers, bx5, (long)H * T, bd5, (long)2 * H * T, nullptr, 0, 0, nullptr, nullptr, bw5, bb5, B, H,
                                           2 * H, T, taps, 1, pad, (glowtts_stream_t)ws));
             if (unpack_desc)
@@ -208,15 +213,19 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
                     WN_TRY(glowtts_res_skip_bwd(nullptr, dskf, mask, nullptr, d_rsf, B, H, T, 1, stream));
                     dskf = d_rsf;
                 }
-                WN_TRY(order_after(ms, ws));
-                WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, dskf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
-                                        1, 0, (glowtts_stream_t)ws));
+                if (!skip_wrw1) {
+                    WN_TRY(order_after(ms, ws));
+                    WN_TRY(glowtts_conv_wrw(acts_i, (long)H * T, dskf, (long)H * T, nullptr, nullptr, L.dwp_rs, L.db_rs, B, H, H, T, 1,
+                                            1, 0, (glowtts_stream_t)ws));
+                }
                 WN_TRY(glowtts_conv_gate_bwd_io(dskf, nullptr, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
                                                 dcond ? dcond + (long)i * B * 2 * H : nullptr, B, H, H, T, 0, stream));
             } else {
-                WN_TRY(order_after(ms, ws));
-                WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dskf, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
-                                         T, 1, 1, 0, (glowtts_stream_t)ws));
+                if (!skip_wrw1) {
+                    WN_TRY(order_after(ms, ws));
+                    WN_TRY(glowtts_conv_wrw2(acts_i, (long)H * T, half, (long)H * T, dskf, (long)H * T, H, L.dwp_rs, L.db_rs, B, H, 2 * H,
+                                             T, 1, 1, 0, (glowtts_stream_t)ws));
+                }
                 WN_TRY(glowtts_conv_gate_bwd_io(half, dskf, L.wb_rs, ts_i, drop_i, drop_scale, dxin_i,
                                                 dcond ? dcond + (long)i * B * 2 * H : nullptr, B, 2 * H, H, T, 0, stream));
             }
@@ -366,9 +375,15 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
     WN_TRY(glowtts_coupling_bwd_io(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, io_f, io_h, stream));
-    // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain
-    WN_TRY(order_after(ms, ws));
-    WN_TRY(wrw_any(skip, HT, dout, CT, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, io_h, (glowtts_stream_t)ws));
+    // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain.
+    // Round 4, two-source form: the block's SIX 1x1 weight gradients (end conv, start conv, the stack's last and two-source
+    // res/skip convs) are one launch behind the block's chain (glowtts_conv_wrw1_multi: 9 tiles of 192 x 192 sharing the compute
+    // units) — alone they were launches of 22 us for < 1 us of matrix work each, and 88 us for the batch of three.
+    const bool multi1 = two_source && !io && blk->n_layers >= 1 && blk->n_layers + 2 <= 8 && H % 64 == 0;
+    if (!multi1) {
+        WN_TRY(order_after(ms, ws));
+        WN_TRY(wrw_any(skip, HT, dout, CT, nullptr, blk->dwp_end, blk->db_end, B, H, C, T, 1, 1, 0, io_h, (glowtts_stream_t)ws));
+    }
     // (two-source form: dskip leaves this conv masked, which is the last WN layer's d_rs — see glowtts_wn_bwd_io)
     const int pre_mask = (two_source && !io) ? 1 : 0;
     WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, pre_mask ? mask : nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0,
@@ -376,12 +391,39 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block).
     // With bf16 tensors the stack masks its own input gradient: the start conv's weight gradient then needs no mask.
     WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, dcond,
-                             nullptr, nullptr, 0, 0, B, H, T, taps, dil_rate, two_source ? (1 | (pre_mask << 1)) : 0, io_h, io_h,
-                             wgrad_stream, stream));
+                             nullptr, nullptr, 0, 0, B, H, T, taps, dil_rate,
+                             two_source ? (1 | (pre_mask << 1) | ((multi1 && pre_mask) ? 4 : 0)) : 0, io_h, io_h, wgrad_stream, stream));
     // start conv (C/2 -> H, 1x1, output masked): its input gradient is ADDED into dy[:, :C/2] where the affine apply left dz0
     WN_TRY(order_after(ms, ws));
-    WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,
-                   (glowtts_stream_t)ws));
+    if (multi1 && pre_mask) {
+        const int nl = blk->n_layers;
+        const long BHT = (long)B * H * T;
+        const float *actsf = static_cast<const float *>(acts), *dxw = static_cast<const float *>(dx_wn);
+        const float *dskf = static_cast<const float *>(dskip);                 // masked by the end conv's backward-data epilogue
+        glowtts_wrw1_problem pr[8] = {};
+        int np = 0;
+        for (int i = 0; i < nl; ++i) {                                        // res/skip convs: x = acts_i, d = [dx_{i+1} mask ; dskip]
+            const glowtts_wn_layer &L = blk->layers[i];
+            glowtts_wrw1_problem &q = pr[np++];
+            q.x = actsf + (long)i * BHT; q.x_bs = HT; q.Cin = H; q.dwp = L.dwp_rs; q.dbias = L.db_rs;
+            if (i == nl - 1) { q.d = dskf; q.d_bs = HT; q.M = H; }
+            else { q.d = dxw + (long)(i + 1) * BHT; q.d_bs = HT; q.d2 = dskf; q.d2_bs = HT; q.d_split = H; q.M = 2 * H; }
+        }
+        {   // end conv: x = the skip sum, d = dout
+            glowtts_wrw1_problem &q = pr[np++];
+            q.x = static_cast<const float *>(skip); q.x_bs = HT; q.Cin = H; q.d = static_cast<const float *>(dout); q.d_bs = CT; q.M = C;
+            q.dwp = blk->dwp_end; q.dbias = blk->db_end;
+        }
+        {   // start conv: x = y[:, :C/2], d = the stack's input gradient times the mask (the conv's output was masked)
+            glowtts_wrw1_problem &q = pr[np++];
+            q.x = static_cast<const float *>(start_in); q.x_bs = start_bs; q.Cin = C / 2; q.d = dxw; q.d_bs = HT; q.M = H; q.mask_d = mask;
+            q.dwp = blk->dwp_start; q.dbias = blk->db_start;
+        }
+        WN_TRY(glowtts_conv_wrw1_multi(np, pr, B, T, (glowtts_stream_t)ws));
+    } else {
+        WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,
+                       (glowtts_stream_t)ws));
+    }
     WN_TRY(glowtts_conv_fwd_io(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, io_h, io_f,
                                stream));
     // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "glowtts_conv_wrw2": [_P, _L, _P, _L, _P, _L, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_wrw": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
     "glowtts_conv_wrw_batch": [_I, _P, _L, _P, _L, _P, _L, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "glowtts_conv_wrw1_multi": [_I, _P, _I, _I],
     "glowtts_chan_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F],
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
@@ -119,6 +120,13 @@ class WnLayer(ctypes.Structure):
     """struct glowtts_wn_layer (include/glowtts_hip.h): device pointers of one WN layer's packed weights and gradients."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("wf_in", "wb_in", "b_in", "wf_rs", "wb_rs", "b_rs", "dwp_in", "dwp_rs",
                                                  "db_in", "db_rs")]
+
+
+class Wrw1Problem(ctypes.Structure):
+    """struct glowtts_wrw1_problem (include/glowtts_hip.h): one 1x1 weight gradient of a multi-problem launch."""
+    _fields_ = ([(n, ctypes.c_void_p) for n in ("x", "d", "d2", "mask_d", "mask_x", "dwp", "dbias")]
+                + [(n, ctypes.c_long) for n in ("x_bs", "d_bs", "d2_bs")]
+                + [(n, ctypes.c_int) for n in ("Cin", "M", "d_split", "reserved")])
 
 
 class FlowBlock(ctypes.Structure):

@@ -24,6 +24,9 @@
  *                                 GLOWTTS_WRW5_BSPLIT [1]     0 = a batched 5-tap weight-gradient launch sizes its split-K per problem
  *                                                     (one round of workgroups per problem) instead of sharing the compute units
  *                                                     between the problems of the batch (csrc/convwrw_tr.hip; read at every launch)
+ *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
+ *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip; read at
+ *                                                     every launch)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
@@ -221,6 +224,25 @@ int glowtts_conv_wrw(const float *x, long x_bs, const float *d, long d_bs, const
 int glowtts_conv_wrw_batch(int n, const float *const *x, long x_bs, const float *const *d, long d_bs, const float *const *d2,
                            long d2_bs, int d_split, const float *mask, const float *mask_x, float *const *dwp,
                            float *const *dbias, int B, int Cin, int M, int T, int taps, int dil, int pad, glowtts_stream_t stream);
+/* n weight gradients of 1x1 convolutions of DIFFERENT shapes in one launch (autograd of the 1x1 convolutions of layers.py:155-156
+ * and attentions.py:97-113, 128-129 — a flow block's three two-source res/skip gradients, its last layer's, the start conv's and
+ * the end conv's — and of the encoder's q / k / v / o projections, attentions.py:204-211): problem q is glowtts_conv_wrw (d2 ==
+ * NULL; mask_d multiplies d, mask_x multiplies x, either may be NULL) or glowtts_conv_wrw2 (rows [d_split, M) of the output
+ * gradient from d2, d_split % 64 == 0, no masks) with taps = 1; all problems share B and T (T % 4 == 0, 16-byte aligned rows).
+ * `problems` is a HOST array.  In the bf16-plane arithmetic (glowtts_conv_math weight-gradient mode 3) the problems' 192 x 192
+ * tiles share one round of workgroups (csrc/convwrw1.hip); otherwise they are launched one by one: same results either way. */
+typedef struct glowtts_wrw1_problem {
+    const float *x;          /* (B, Cin, T), batch stride x_bs elements */
+    const float *d;          /* (B, M, T) — or (B, d_split, T) when d2 != NULL —, batch stride d_bs */
+    const float *d2;         /* NULL, or (B, M - d_split, T): rows [d_split, M) of the output gradient, batch stride d2_bs */
+    const float *mask_d;     /* NULL or (B, T) */
+    const float *mask_x;     /* NULL or (B, T) */
+    float *dwp;              /* [Cin][M] accumulated */
+    float *dbias;            /* NULL or [M] accumulated row sums of the (masked) output gradient */
+    long x_bs, d_bs, d2_bs;
+    int Cin, M, d_split, reserved;
+} glowtts_wrw1_problem;
+int glowtts_conv_wrw1_multi(int n, const glowtts_wrw1_problem *problems, int B, int T, glowtts_stream_t stream);
 int glowtts_pack_weight(const float *v, const float *g, float *wp_f, float *wp_b, float *inv_norm, int Cout, int Cin,
                         int taps, glowtts_stream_t stream);
 

@@ -355,3 +355,51 @@ def test_encoder_ffn_convs_take_the_group_planes(M):
         assert x6[k] <= 1.5 * native[k] + 2e-7, (k, x6, native)
         # the plane kernels really ran: the same numbers to fp32 accuracy, not the same bits (another summation order)
         assert not torch.equal(t_x6[k], t_native[k]), f"{k}: bit-identical to the native kernels"
+
+
+@pytest.mark.parametrize("mode", ["bf16x6+wrw", "fp32"])
+@pytest.mark.parametrize("b,t", [(3, 100), (2, 400), (4, 36)])
+def test_multi_problem_1x1_weight_gradient_against_fp64(M, mode, b, t):
+    """glowtts_conv_wrw1_multi (csrc/convwrw1.hip): the 1x1 weight gradients of a flow block — and problems of other shapes —
+    in ONE launch (192 x 192 tiles, 32-frame steps) against an fp64 contraction: two-source output gradients, a slice of a wider
+    tensor as x, masks on either operand, more than 192 channels either side, tiny problems; in native fp32 arithmetic the entry
+    launches the problems one by one (same results).  Accumulates into dwp / dbias."""
+    import ctypes
+
+    torch.manual_seed(b * 1000 + t)
+    dev = "cuda"
+    M.convops.set_conv_math(mode)
+    lens = torch.randint(t // 2, t + 1, (b,))
+    lens[0] = t
+    mask = (torch.arange(t)[None] < lens[:, None]).float().to(dev)
+    wide = torch.randn(b, 160, t, device=dev)
+    # (Cin, M, two-source split or 0, mask on d, mask on x, x tensor or None)
+    specs = [(192, 384, 192, False, False, None), (192, 192, 0, False, False, None), (80, 192, 0, True, False, wide),
+             (192, 160, 0, False, False, None), (48, 16, 0, False, True, None), (200, 200, 0, True, True, None),
+             (192, 384, 192, False, False, None), (64, 320, 64, False, False, None)]
+    probs = (M.hip.Wrw1Problem * len(specs))()
+    keep, want = [], []
+    for j, (cin, m, split, md, mx, xt) in enumerate(specs):
+        x = xt if xt is not None else torch.randn(b, cin, t, device=dev)
+        d = torch.randn(b, split if split else m, t, device=dev)
+        d2 = torch.randn(b, m - split, t, device=dev) if split else None
+        dwp = 0.5 * torch.randn(cin, m, device=dev)
+        dbias = 0.5 * torch.randn(m, device=dev)
+        xe = x[:, :cin].double() * (mask[:, None].double() if mx else 1.0)
+        de = (torch.cat([d, d2], 1) if split else d).double() * (mask[:, None].double() if md else 1.0)
+        want.append((dwp.double() + torch.einsum("bkt,bmt->km", xe, de), dbias.double() + de.sum((0, 2))))
+        q = probs[j]
+        q.x, q.d, q.d2 = x.data_ptr(), d.data_ptr(), (d2.data_ptr() if split else None)
+        q.mask_d, q.mask_x = (mask.data_ptr() if md else None), (mask.data_ptr() if mx else None)
+        q.dwp, q.dbias = dwp.data_ptr(), dbias.data_ptr()
+        q.x_bs, q.d_bs, q.d2_bs = x.shape[1] * t, d.shape[1] * t, ((m - split) * t if split else 0)
+        q.Cin, q.M, q.d_split = cin, m, split
+        keep.append((x, d, d2, dwp, dbias))
+    M.hip.call("glowtts_conv_wrw1_multi", len(specs), ctypes.addressof(probs), b, t)
+    torch.cuda.synchronize()
+    for j, ((x, d, d2, dwp, dbias), (w_ref, b_ref)) in enumerate(zip(keep, want)):
+        scale = float(w_ref.abs().max())
+        err = float((dwp.double() - w_ref).abs().max()) / scale
+        assert err < 2e-5, f"problem {j} {specs[j][:3]}: dW off by {err:.2e} of its largest element ({mode})"
+        errb = float((dbias.double() - b_ref).abs().max()) / float(b_ref.abs().max())
+        assert errb < 2e-5, f"problem {j}: dbias off by {errb:.2e} ({mode})"
