@@ -32,7 +32,8 @@ struct Wrw1Params {
     long x_bs[kW1Max], d_bs[kW1Max], d2_bs[kW1Max];
     int Cin[kW1Max], M[kW1Max], d_split[kW1Max];
     int tile0[kW1Max + 1];       // first tile of each problem in the launch's tile numbering
-    int n, B, T, steps_u, total_steps, nb, total_tiles;
+    int n, B, T, steps_u, total_steps, nb, total_tiles, splits;
+    int exp;                     // timing experiments (tools/wrw1_bench.py): bit 0 = no atomics, bit 1 = no plane split
 };
 
 int conv_math_wrw();             // convgemm_split.hip: planes per fp32 operand of the weight-gradient kernels (0 = native fp32)
@@ -44,19 +45,21 @@ __device__ __forceinline__ void w1_store8(void *p, unsigned lo, unsigned hi) {  
 
 template <int NS>
 __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
-    constexpr int TK = 192, TM = 192, ROWS = TK + TM, RP = 40, PLANE = ROWS * RP;
-    constexpr int NI = ROWS * 8 / 512;               // 16-byte staging items per thread and step (6)
-    static_assert(NI == 6, "six items per thread");
-    extern __shared__ __align__(16) unsigned short w1_lds[];                 // [NS][ROWS][RP]
-    float *rowacc = reinterpret_cast<float *>(w1_lds + NS * PLANE);          // [TM]
+    constexpr int TK = 192, TM = 128, ROWS = TK + TM, RP = 40, PLANE = ROWS * RP, IMG = NS * PLANE;
+    constexpr int NI = ROWS * 8 / 256, NXI = TK / 32;     // 16-byte staging items per thread and step: 6 of x, 4 of d
+    static_assert(NI == 10 && NXI == 6, "ten items per thread");
+    extern __shared__ __align__(16) unsigned short w1_lds[];                 // [2 groups][NS][ROWS][RP]
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, wv = (tid >> 6) & 3, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
-    const int kw = wave & 3, mw = wave >> 2;
+    unsigned short *img = w1_lds + grp * IMG;
 
     // ---- which problem, which tile, which steps -----------------------------------------------------------------------------
+    // workgroup id = tile * splits + split with splits a multiple of 8 where the grid allows it: blocks are dealt round-robin over
+    // the 8 XCDs, so the tiles of ONE split — which read the same frames: x for a problem's m tiles, dskip for a block's four
+    // res/skip problems — share an XCD and its L2 (speed only, never correctness)
     const int id = blockIdx.x;
-    const int tile = id % P.total_tiles, split = id / P.total_tiles;
+    const int tile = id / P.splits, split = id - tile * P.splits;
     int pi = 0;
 #pragma unroll
     for (int j = 1; j < kW1Max; ++j)
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
     const int k0 = kt * TK, m0 = mt * TM;
     const int T = P.T;
     const int s_begin = split * P.nb, s_end = min(P.total_steps, s_begin + P.nb);
+    const int n_steps = max(0, s_end - s_begin);
+    const int n_my = (n_steps - grp + 1) / 2;         // this group: steps s_begin + grp, s_begin + grp + 2, ...
+    const int n_max = (n_steps + 1) / 2;
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(px), 0, (int)(((long)(P.B - 1) * x_bs + (long)Cin * T) * 4), 0x00020000);
@@ -92,87 +98,78 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
     };
 
-    // ---- staging map: item i = rows 64 i .. 64 i + 63 of the image (i < 3: x rows, else d rows), thread = (row, frame quad) ------
-    const int srow = tid >> 3, q = tid & 7;
-    int roff[NI];                                    // element offset of the row inside its utterance, or -1
-    bool second[NI - 3];                             // d items that come from the second source (uniform per item)
+    // ---- staging map of a group: item i = rows 32 i .. 32 i + 31 of its image (i < 6: x rows, else d rows), thread = (row, quad) --
+    const int srow = gt >> 3, q = gt & 7;
+    // row of item i: x row k0 + 32 i + srow, d row m0 + 32 (i - 6) + srow (second source: minus d_split); `valid` bit i = the row exists
+    const int xoff0 = (k0 + srow) * T, doff0 = (m0 + srow) * T;
+    unsigned valid = 0;
+    bool second[NI - NXI];                           // d items that come from the second source (uniform per item)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int k = k0 + 64 * i + srow;
-        roff[i] = k < Cin ? k * T : -1;
-    }
+    for (int i = 0; i < NXI; ++i)
+        if (k0 + 32 * i + srow < Cin) valid |= 1u << i;
 #pragma unroll
-    for (int i = 3; i < NI; ++i) {
-        const int mbase = m0 + 64 * (i - 3);
-        second[i - 3] = pd2 != nullptr && mbase >= d_split;
-        const int m = mbase + srow;
-        roff[i] = m < M ? (second[i - 3] ? m - d_split : m) * T : -1;
+    for (int i = NXI; i < NI; ++i) {
+        const int mbase = m0 + 32 * (i - NXI);
+        second[i - NXI] = pd2 != nullptr && mbase >= d_split;
+        if (mbase + srow < M) valid |= 1u << i;
     }
+    const int dsT = d_split * T;
     const bool do_bias = pdb != nullptr && kt == 0;
-    float bsum[NI - 3] = {0.f, 0.f, 0.f};
+    float bsum[NI - NXI] = {0.f, 0.f, 0.f, 0.f};
 
     f32x4 raw[NI], mxv, mdv;
-    auto load_step = [&](int s) {
+    int ld_i = 0;                                     // next item of this group to load
+    auto load_next = [&]() {
+        const int s = s_begin + grp + 2 * ld_i;
+        ++ld_i;
         const int b = s / P.steps_u, t = (s - b * P.steps_u) * 32 + q * 4;
         const bool tok = t < T;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            raw[i] = ld16(xrs, (tok && roff[i] >= 0) ? (int)(((long)b * x_bs + roff[i] + t) * 4) : kOOB);
+        for (int i = 0; i < NXI; ++i)
+            raw[i] = ld16(xrs, (tok && ((valid >> i) & 1)) ? (int)(((long)b * x_bs + xoff0 + 32 * i * T + t) * 4) : kOOB);
 #pragma unroll
-        for (int i = 3; i < NI; ++i) {
-            if (second[i - 3]) raw[i] = ld16(d2rs, (tok && roff[i] >= 0) ? (int)(((long)b * d2_bs + roff[i] + t) * 4) : kOOB);
-            else               raw[i] = ld16(drs, (tok && roff[i] >= 0) ? (int)(((long)b * d_bs + roff[i] + t) * 4) : kOOB);
+        for (int i = NXI; i < NI; ++i) {
+            const bool ok = tok && ((valid >> i) & 1);
+            const int ro = doff0 + 32 * (i - NXI) * T + t;
+            if (second[i - NXI]) raw[i] = ld16(d2rs, ok ? (int)(((long)b * d2_bs + ro - dsT) * 4) : kOOB);
+            else                 raw[i] = ld16(drs, ok ? (int)(((long)b * d_bs + ro) * 4) : kOOB);
         }
         if (pmx) mxv = ld16(mxrs, tok ? (b * T + t) * 4 : kOOB);
         if (pmd) mdv = ld16(mdrs, tok ? (b * T + t) * 4 : kOOB);
     };
-    unsigned pl[NI][NS][2];
-    auto unit = [&](int i) {                          // the planes of item i of the step whose raw values are in registers
-        f32x4 v = raw[i];
-        if (i < 3) { if (pmx) v *= mxv; }
-        else {
-            if (pmd) v *= mdv;
-            if (do_bias) bsum[i - 3] += (v[0] + v[1]) + (v[2] + v[3]);
+    auto stage = [&]() {                              // the loaded step: split into planes, into this group's image
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            f32x4 v = raw[i];
+            if (i < NXI) { if (pmx) v *= mxv; }
+            else {
+                if (pmd) v *= mdv;
+                if (do_bias) bsum[i - NXI] += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            unsigned o01[NS], o23[NS];
+            split_planes2<NS>(v[0], v[1], o01);
+            split_planes2<NS>(v[2], v[3], o23);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) w1_store8(img + p * PLANE + (32 * i + srow) * RP + q * 4, o01[p], o23[p]);
         }
-        unsigned o01[NS], o23[NS];
-        split_planes2<NS>(v[0], v[1], o01);
-        split_planes2<NS>(v[2], v[3], o23);
-#pragma unroll
-        for (int p = 0; p < NS; ++p) { pl[i][p][0] = o01[p]; pl[i][p][1] = o23[p]; }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-                w1_store8(w1_lds + p * PLANE + (64 * i + srow) * RP + q * 4, pl[i][p][0], pl[i][p][1]);
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // ---- accumulators: wave (kw, mw) owns x rows 48 kw .. + 48 and d rows 96 mw .. + 96 of the tile ----------------------------
-    f32x4 acc[3][6];
+    // ---- accumulators: wave wv of a group owns x rows 48 wv .. + 48 and all 128 d rows of the tile ---------------------------------
+    f32x4 acc[3][8];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool a_ok[3], c_ok[6];
+        for (int c = 0; c < 8; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool a_ok[3], c_ok[8];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) a_ok[a] = k0 + 48 * kw + 16 * a < Cin;
+    for (int a = 0; a < 3; ++a) a_ok[a] = k0 + 48 * wv + 16 * a < Cin;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) c_ok[c] = m0 + 96 * mw + 16 * c < M;
-    const unsigned short *xa = w1_lds + (48 * kw + lrow) * RP + lk * 8;
-    const unsigned short *da = w1_lds + (TK + 96 * mw + lrow) * RP + lk * 8;
+    for (int c = 0; c < 8; ++c) c_ok[c] = m0 + 16 * c < M;
 
-    if (s_begin < s_end) {
-        load_step(s_begin);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) unit(i);
-        commit();
-        if (s_begin + 1 < s_end) load_step(s_begin + 1);
-    }
-    lds_barrier();
-    for (int s = s_begin; s < s_end; ++s) {
-        const bool more = s + 1 < s_end;
+    const unsigned short *xa = img + (48 * wv + lrow) * RP + lk * 8;
+    const unsigned short *da = img + (TK + lrow) * RP + lk * 8;
+    auto compute = [&]() {
         i32x4 A[3][NS], Bv[2][NS];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -181,8 +178,8 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
 #pragma unroll
         for (int p = 0; p < NS; ++p) Bv[0][p] = *reinterpret_cast<const i32x4 *>(da + p * PLANE);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            if (c + 1 < 6)
+        for (int c = 0; c < 8; ++c) {
+            if (c + 1 < 8)
 #pragma unroll
                 for (int p = 0; p < NS; ++p) Bv[(c + 1) & 1][p] = *reinterpret_cast<const i32x4 *>(da + p * PLANE + 16 * (c + 1) * RP);
             __builtin_amdgcn_sched_barrier(0);
@@ -198,40 +195,67 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) unit(c);                        // one item of the NEXT step behind each MFMA group
-            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 2 < s_end) load_step(s + 2);          // the units have consumed the registers of step s + 1
-        lds_barrier();                                // every wave is through with this step's image
-        if (more) {
-            commit();
-            lds_barrier();
+    };
+
+    // ---- half-period schedule (convwrw_tr.hip's): group g multiplies its item i in phase 2 i + g and, in phase 2 i + g + 1, stages
+    // item i + 1 into its own image and issues the loads of item i + 2: every SIMD has one wave multiplying and one staging
+    if (n_my > 0) load_next();
+    if (grp == 0 && n_my > 0) {
+        stage();
+        if (n_my > 1) load_next();
+    }
+    lds_barrier();
+    for (int ph = 0; ph < 2 * n_max; ++ph) {
+        const int rel = ph - grp;
+        if (rel >= 0 && (rel & 1) == 0) {
+            if ((rel >> 1) < n_my && !(P.exp & 4)) compute();
+        } else {
+            const int i = (rel + 1) >> 1;
+            if (i < n_my && (i > 0 || grp == 1)) {
+                stage();
+                if (i + 1 < n_my) load_next();
+            }
         }
+        lds_barrier();
     }
 
-    // ---- split-K: one set of float atomics per workgroup --------------------------------------------------------------------------
+    // ---- the two groups' sums meet in LDS (the images are dead); group 0 sends the tile's split-K atomics -----------------------------
+    if (P.exp & 1) { if (acc[0][0][0] == 123.456f) pdw[0] = 1.f; return; }
+    float *red = reinterpret_cast<float *>(w1_lds);
+    if (grp == 1) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+            for (int c = 0; c < 8; ++c)
+                *reinterpret_cast<f32x4 *>(red + (((a * 8 + c) * 256) + gt) * 4) = acc[a][c];
+    }
+    __syncthreads();
+    if (grp == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 48 * kw + 16 * a + 4 * lk + r;
-                const int m = m0 + 96 * mw + 16 * c + lrow;
-                if (k < Cin && m < M) atomicAdd(pdw + (long)k * M + m, acc[a][c][r]);
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(red + (((a * 8 + c) * 256) + gt) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = k0 + 48 * wv + 16 * a + 4 * lk + r;
+                    const int m = m0 + 16 * c + lrow;
+                    if (k < Cin && m < M) atomicAdd(pdw + (long)k * M + m, acc[a][c][r] + o[r]);
+                }
             }
-    if (do_bias) {                                    // row sums of the (masked) d rows this workgroup staged
+    }
+    if (do_bias) {                                    // row sums of the (masked) d rows each group staged
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NI - NXI; ++i) {
             float v = bsum[i];
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
             v += __shfl_xor(v, 4, 64);
-            const int m = m0 + 64 * i + srow;
+            const int m = m0 + 32 * i + srow;
             if (q == 0 && m < M) atomicAdd(pdb + m, v);
         }
     }
-    (void)rowacc;
 }
 
 static int w1_compute_units() {
@@ -266,18 +290,21 @@ int conv_wrw1_multi_dispatch(int n, const glowtts_wrw1_problem *pr, int B, int T
         P.x[j] = q.x; P.d[j] = q.d; P.d2[j] = q.d2; P.mask_d[j] = q.mask_d; P.mask_x[j] = q.mask_x; P.dwp[j] = q.dwp; P.dbias[j] = q.dbias;
         P.x_bs[j] = q.x_bs; P.d_bs[j] = q.d_bs; P.d2_bs[j] = q.d2_bs; P.Cin[j] = q.Cin; P.M[j] = q.M; P.d_split[j] = q.d_split;
         P.tile0[j] = tiles;
-        tiles += ((q.Cin + 191) / 192) * ((q.M + 191) / 192);
+        tiles += ((q.Cin + 191) / 192) * ((q.M + 127) / 128);
     }
     for (int j = n; j <= kW1Max; ++j) P.tile0[j] = tiles;
     P.n = n; P.B = B; P.T = T; P.total_tiles = tiles;
+    P.exp = env_knob("GLOWTTS_WRW1_EXP", 0);
     P.steps_u = (T + 31) / 32;
     P.total_steps = B * P.steps_u;
-    int splits = w1_compute_units() / tiles;
+    int splits = env_knob("GLOWTTS_WRW1_CUS", w1_compute_units()) / tiles;
+    if (splits >= 16 && env_knob("GLOWTTS_WRW1_XCD", 1)) splits &= ~7;      // (see the kernel's workgroup numbering)
     if (splits > P.total_steps) splits = P.total_steps;
     if (splits < 1) splits = 1;
     P.nb = (P.total_steps + splits - 1) / splits;
-    splits = (P.total_steps + P.nb - 1) / P.nb;
-    constexpr size_t lds = (size_t)3 * 384 * 40 * 2 + 192 * sizeof(float);
+    if (!(splits >= 16 && (splits & 7) == 0)) splits = (P.total_steps + P.nb - 1) / P.nb;       // (a multiple of 8 stays: a split may be empty)
+    P.splits = splits;
+    constexpr size_t lds = (size_t)2 * 3 * 320 * 40 * 2;             // two groups' images; the group reduction reuses them
     static LdsLimit attr_max_e;
     if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw1_kernel<3>), lds, "glowtts_conv_wrw1_multi")) return rc_;
     hipLaunchKernelGGL((convwrw1_kernel<3>), dim3(tiles * splits), dim3(512), lds, s, P);
