@@ -8,16 +8,20 @@
 // then used by only 64 output channels — ~3.3 vector instructions per MFMA on the issue port the MFMAs share; and the small
 // problems of a flow block (start / end conv, last layer) were launches of their own, 22 us each for < 1 us of matrix work.
 // Here:
-//   tile      192 x channels x 192 d channels per workgroup (8 waves as 4 x 2, a wave owns 48 x 96 = 3 x 6 accumulator tiles):
-//             a staged value feeds 192 outputs — 1.2 vector instructions per MFMA; K <= 192 is ONE k tile, so x is staged once
-//             per 192 output channels and d exactly once;
-//   step      32 frames = one v_mfma_f32_16x16x32_bf16 step: 384 rows x 32 frames = 6 x 16-byte loads per thread; the planes of
-//             step s + 1 are formed BETWEEN the six MFMA groups of step s (one load's worth per group) and wait in registers; the
-//             raw values of step s + 2 are in flight across the (LDS-only) barriers;
-//   LDS       one image [3 planes][384 rows][32 frames + 8] bf16 (80-byte pitch: conflict-free ds_read_b128), 92 KB;
+//   tile      192 x channels x 128 d channels per workgroup: a staged value feeds 128-192 outputs (1.5 vector instructions per MFMA);
+//             K <= 192 is ONE k tile, so d is staged exactly once and x once per 128 output channels;
+//   step      32 frames = one v_mfma_f32_16x16x32_bf16 step: 320 rows x 32 frames = 10 x 16-byte loads per thread of a group;
+//   groups    a workgroup = 2 groups of 4 waves on the same tile, each with its own LDS image [3 planes][320 rows][32 frames + 8]
+//             bf16 (80-byte pitch: conflict-free ds_read_b128; 2 x 77 KB); the groups take alternate steps and run HALF A PERIOD apart
+//             (convwrw_tr.hip's schedule): while one multiplies (a wave owns 48 x 128 = 3 x 8 accumulator tiles: 144 MFMAs per
+//             step), the other splits its next step into planes and stores them into ITS image, then issues the loads of the step
+//             after that; one LDS-only barrier per half period, the loads stay in flight across it.  The first form of this kernel
+//             (one group, 192 x 192 tiles, the split interleaved with the MFMA groups, two barriers per step) left the matrix pipe
+//             idle while both waves of a SIMD stored planes and waited: 91 us for a flow block's six problems, this one 79;
 //   batch     up to 8 problems per launch, each with its own channel counts, strides, masks, two-source gradient; the tiles of all
 //             problems share the compute units: splits = CUs / (tiles of the batch), one round of workgroups.  A flow block's six
-//             1x1 weight gradients (3 two-source res/skip, last res/skip, start, end) are ONE launch of 9 tiles x 28 splits.
+//             1x1 weight gradients (3 two-source res/skip, last res/skip, start, end) are ONE launch of 15 tiles;
+//   epilogue  the two groups' sums meet in LDS, one set of float atomics per workgroup.
 // Arithmetic: the six bf16 x bf16 products per fp32 product of convgemm_split.hip (exact 3-plane split, fp32 accumulation).
 #include "convgemm_common.hpp"
 #include "split_planes.hpp"
@@ -297,7 +301,11 @@ int conv_wrw1_multi_dispatch(int n, const glowtts_wrw1_problem *pr, int B, int T
     P.exp = env_knob("GLOWTTS_WRW1_EXP", 0);
     P.steps_u = (T + 31) / 32;
     P.total_steps = B * P.steps_u;
-    int splits = env_knob("GLOWTTS_WRW1_CUS", w1_compute_units()) / tiles;
+    // split-K sized for HALF the compute units: every workgroup ends with 98 KB of float atomics (a tile is the whole problem, so
+    // splits x tiles x 98 KB leave the chip at ~1.3 TB/s whatever the kernel does), and the launch shares the GPU with the
+    // backward's chain on the other stream — alone the launch is faster on all CUs (79 against 117 us for a flow block's six
+    // problems), in the step it is not: 14.34 / 14.24 / 14.17 ms per step for 256 / 192 / 128 (tools/ab_flags.py envs=GLOWTTS_WRW1_CUS:..)
+    int splits = env_knob("GLOWTTS_WRW1_CUS", w1_compute_units() / 2) / tiles;
     if (splits >= 16 && env_knob("GLOWTTS_WRW1_XCD", 1)) splits &= ~7;      // (see the kernel's workgroup numbering)
     if (splits > P.total_steps) splits = P.total_steps;
     if (splits < 1) splits = 1;

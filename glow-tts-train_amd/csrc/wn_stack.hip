@@ -524,9 +524,7 @@ extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float
     WN_TRY(glowtts_chan_layernorm_bwd_ex(x, o, mask, drop_o, drop_scale, L->gamma1, stats1, dx1, dxa, drop_o ? d_o : nullptr,
                                          L->dgamma1, L->dbeta1, B, H, T, stream));
     const float *go = drop_o ? d_o : dxa;
-    // conv_o
-    WN_TRY(order_after(ms, ws));
-    WN_TRY(glowtts_conv_wrw(y_att, HT, go, HT, nullptr, nullptr, L->dwp_o, L->db_o, B, H, H, T, 1, 1, 0, wss));
+    // conv_o (its weight gradient joins those of q / k / v below: one multi-problem launch, csrc/convwrw1.hip)
     WN_TRY(glowtts_conv_fwd(go, HT, L->wb_o, nullptr, nullptr, nullptr, 0, dy_att, HT, B, H, H, T, 1, 1, 0, 0, 0, 0, stream));
     // attention
     WN_TRY(glowtts_rel_attn_bwd_ex(dy_att, q, k, v, L->emb_k, L->emb_v, mask, drop_a, drop_scale, p_attn, ds, dq, dkk, dv, L->demb_k,
@@ -534,9 +532,15 @@ extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float
     // q, k, v convs of x * mask: dx = dxa + mask * (Wq^T dq + Wk^T dk + Wv^T dv)
     WN_TRY(order_after(ms, ws));
     {
-        const float *bx[3] = {x, x, x}, *bd[3] = {dq, dkk, dv};
+        glowtts_wrw1_problem pr[4] = {};
+        const float *bd[3] = {dq, dkk, dv};
         float *bw[3] = {L->dwp_q, L->dwp_k, L->dwp_v}, *bb[3] = {L->db_q, L->db_k, L->db_v};
-        WN_TRY(glowtts_conv_wrw_batch(3, bx, HT, bd, HT, nullptr, 0, 0, nullptr, mask, bw, bb, B, H, H, T, 1, 1, 0, wss));
+        for (int j = 0; j < 3; ++j) {                 // q, k, v = conv(x * mask)
+            pr[j].x = x; pr[j].x_bs = HT; pr[j].Cin = H; pr[j].d = bd[j]; pr[j].d_bs = HT; pr[j].M = H; pr[j].mask_x = mask;
+            pr[j].dwp = bw[j]; pr[j].dbias = bb[j];
+        }
+        pr[3].x = y_att; pr[3].x_bs = HT; pr[3].Cin = H; pr[3].d = go; pr[3].d_bs = HT; pr[3].M = H; pr[3].dwp = L->dwp_o; pr[3].dbias = L->db_o;
+        WN_TRY(glowtts_conv_wrw1_multi(4, pr, B, T, wss));
     }
     // dxa is masked already and mask * mask = mask, so dxa + mask * S = mask * (dxa + S): the chain starts from dxa and the
     // last convolution masks the sum
