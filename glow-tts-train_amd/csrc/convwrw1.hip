@@ -43,8 +43,11 @@ struct Wrw1Params {
 int conv_math_wrw();             // convgemm_split.hip: planes per fp32 operand of the weight-gradient kernels (0 = native fp32)
 
 __device__ __forceinline__ void w1_store8(void *p, unsigned lo, unsigned hi) {      // (see lds_store8 in convgemm_split.hip)
+    // no "memory" clobber: the plane arithmetic of the other items may be scheduled around a store (with it every item's
+    // dependent split chain ran alone, ~8 cycles per instruction: the staging phase took 1.2 us per step).  Volatile asms keep
+    // their order among themselves, and the LDS-only barrier between a staging phase and the reads of the image does clobber memory.
     asm volatile("ds_write2_b32 %0, %1, %2 offset1:1"
-                 :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) void *)p), "v"(lo), "v"(hi) : "memory");
+                 :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) void *)p), "v"(lo), "v"(hi));
 }
 
 template <int NS>
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
     auto load_next = [&]() {
         const int s = s_begin + grp + 2 * ld_i;
         ++ld_i;
+        if ((P.exp & 8) && ld_i > 1) return;          // (timing experiment: no global loads after the first step)
         const int b = s / P.steps_u, t = (s - b * P.steps_u) * 32 + q * 4;
         const bool tok = t < T;
 #pragma unroll
