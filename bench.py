@@ -22,9 +22,12 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                      mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed PMC
                                         pass (profiles/r04_pmc.json), null when no pass exists for the kernel;
                    with GLOWTTS_CONV_MATH=fp32 the peak is the 157.3 TFLOP/s dense fp32 MFMA figure and all three coincide.
-                   "as_launched_in_the_step": the same kernel timed as the step launches it — the four layers' problems of a WN
-                   stack in one glowtts_conv_wrw_batch launch — microseconds per problem and the pipe fraction that gives
-                   (information beside `frac`, which stays the single launch of the instrumented pass).
+                   Round 4: `frac`, `achieved`, `mean_us` are those of the launch the step really makes — the four layers'
+                   problems of a WN stack in ONE glowtts_conv_wrw_batch launch (HIP events on its stream around back-to-back
+                   launches after the timed region; "as_launched_in_the_step" has the per-problem figures); the single-problem
+                   launch of the instrumented pass stays beside them as "single_launch".
+                   "wrw1_multi_as_launched_in_the_step": a flow block's six 1x1 weight gradients as the one
+                   glowtts_conv_wrw1_multi launch the step makes for them (csrc/convwrw1.hip).
                    "traffic" = HBM-side bytes per launch from the PMC passes.  Every MFMA kernel is listed with its
                    algorithmic bytes and FLOPs, its time at each roof and `bound: hbm|mfma` (the 1x1 convolutions are
                    byte-bound: they are reported against 8 TB/s, not as TFLOP/s alone); every streaming kernel with GB/s against
@@ -122,7 +125,9 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
 
 # bench tag -> (HIP kernel, grid size) of the committed counter passes, per arithmetic of the WN convolutions
 _PMC_KERNEL = {
-    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false> grid=129024",
+    # round 4: the launch the step makes — a WN stack's four problems sharing one round of 216 workgroups (the pre-net's single
+    # 5-tap problems have the same grid size: tools/rocpd_summary.py separates the two duration classes)
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false> grid=110592#long",
     ("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32"): "convwrw_fp_kernel<5,5,2> grid=196608",
     ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
     ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
@@ -146,9 +151,11 @@ def pmc_entry(kernel_tag, math="bf16x6+wrw"):
             continue
         if key in table:
             return dict(table[key], source="profiles/" + fn)
+        if "#long" in key:                         # the batched launch was never profiled before round 4: no older record applies
+            continue
         same = [k for k in table if k.split(" grid=")[0] == name]
         if same:                                   # same kernel, another grid size: the largest (the config-2 shape)
-            k = max(same, key=lambda k_: int(k_.split("grid=")[1]))
+            k = max(same, key=lambda k_: int(k_.split("grid=")[1].split("#")[0]))
             return dict(table[k], source="profiles/" + fn)
     return {}
 
@@ -218,6 +225,55 @@ def batched_wrw_time(tag, dev, n=4, iters=20):
     return {"problems_per_launch": n, "us_per_problem": round(us, 2),
             "frac_pipe": round(6.0 * flop / (us * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
             "note": "one glowtts_conv_wrw_batch launch per WN stack in the timed step; alone, back-to-back, distinct operands"}
+
+
+def wrw1_multi_time(args, dev, iters=20):
+    """`glowtts_conv_wrw1_multi` on a flow block's six 1x1 weight-gradient problems (three two-source res/skip gradients, the last
+    layer's, the end conv's, the start conv's) at the benchmark's shape, as the block executor launches them: HIP events on the
+    launch stream around back-to-back launches.  The kernel is bound by the rate at which a compute unit can take in its operands
+    (fp32 rows of x and d, x once per 128 output channels): both roofs are reported."""
+    import ctypes
+
+    from glow_tts_train import _hip
+
+    b, t, h, c = args.batch, args.t_mel // 2, 192, 160
+    specs = [(h, 2 * h, h, False, 0)] * 3 + [(h, h, 0, False, 0), (h, c, 0, False, 0), (c // 2, h, 0, True, c)]
+    probs = (_hip.Wrw1Problem * len(specs))()
+    keep = []
+    mask = torch.ones(b, t, device=dev)
+    flop = 0.0
+    alg_bytes = 0.0
+    for j, (cin, m, split, md, xw) in enumerate(specs):
+        x = torch.randn(b, xw or cin, t, device=dev)
+        d = torch.randn(b, split if split else m, t, device=dev)
+        d2 = torch.randn(b, m - split, t, device=dev) if split else None
+        dwp, dbias = torch.zeros(cin, m, device=dev), torch.zeros(m, device=dev)
+        q = probs[j]
+        q.x, q.d, q.d2 = x.data_ptr(), d.data_ptr(), (d2.data_ptr() if split else None)
+        q.mask_d, q.mask_x = (mask.data_ptr() if md else None), None
+        q.dwp, q.dbias = dwp.data_ptr(), dbias.data_ptr()
+        q.x_bs, q.d_bs, q.d2_bs = x.shape[1] * t, d.shape[1] * t, ((m - split) * t if split else 0)
+        q.Cin, q.M, q.d_split = cin, m, split
+        keep.append((x, d, d2, dwp, dbias))
+        flop += 2.0 * cin * m * b * t
+        alg_bytes += 4.0 * ((cin + m) * b * t + cin * m)
+    run = lambda: _hip.call("glowtts_conv_wrw1_multi", len(specs), ctypes.addressof(probs), b, t)   # noqa: E731
+    for _ in range(3):
+        run()
+    cur = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(cur)
+    for _ in range(iters):
+        run()
+    e1.record(cur)
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    return {"problems_per_launch": len(specs), "mean_us": round(us, 2), "alg_GFLOP": round(flop / 1e9, 3),
+            "alg_MB": round(alg_bytes / 1e6, 2),
+            "frac_pipe": round(6.0 * flop / (us * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+            "hbm_frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "one launch per flow block in the timed step (replaces one 3-problem batch and three single launches of the "
+                    "frame-packed kernel); split-K sized for half the CUs, as the step launches it; alone, back-to-back"}
 
 
 def decoder_alone(model, batch, cfg, n_iter=5):
@@ -660,9 +716,30 @@ def main():
                                    "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
                                    "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
                 try:        # the form the timed step launches: the four layers' problems of a WN stack in ONE launch (lesson 20)
-                    out["roofline"]["as_launched_in_the_step"] = batched_wrw_time(dom, dev)
+                    bt = batched_wrw_time(dom, dev)
+                    rf = out["roofline"]
+                    rf["as_launched_in_the_step"] = bt
+                    # Round 4: the step no longer makes the single launch the instrumented pass times — every WN
+                    # stack's four 5-tap weight gradients are ONE launch whose problems share a round of workgroups.  `frac`,
+                    # `achieved` and `mean_us` are that launch's (four problems' FLOPs over its duration, HIP events on its stream);
+                    # the single-problem launch stays beside them.
+                    rf["single_launch"] = {"mean_us": rf["mean_us"], "frac_pipe": rf["frac_pipe"], "frac_algorithmic": rf["frac_algorithmic"],
+                                           "fp32_equivalent_TFLOPs": rf["fp32_equivalent_TFLOPs"]}
+                    n_p, us_l = bt["problems_per_launch"], bt["us_per_problem"] * bt["problems_per_launch"]
+                    tf = (n_p * mfma[dom]["alg_GFLOP"] * 1e9) / (us_l * 1e-6) / 1e12      # fp32-equivalent TFLOP/s of the launch
+                    rf.update(kernel=dom + f" x{n_p} (one glowtts_conv_wrw_batch launch, as the step makes it)",
+                              achieved=round(6.0 * tf, 2), frac=6.0 * tf / BF16_MFMA_PEAK_TFLOPS,
+                              frac_pipe=round(6.0 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                              frac_algorithmic=round(tf / BF16_MFMA_PEAK_TFLOPS, 4), mean_us=round(us_l, 2),
+                              alg_GFLOP=round(n_p * mfma[dom]["alg_GFLOP"], 3), alg_MB=round(n_p * mfma[dom]["alg_MB"], 2),
+                              fp32_equivalent_TFLOPs=round(tf, 2),
+                              fp32_equivalent_vs_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
                 except Exception as exc:
                     log(f"batched weight-gradient timing failed ({type(exc).__name__}: {exc})")
+                try:        # the flow block's six 1x1 weight gradients: one multi-problem launch (csrc/convwrw1.hip)
+                    out["roofline"]["wrw1_multi_as_launched_in_the_step"] = wrw1_multi_time(args, dev)
+                except Exception as exc:
+                    log(f"multi-problem 1x1 weight-gradient timing failed ({type(exc).__name__}: {exc})")
             else:
                 fr = mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
                 out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
