@@ -46,7 +46,7 @@ def test_cabi_argument_errors_do_not_need_a_gpu():
     assert rc != 0 and b"null pointer" in lib.glowtts_last_error()
     rc = lib.glowtts_mas_path(1, 1, 1, 1, 1, 2100, 10, None)          # non-null dummies; Tx over the limit
     assert rc != 0 and b"2048" in lib.glowtts_last_error()
-    rc = lib.glowtts_invconv_fwd(1, 1, 1, None, None, 1, None, 1, 12, 4, 6, None)
+    rc = lib.glowtts_invconv_fwd(1, 1, 1, None, None, 1, None, 1, 12, 4, 3, None)      # odd group size (layers.py:227)
     assert rc != 0 and b"n_split" in lib.glowtts_last_error()
     assert lib.glowtts_actnorm_fwd(1, 1, 1, 1, None, 1, None, 0, 4, 0, 0, None) == 0   # empty batch: no launch
 
