@@ -160,6 +160,30 @@ def pmc_entry(kernel_tag, math="bf16x6+wrw"):
     return {}
 
 
+def subset_from_kernel_trace(sub_bytes, survey_gb, blocks):
+    """The invertible subset's kernels in the committed rocprofv3 kernel trace (profiles/r04_kernel_stats.csv: average dispatch
+    duration over the step's launches, one launch of each per flow block and direction): ms per step and the fractions of 8 TB/s that
+    gives — beside the HIP-event figures of this run, which include each launch's latency."""
+    import csv
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    names = ("actnorm_invconv_fwd_kernel", "actnorm_invconv_bwd_kernel", "coupling_fwd_kernel", "coupling_bwd_kernel")
+    try:
+        rows = list(csv.DictReader(open(os.path.join(here, "profiles", "r04_kernel_stats.csv"))))
+    except Exception:
+        return None
+    us = {}
+    for r in rows:
+        for n in names:
+            if "glowtts::" + n + "<" in r["Name"] and n not in us:
+                us[n] = float(r["AverageNs"]) / 1e3
+    if len(us) != len(names):
+        return None
+    ms = sum(us.values()) * blocks / 1e3
+    return {"source": "profiles/r04_kernel_stats.csv", "mean_us": {k: round(v, 2) for k, v in us.items()}, "ms_per_step": round(ms, 3),
+            "frac": round(sub_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "survey_frac": round(survey_gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+
+
 def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
     e = pmc_entry(kernel_tag, math)
     if "traffic_bytes" in e:
@@ -762,7 +786,10 @@ def main():
                                   # the un-fused per-flow byte count (6.5 C e per column per block,
                                   # x3 for fwd+bwd) over the measured subset time -- fusing flows lowers the time only
                                   "survey_alg_GB": round(survey_gb, 3),
-                                  "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None},
+                                  "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None,
+                                  # HIP events around a 6-15 us launch include its launch latency (~4 us); the committed
+                                  # rocprofv3 kernel trace of this same command times the kernels themselves
+                                  "rocprofv3": subset_from_kernel_trace(sub_bytes, survey_gb, args.blocks)},
             "step_ms": round(ms_per_step, 3),
             "decoder": dec,
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
