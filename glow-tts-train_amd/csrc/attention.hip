@@ -15,7 +15,8 @@
 // relative-value term); phase 2 becomes the softmax backward dS = P (dP - sum_j P dP) * keep/scale; B2 = K, E2 = E_k
 // give dQ; dS is written to HBM for the second half (attn_dkv_kernel: dV = dO Pd, dK = Q dS, contraction over
 // queries) and for the two small embedding-gradient reductions (attn_relgrad_kernel).
-// Limits: T <= 512 (T > 256: the LONG form below), d_k % 16 == 0, d_k <= 128, window <= 7.
+// Limits: d_k % 16 == 0, d_k <= 128, window <= 7.  T <= 256: strip in LDS; 256 < T <= 512: the LONG form below (strip in registers);
+// T > 512: attention_long.hip (plain tiled kernels through the (B, h, T, T) matrices; the backward's dK / dV kernel here has no limit).
 #include "common.hpp"
 
 namespace glowtts {
@@ -808,9 +809,18 @@ __global__ __launch_bounds__(256) void attn_relgrad_kernel(const float *__restri
     }
 }
 
+// attention_long.hip: the same arithmetic beyond the strip kernels' 512 tokens (plain tiled kernels through p_attn / ds)
+int attn_long_forward(const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v, const float *mask,
+                      const unsigned char *drop, float drop_scale, float *p_attn, float *out, int B, int H, int T, int dk, int w,
+                      int e_hs, int block_len, float scale, hipStream_t s);
+int attn_long_backward(const float *dout, const float *q, const float *k, const float *v, const float *emb_k, const float *emb_v,
+                       const float *mask, const unsigned char *drop, float drop_scale, const float *p_attn, float *ds, float *dq,
+                       float *demb_k, float *demb_v, int B, int H, int T, int dk, int w, int e_hs, int block_len, float scale,
+                       bool relgrad, hipStream_t s);
+constexpr int kAttnStripMaxT = 512;
+
 static int attn_check(const char *name, int B, int H, int T, int dk, int w) {
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && dk > 0, "%s: bad shape", name);
-    GLOWTTS_CHECK_ARG(T <= 512, "%s: T=%d exceeds the 512-token limit of this build", name, T);
     GLOWTTS_CHECK_ARG(dk % 16 == 0 && dk <= 128, "%s: head width %d must be a multiple of 16 and <= 128", name, dk);
     GLOWTTS_CHECK_ARG(w <= 7, "%s: window %d > 7", name, w);
     return 0;
@@ -858,6 +868,9 @@ extern "C" int glowtts_rel_attn_fwd_ex(const float *q, const float *k, const flo
     p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
     p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
     p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
+    if (T > kAttnStripMaxT)
+        return attn_long_forward(q, k, v, emb_k, emb_v, mask, drop, drop_scale, p_attn, out, B, H, T, dk, window, p.e_hs, block_len,
+                                 p.scale, (hipStream_t)stream);
     return bf16_mma ? attn_launch<0, true>(p, (hipStream_t)stream) : attn_launch<0, false>(p, (hipStream_t)stream);
 }
 
@@ -885,7 +898,12 @@ extern "C" int glowtts_rel_attn_bwd_ex(const float *dout, const float *q, const 
     p.B = B; p.H = H; p.T = T; p.dk = dk; p.w = emb_k ? window : -1; p.block_len = block_len;
     p.e_hs = heads_share ? 0 : (2 * window + 1) * dk;
     p.scale = 1.0f / sqrtf((float)dk); p.drop_scale = drop_scale;
-    if (int rc = bf16_mma ? attn_launch<1, true>(p, s) : attn_launch<1, false>(p, s)) return rc;
+    const bool long_form = T > kAttnStripMaxT;
+    if (long_form) {
+        if (int rc = attn_long_backward(dout, q, k, v, emb_k, emb_v, mask, drop, drop_scale, p_attn, ds, dq, demb_k, demb_v, B, H, T, dk,
+                                        window, p.e_hs, block_len, p.scale, true, s))
+            return rc;
+    } else if (int rc = bf16_mma ? attn_launch<1, true>(p, s) : attn_launch<1, false>(p, s)) return rc;
     AttnDkvParams d{};
     d.dout = dout; d.q = q; d.p = p_attn; d.ds = ds; d.drop = drop; d.dv = dv; d.dkk = dk_out;
     d.B = B; d.H = H; d.T = T; d.dk = dk; d.drop_scale = drop_scale;
@@ -904,7 +922,7 @@ extern "C" int glowtts_rel_attn_bwd_ex(const float *dout, const float *q, const 
             else hipLaunchKernelGGL((attn_dkv_kernel<false, 0>), grid, dim3(256), lds, s, d);
         }
     }
-    if (emb_k) {
+    if (emb_k && !long_form) {
         const int nr = 2 * window + 1;
         int DC = (256 / nr) & ~7;                      // one (r, d) output per thread, slab rows a multiple of 8
         if (DC > dk) DC = dk;

@@ -177,10 +177,11 @@ class MultiHeadAttention(nn.Module):
         return convops.conv1d(self.conv_o, y)
 
     def _kernel_applicable(self, query, key, mask):
-        """The MFMA kernel covers self-attention with a (B,1,T,T) mask that is an outer product of a sequence mask
-        (what Encoder builds, attentions.py:63), T <= 512, d_k a multiple of 16 (<= 128), window <= 7, no proximal bias."""
+        """The HIP kernels cover self-attention with a (B,1,T,T) mask that is an outer product of a sequence mask
+        (what Encoder builds, attentions.py:63), any length (MFMA strip kernels up to 512 tokens, tiled kernels beyond:
+        csrc/attention_long.hip), d_k a multiple of 16 (<= 128), window <= 7, no proximal bias."""
         t = key.size(2)
-        return (query.is_cuda and query.size(2) == t and t <= 512 and self.k_channels % 16 == 0 and self.k_channels <= 128
+        return (query.is_cuda and query.size(2) == t and self.k_channels % 16 == 0 and self.k_channels <= 128
                 and (self.window_size is None or self.window_size <= 7) and not self.proximal_bias and mask is not None
                 and mask.dim() == 4 and mask.size(1) == 1)
 
@@ -198,13 +199,13 @@ class MultiHeadAttention(nn.Module):
             MultiHeadAttention._warned_general = True
             import logging
             logging.getLogger("glow_tts_train.attentions").warning(
-                "MultiHeadAttention: shape outside the MFMA kernel's envelope (T=%d > 512, d_k=%d, window=%s, cross-attention "
-                "or proximal bias): using the composition of PyTorch ops (slower; still on the GPU)", key.size(2),
-                self.k_channels, self.window_size)
+                "MultiHeadAttention: shape outside the HIP kernels' envelope (T=%d, d_k=%d not a multiple of 16 or > 128, "
+                "window=%s > 7, cross-attention or proximal bias): using the composition of PyTorch ops (slower; still on the "
+                "GPU)", key.size(2), self.k_channels, self.window_size)
         return self._attention_general(query, key, value, mask)
 
     def _attention_general(self, query, key, value, mask=None):
-        """Shapes outside the kernel's envelope (cross-attention, T > 512, proximal bias): torch ops, index-based."""
+        """Shapes outside the kernels' envelope (cross-attention, proximal bias, odd head widths): torch ops, index-based."""
         b, d, t_s = key.size()
         t_t = query.size(2)
         nh, dk, w = self.n_heads, self.k_channels, self.window_size

@@ -1171,7 +1171,7 @@ def encoder_layer_eligible(group, attn, ffn, norm1, norm2, x) -> bool:
     if not group.active or group.modules != [attn.conv_q, attn.conv_k, attn.conv_v, attn.conv_o, ffn.conv_1, ffn.conv_2]:
         return False
     t = x.size(2)
-    if not (t <= 512 and attn.k_channels % 16 == 0 and attn.k_channels <= 128 and (attn.window_size is None or attn.window_size <= 7)
+    if not (attn.k_channels % 16 == 0 and attn.k_channels <= 128 and (attn.window_size is None or attn.window_size <= 7)
             and not attn.proximal_bias and ffn.activation is None and ffn.kernel_size % 2 == 1):
         return False
     if attn.conv_o.weight.shape[0] != attn.channels or any(c.bias is None for c in group.modules):

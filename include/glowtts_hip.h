@@ -536,7 +536,9 @@ int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const void *x, cons
  * drop_scale, or NULL.  p_attn (B, H, T, T) receives softmax(P) BEFORE dropout (saved for the backward).
  * fwd : scores = (q_i.k_j + q_i.emb_k[j-i+w]) / sqrt(dk) ; out_i = sum_j Pd_ij v_j + sum_r Pd[i][i+r-w] emb_v[r]
  * bwd : dq, dk, dv (B, H*dk, T) written; demb_k / demb_v accumulated; ds (B, H, T, T) is scratch (scaled score grads).
- * Limits: T <= 256, dk % 16 == 0, dk <= 128, window <= 7.
+ * Limits: dk % 16 == 0, dk <= 128, window <= 7; any T: MFMA kernels with the 64-query score strip on the chip up to 512 tokens
+ * (in LDS to 256, in registers to 512), plain tiled kernels through p_attn / ds beyond (csrc/attention_long.hip; the bf16_mma
+ * switch of the _ex forms has no effect there).
  * The `_ex` forms take bf16_mma: 0 = exactly the functions above (v_mfma_f32_16x16x4_f32); 1 = the contractions
  * (q k^T, q emb_k^T, P v, P_w emb_v, and dP, dq, dk, dv in the backward) on v_mfma_f32_16x16x16_bf16 with fp32
  * accumulation — operands are rounded to bf16 (nearest even) in registers as they leave LDS; q, k, v, p_attn, the

@@ -919,7 +919,8 @@ def test_wn_dropout_path_matches_manual_mask(G):
         assert_close(named[k].grad, vref.grad, what="grad " + k, rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("t,lens", [(50, (50, 31, 7)), (300, (300, 211, 64))], ids=["t50", "t300-long-form"])
+@pytest.mark.parametrize("t,lens", [(50, (50, 31, 7)), (300, (300, 211, 64)), (640, (640, 513, 90))],
+                         ids=["t50", "t300-long-form", "t640-beyond-the-strips"])
 def test_attention_dropout_matches_manual_mask(G, t, lens):
     """Training-mode attention dropout (attentions.py:251): the kernel's keep-mask read back (ops.keep_mask_tap) and handed to the
     index-based torch composition (ops.keep_mask_inject) — outputs and every gradient agree."""
@@ -959,7 +960,9 @@ def test_attention_dropout_matches_manual_mask(G, t, lens):
 @pytest.mark.parametrize("t,ch,win,blk", [(160, 192, 4, None), (256, 64, 7, None), (200, 32, 4, 20), (33, 256, 2, None),
                                           (240, 192, 4, None), (256, 192, 7, None),      # config 5 / the short form's limit
                                           (257, 192, 4, None), (300, 192, 7, 30), (384, 64, 4, None), (500, 32, 2, None),
-                                          (512, 192, 7, None)])                          # the LONG form: 256 < T <= 512
+                                          (512, 192, 7, None),                           # the LONG form: 256 < T <= 512
+                                          (513, 32, 2, None), (600, 192, 4, None), (777, 64, 7, 50),
+                                          (1024, 192, 4, None)])                         # beyond the strips: csrc/attention_long.hip
 def test_attention_kernel_vs_general_path(G, t, ch, win, blk):
     torch.manual_seed(t)
     b = 2
