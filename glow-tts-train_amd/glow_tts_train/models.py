@@ -21,6 +21,8 @@ from .optimize import OptimizerType
 from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 
 _actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
+_flow_stack_apply = _hip.direct_apply(convops.FlowStackFn)
+_FLOW_STACK = __import__("os").environ.get("GLOWTTS_FLOW_STACK", "1") != "0"
 _flow_block_apply = _hip.direct_apply(convops.FlowBlockFn)
 _align_expand_apply = _hip.direct_apply(ops.AlignExpandFn)
 _embed_apply = _hip.direct_apply(convops.EmbedFn)
@@ -176,6 +178,36 @@ class FlowSpecDecoder(nn.Module):
             return 0
         return 1 if self.io_bf16 == "hidden" else 3
 
+    def _stack_args(self, x, g, io, blocks, m2):
+        """Arguments of convops.FlowStackFn when EVERY block of the decoder can share one autograd node: the standard
+        [ActNorm, InvConvNear, CouplingBlock] layout, fp32 tensors, no conditioning input, every block eligible for the native
+        executors with one common shape.  GLOWTTS_FLOW_STACK=0 keeps one node per block."""
+        if io or g is not None or not _FLOW_STACK or not blocks:
+            return None
+        trip = self._blocks()
+        if not trip:
+            return None
+        wn0 = blocks[0].wn
+        cfg = None
+        bplans, counts, params = [], [], []
+        for a, inv, c in trip:
+            if not convops.flow_block_eligible(a, inv, c, x, g):
+                return None
+            wn = c.wn
+            k = (inv.n_split, bool(c.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0, wn.dilation_rate, wn.n_layers,
+                 wn.hidden_channels)
+            if cfg is None:
+                cfg = k
+            elif k != cfg or wn.kernel_size != wn0.kernel_size:
+                return None
+            if not hasattr(c, "_block_plan"):
+                c._block_plan = convops.FlowBlockPlan()
+            pk = convops.flow_block_params(a, inv, c)
+            bplans.append(c._block_plan)
+            counts.append(len(pk))
+            params.extend(pk)
+        return cfg, bplans, counts, params
+
     def forward(self, x, x_mask, g=None, reverse=False):
         io = self._use_bf16(x, g, reverse)
         flow16 = bool(io & 2)
@@ -194,6 +226,7 @@ class FlowSpecDecoder(nn.Module):
             # dropout keep-masks of EVERY coupling block's WN stack from one generator launch (12 launches of 20 MB each
             # sat on the forward's dependency chain: 0.26 ms per step); block k takes slice k
             blocks = [f for f in self.flows if isinstance(f, CouplingBlock)]
+            masks = None
             if (x.is_cuda and self.training and blocks and self.p_dropout > 0
                     and all(f.wn.n_layers == blocks[0].wn.n_layers and f.wn.hidden_channels == blocks[0].wn.hidden_channels
                             and f.wn.p_dropout == blocks[0].wn.p_dropout and f.wn.training for f in blocks)):
@@ -202,6 +235,15 @@ class FlowSpecDecoder(nn.Module):
                                       float(wn0.p_dropout), x.device, "decoder.wn")
                 for k, f in enumerate(blocks):
                     f.wn._drop_pre = masks[k]
+            stack = self._stack_args(x, g, io, blocks, m2)
+            if stack is not None:                      # every block in ONE autograd node (convops.FlowStackFn)
+                cfg, bplans, counts, params = stack
+                for f in blocks:
+                    f.wn._drop_pre = None
+                x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, *params)
+                if self.n_sqz > 1:
+                    x, x_mask = unsqueeze(x, x_mask, self.n_sqz, io_bf16=flow16)
+                return x, logdet_tot
             i = 0
             while i < len(self.flows):
                 f = self.flows[i]

@@ -1345,11 +1345,15 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
     s = torch.randn(b, device="cuda")
     res = {}
     used = {}
-    orig = convops.FlowBlockFn.forward
-    for mode in ("both", "fwd"):                       # "fwd": the block executor declines, per-op path runs
-        convops._WN_NATIVE = mode
-        calls = []
+    orig, orig_stack = convops.FlowBlockFn.forward, convops.FlowStackFn.forward
+    # "stack": every block in ONE autograd node (convops.FlowStackFn; not with conditioning rows); "both": one node per block;
+    # "fwd": the block executor declines, the per-operator path runs
+    for mode in ("stack", "both", "fwd"):
+        convops._WN_NATIVE = "both" if mode == "stack" else mode
+        G.models._FLOW_STACK = mode == "stack"
+        calls, stack_calls = [], []
         convops.FlowBlockFn.forward = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
+        convops.FlowStackFn.forward = staticmethod(lambda *a, _o=orig_stack, _c=stack_calls: (_c.append(1), _o(*a))[1])
         try:
             for p in dec.parameters():
                 p.grad = torch.zeros_like(p)
@@ -1362,20 +1366,24 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
             torch.cuda.synchronize()
         finally:
             convops._WN_NATIVE = "both"
+            G.models._FLOW_STACK = True
             convops.FlowBlockFn.forward = orig
-        used[mode] = len(calls)
+            convops.FlowStackFn.forward = orig_stack
+        used[mode] = (len(calls), len(stack_calls))
         grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
         if gg is not None:
             grads["<speaker rows g>"] = gg.grad.clone()
         res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), grads)
-    assert used["both"] == blocks and used["fwd"] == 0, used
-    z1, l1, dx1, g1 = res["both"]
+    assert used["both"] == (blocks, 0) and used["fwd"] == (0, 0), used
+    assert used["stack"] == ((0, 1) if gin == 0 else (blocks, 0)), used          # conditioning rows: one node per block
     z0, l0, dx0, g0 = res["fwd"]
-    assert_close(z1, z0, what="z", rtol=1e-6, atol=1e-6)
-    assert_close(l1, l0, what="logdet", rtol=1e-6, atol=1e-4)
-    assert_close(dx1, dx0, what="dx", rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
-    for k in g0:
-        assert_close(g1[k], g0[k], what=f"grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
+    for mode in ("both", "stack"):
+        z1, l1, dx1, g1 = res[mode]
+        assert_close(z1, z0, what=f"{mode}: z", rtol=1e-6, atol=1e-6)
+        assert_close(l1, l0, what=f"{mode}: logdet", rtol=1e-6, atol=1e-4)
+        assert_close(dx1, dx0, what=f"{mode}: dx", rtol=1e-4, atol=1e-5 * float(dx0.abs().max()))
+        for k in g0:
+            assert_close(g1[k], g0[k], what=f"{mode}: grad {k}", rtol=2e-4, atol=2e-5 * max(1.0, float(g0[k].abs().max())))
 
 
 @pytest.mark.usefixtures("conv_mode")
