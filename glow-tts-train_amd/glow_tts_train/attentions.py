@@ -17,6 +17,8 @@ from .layers import WN, LayerNorm
 _coupling_apply = direct_apply(ops.CouplingFn)
 _rel_attn_apply = direct_apply(ops.RelAttnFn)
 _enc_layer_apply = direct_apply(convops.EncoderLayerFn)
+_enc_stack_apply = direct_apply(convops.EncoderStackFn)
+_ENC_STACK = __import__("os").environ.get("GLOWTTS_ENC_STACK", "1") != "0"
 
 
 class Encoder(nn.Module):
@@ -63,6 +65,18 @@ class Encoder(nn.Module):
             keep = None
             if p > 0.0:
                 keep = ops.keep_mask((len(layers) * sum(sizes),), p, x.device, "encoder.layers")
+            if _ENC_STACK and len({(f.kernel_size, f.filter_channels, a.window_size, a.heads_share, a.block_length, n.eps)
+                                   for _, a, f, n, _ in layers}) == 1:
+                # every layer in ONE autograd node (convops.EncoderStackFn)
+                _, attn, ffn, norm1, _ = layers[0]
+                cfg = (nh, ffn.kernel_size, -1 if attn.window_size is None else attn.window_size, int(attn.heads_share),
+                       -1 if attn.block_length is None else attn.block_length, norm1.eps, p)
+                counts, params = [], []
+                for mods in layers:
+                    _, live = convops._enc_layer_table(*mods)
+                    counts.append(len(live))
+                    params.extend(live)
+                return _enc_stack_apply(x, m2, keep, cfg, layers, counts, *params) * x_mask
             pos = 0
             for group, attn, ffn, norm1, norm2 in layers:
                 drops = None

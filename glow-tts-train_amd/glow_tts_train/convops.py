@@ -1308,6 +1308,113 @@ def encoder_layer_eligible(group, attn, ffn, norm1, norm2, x) -> bool:
     return all(p.requires_grad and p.grad is not None and p.grad.is_contiguous() for p in params)
 
 
+class EncoderStackFn(Function):
+    """ALL post-LN transformer layers of the text encoder (reference attentions.py:63-73: the loop over the layers) as ONE
+    autograd node (round 4): EncoderLayerFn's native call per layer, but one activation buffer, one workspace, one saved-tensor
+    list and one node for the stack — the layers' slices are addressed by pointer arithmetic.  `keep`: the byte keep-masks of all
+    four dropouts of all layers, laid out layer by layer as [attention (B,h,T,T) | branch 1 (B,H,T) | FFN (B,F,T) | branch 2
+    (B,H,T)], or None."""
+
+    @staticmethod
+    def forward(ctx, x, m2, keep, cfg, layers, counts, *params):
+        import ctypes
+        heads, taps, window, share, blk, eps, p_drop = cfg
+        nl = len(layers)
+        x = f32(x.contiguous())
+        B, H, T = x.shape
+        F_ = layers[0][2].filter_channels
+        dev = x.device
+        n_ht, n_ft, n_tt = B * H * T, B * F_ * T, B * heads * T * T
+        per = 8 * n_ht + n_ft + n_tt + 4 * B * T                  # floats of one layer's activations (EncoderLayerFn's layout)
+        buf = torch.empty(nl, per, device=dev, dtype=torch.float32)
+        scale = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
+        pk_, pb, px, pm = ptr(keep), ptr(buf), ptr(x), ptr(m2)
+        ksz = n_tt + n_ht + n_ft + n_ht                            # keep bytes of one layer
+        o_q, o_k, o_v, o_ya, o_o, o_x1, o_y2, o_x2 = (4 * j * n_ht for j in range(8))
+        o_h = 4 * 8 * n_ht
+        o_p = o_h + 4 * n_ft
+        o_s1 = o_p + 4 * n_tt
+        o_s2 = o_s1 + 4 * 2 * B * T
+        for l, (group, attn, ffn, norm1, norm2) in enumerate(layers):
+            tab, _ = _enc_layer_table(group, attn, ffn, norm1, norm2)
+            base = pb + 4 * l * per
+            xin = px if l == 0 else pb + 4 * (l - 1) * per + o_x2
+            kb = None if pk_ is None else pk_ + l * ksz
+            bound = group.plan.bind()                    # the FFN convolutions take the group's bf16 planes (conv arithmetic)
+            try:
+                call("glowtts_encoder_layer_fwd", ctypes.addressof(tab), xin, pm, kb, None if kb is None else kb + n_tt,
+                     None if kb is None else kb + n_tt + n_ht, None if kb is None else kb + n_tt + n_ht + n_ft, scale,
+                     base + o_q, base + o_k, base + o_v, base + o_p, base + o_ya, base + o_o, base + o_x1, base + o_s1, base + o_h,
+                     base + o_y2, base + o_x2, base + o_s2, B, H, F_, T, heads, taps, window, share, blk, float(eps))
+            finally:
+                WNPackPlan.unbind(bound)
+            attn.attn = buf[l, (o_p // 4): (o_p // 4) + n_tt].view(B, heads, T, T).detach()
+        ctx.save_for_backward(x, m2, buf, *([] if keep is None else [keep]))
+        ctx.cfg, ctx.layers, ctx.counts, ctx.dims, ctx.scale, ctx.params = cfg, layers, counts, (B, H, F_, T), scale, params
+        return buf[nl - 1, (o_x2 // 4): (o_x2 // 4) + n_ht].view(B, H, T)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dx_out):
+        import ctypes
+        heads, taps, window, share, blk, eps, p_drop = ctx.cfg
+        layers, counts, params = ctx.layers, ctx.counts, ctx.params
+        nl = len(layers)
+        B, H, F_, T = ctx.dims
+        sv = ctx.saved_tensors
+        x, m2, buf = sv[:3]
+        keep = sv[3] if len(sv) > 3 else None
+        dev = x.device
+        n_ht, n_ft, n_tt = B * H * T, B * F_ * T, B * heads * T * T
+        per = 8 * n_ht + n_ft + n_tt + 4 * B * T
+        wper = 10 * n_ht + n_ft + n_tt                            # floats of one layer's backward workspace
+        ws = torch.empty(nl, wper, device=dev, dtype=torch.float32)
+        dx_out = f32(dx_out.contiguous())
+        wgrad = _WgradStream(dev)
+        wgrad.enabled = wgrad.enabled and _ENC_WGRAD          # (see EncoderLayerFn.backward: the weight gradients stay on this stream)
+        pk_, pb, px, pm, pw, pdo = ptr(keep), ptr(buf), ptr(x), ptr(m2), ptr(ws), ptr(dx_out)
+        ksz = n_tt + n_ht + n_ft + n_ht
+        o_q, o_k, o_v, o_ya, o_o, o_x1, o_y2, o_x2 = (4 * j * n_ht for j in range(8))
+        o_h = 4 * 8 * n_ht
+        o_p = o_h + 4 * n_ft
+        o_s1 = o_p + 4 * n_tt
+        o_s2 = o_s1 + 4 * 2 * B * T
+        w_dx1a, w_dy2, w_dx1, w_dxa, w_do, w_dya, w_dq, w_dk, w_dv, w_dx = (4 * j * n_ht for j in range(10))
+        w_dpre = 4 * 10 * n_ht
+        w_ds = w_dpre + 4 * n_ft
+        side = wgrad.side.cuda_stream if wgrad.enabled else None
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        if wgrad.enabled:
+            for t in (x, buf, ws, dx_out):
+                t.record_stream(wgrad.side)
+        for l in range(nl - 1, -1, -1):
+            group, attn, ffn, norm1, norm2 = layers[l]
+            tab, live = _enc_layer_table(group, attn, ffn, norm1, norm2)
+            base, wb = pb + 4 * l * per, pw + 4 * l * wper
+            xin = px if l == 0 else pb + 4 * (l - 1) * per + o_x2
+            din = pdo if l == nl - 1 else pw + 4 * (l + 1) * wper + w_dx
+            kb = None if pk_ is None else pk_ + l * ksz
+            bound = group.plan.bind()
+            try:
+                call("glowtts_encoder_layer_bwd", ctypes.addressof(tab), xin, pm, kb, None if kb is None else kb + n_tt,
+                     None if kb is None else kb + n_tt + n_ht, None if kb is None else kb + n_tt + n_ht + n_ft, ctx.scale,
+                     base + o_q, base + o_k, base + o_v, base + o_p, base + o_ya, base + o_o, base + o_x1, base + o_s1, base + o_h,
+                     base + o_y2, base + o_s2, din, wb + w_dx1a, wb + w_dy2, wb + w_dpre, wb + w_dx1, wb + w_dxa, wb + w_do,
+                     wb + w_dya, wb + w_ds, wb + w_dq, wb + w_dk, wb + w_dv, wb + w_dx, B, H, F_, T, heads, taps, window, share,
+                     blk, side)
+            finally:
+                WNPackPlan.unbind(bound)
+            _mark_direct(live, True)
+            if wgrad.enabled:
+                with torch.cuda.stream(wgrad.side):
+                    _notify(live)
+            else:
+                _notify(live)
+        return (ws[0, (w_dx // 4): (w_dx // 4) + n_ht].view(B, H, T), None, None, None, None, None) + (None,) * len(params)
+
+
 class EncoderLayerFn(Function):
     """One post-LN transformer layer of the text encoder (reference attentions.py:63-73, 204-264, 373-381) as ONE autograd
     node: forward and backward are one native call each (csrc/wn_stack.hip: glowtts_encoder_layer_fwd / _bwd)."""

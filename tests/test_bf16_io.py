@@ -378,8 +378,9 @@ def test_encoder_layer_executor_honours_bf16_mma(G):
     mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
     r = torch.randn(b, hch, t, device="cuda")
     out, calls = {}, []
-    orig = convops.EncoderLayerFn.forward
+    orig, orig_stack = convops.EncoderLayerFn.forward, convops.EncoderStackFn.forward
     convops.EncoderLayerFn.forward = staticmethod(lambda *a, _o=orig: (calls.append(1), _o(*a))[1])
+    convops.EncoderStackFn.forward = staticmethod(lambda *a, _o=orig_stack: (calls.extend([1] * nl), _o(*a))[1])
     try:
         for flag in (False, True):
             for m in enc.attn_layers:
@@ -395,7 +396,8 @@ def test_encoder_layer_executor_honours_bf16_mma(G):
             out[flag] = [y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
     finally:
         convops.EncoderLayerFn.forward = orig
-    assert len(calls) == 2 * nl, "the layer executor did not run"
+        convops.EncoderStackFn.forward = orig_stack
+    assert len(calls) == 2 * nl, "the layer / stack executor did not run"
     gmax = max(float(e.abs().max()) for e in out[False][2:])
     names = ["y", "dx"] + [k for k, _ in enc.named_parameters()]
     errs = {n: rel_err(a, e) for n, a, e in zip(names, out[True], out[False])

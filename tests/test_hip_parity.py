@@ -1269,8 +1269,9 @@ def test_encoder_layer_executor_vs_torch_and_per_op_path(G, b, hch, fch, t, nl, 
     mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().unsqueeze(1)
     r = torch.randn(b, hch, t, device="cuda")
 
-    def run(native):
+    def run(native, stack=True):
         convops._WN_NATIVE = "both" if native else "fwd"
+        G.attentions._ENC_STACK = stack
         opt.zero_grad()
         for g in groups:
             g.begin()
@@ -1281,16 +1282,25 @@ def test_encoder_layer_executor_vs_torch_and_per_op_path(G, b, hch, fch, t, nl, 
         convops.flush_groups()
         torch.cuda.synchronize()
         convops._WN_NATIVE = "both"
+        G.attentions._ENC_STACK = True
         return y.detach().clone(), x.grad.clone(), {k_: p_.grad.clone() for k_, p_ in enc.named_parameters()}
 
-    calls = []
-    orig = convops.EncoderLayerFn.forward
+    calls, stack_calls = [], []
+    orig, orig_stack = convops.EncoderLayerFn.forward, convops.EncoderStackFn.forward
     convops.EncoderLayerFn.forward = staticmethod(lambda *a, _o=orig: (calls.append(1), _o(*a))[1])
+    convops.EncoderStackFn.forward = staticmethod(lambda *a, _o=orig_stack: (stack_calls.append(1), _o(*a))[1])
     try:
-        y1, dx1, g1 = run(True)
+        y1, dx1, g1 = run(True)                              # every layer in ONE autograd node (convops.EncoderStackFn)
+        assert (len(calls), len(stack_calls)) == (0, 1), "the stack executor did not run"
+        y2, dx2, g2 = run(True, stack=False)                 # one node per layer: the same launches
+        assert (len(calls), len(stack_calls)) == (nl, 1), "the layer executor did not run"
     finally:
         convops.EncoderLayerFn.forward = orig
-    assert len(calls) == nl, "the layer executor did not run"
+        convops.EncoderStackFn.forward = orig_stack
+    assert_close(y2, y1, what="y: layer nodes vs stack node", rtol=1e-6, atol=1e-6)
+    assert_close(dx2, dx1, what="dx: layer nodes vs stack node", rtol=1e-5, atol=1e-6 * float(dx1.abs().max()))
+    for k_ in g1:
+        assert_close(g2[k_], g1[k_], what=f"grad {k_}: layer nodes vs stack node", rtol=2e-4, atol=2e-5 * max(1.0, float(g1[k_].abs().max())))
     # plain torch with the same keep-masks (the executor draws them in ONE generator call at the top of Encoder.forward)
     keep = None
     if p > 0:
