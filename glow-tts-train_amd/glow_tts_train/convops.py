@@ -1131,23 +1131,31 @@ class FlowStackFn(Function):
     (round 4).  The launch sequence is FlowBlockFn's, block by block — one `glowtts_flow_block_fwd_io` /
     `_bwd_io` call each — but the host does per STACK what it did per block: one allocation per kind of activation slab
     ((n_blocks, ...) tensors; a block's buffers are slices addressed by pointer arithmetic), one saved-tensor list, one autograd
-    node instead of twelve.  Per block the Python side is the weight pack, the plane binding, the cached table and one C call
-    (forward 225 -> ~60 us of host time per block, backward 260 -> ~80).  fp32 tensors, no conditioning input; anything else
-    takes the per-block nodes."""
+    node instead of twelve.  Per block the Python side is the weight pack, the plane binding, the cached table and one C call.
+    fp32 or bf16 tensors (`io` as in FlowBlockFn), no conditioning input; anything else takes the per-block nodes."""
 
     @staticmethod
     def forward(ctx, x, m2, x_len, drops, cfg, bplans, counts, *params):
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = cfg
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
+        fdt = torch.bfloat16 if io & 2 else torch.float32
+        adt = torch.bfloat16 if io & 1 else torch.float32
+        eF, eA = (2 if io & 2 else 4), (2 if io & 1 else 4)
         nb = len(bplans)
         x = x.contiguous()
+        if x.dtype != fdt:
+            raise RuntimeError(f"FlowStackFn: flow tensor is {x.dtype}, the stack runs with {fdt} flow tensors")
         B, C, T = x.shape
         dev = x.device
         new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                      # noqa: E731
-        zs, y, out = new(nb, B, C, T), new(nb, B, C, T), new(nb, B, C, T)
-        h0, skip = new(nb, B, H, T), new(nb, B, H, T)
-        acts, ts = new(nb, n_layers, B, H, T), new(nb, n_layers, B, 2 * H, T)
-        xs = new(nb, max(n_layers - 1, 1), B, H, T)
+        act = lambda *shape: torch.empty(shape, device=dev, dtype=adt)                                # noqa: E731
+        zs, y = torch.empty(nb, B, C, T, device=dev, dtype=fdt), torch.empty(nb, B, C, T, device=dev, dtype=fdt)
+        out = new(nb, B, C, T)
+        y0h = act(nb, B, C // 2, T) if io == 1 else None
+        h0, skip = act(nb, B, H, T), act(nb, B, H, T)
+        acts, ts = act(nb, n_layers, B, H, T), act(nb, n_layers, B, 2 * H, T)
+        nx = max(n_layers - 1, 1)
+        xs = act(nb, nx, B, H, T)
         logdets = new(nb, B)
         winv = new(nb, n_split * n_split + 1)
         if p_drop > 0.0 and (drops is None or tuple(drops.shape) != (nb, n_layers, B, 2 * H, T) or not drops.is_contiguous()):
@@ -1155,9 +1163,9 @@ class FlowStackFn(Function):
         if p_drop <= 0.0:
             drops = None
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-        sC, sH = B * C * T * 4, B * H * T * 4
+        nC, nH = B * C * T, B * H * T                             # elements of a flow / hidden tensor
         px, pm, pl = ptr(x), ptr(m2), ptr(x_len)
-        pz, py, po, ph, psk = ptr(zs), ptr(y), ptr(out), ptr(h0), ptr(skip)
+        pz, py, po, ph, psk, py0 = ptr(zs), ptr(y), ptr(out), ptr(h0), ptr(skip), ptr(y0h)
         pa, pts, pxs, pld, pw = ptr(acts), ptr(ts), ptr(xs), ptr(logdets), ptr(winv)
         pdr = ptr(drops)
         taps = params[8].shape[2]
@@ -1169,19 +1177,21 @@ class FlowStackFn(Function):
             plan = bplan.plan
             plan.ensure(FlowBlockPlan.conv_params(pk, n_layers), n_convs=2 + 2 * n_layers)
             plan.pack()
-            bound = bplan.bind(0)
+            bound = bplan.bind(io)
             try:
                 tab = bplan.table(pk, n_layers)
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
-                call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * sC, pm, pl, None,
-                     None if pdr is None else pdr + k * n_layers * B * 2 * H * T, scale, py + k * sC, None, ph + k * sH,
-                     pxs + k * max(n_layers - 1, 1) * sH if n_layers > 1 else None, pa + k * n_layers * sH,
-                     pts + k * n_layers * 2 * sH, psk + k * sH, po + k * sC, pz + k * sC, pld + k * B * 4, B, C, H, T, taps, dil_rate,
-                     n_split, int(sigmoid_scale), 0)
+                call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl, None,
+                     None if pdr is None else pdr + k * n_layers * 2 * nH, scale, py + k * nC * eF,
+                     None if py0 is None else py0 + k * (nC // 2) * eA, ph + k * nH * eA,
+                     pxs + k * nx * nH * eA if n_layers > 1 else None, pa + k * n_layers * nH * eA,
+                     pts + k * n_layers * 2 * nH * eA, psk + k * nH * eA, po + k * nC * 4, pz + k * nC * eF, pld + k * B * 4, B, C, H, T,
+                     taps, dil_rate, n_split, int(sigmoid_scale), int(io))
             finally:
                 bplan.unbind(bound)
-        ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]))
+        ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]),
+                              *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale = cfg, bplans, counts, params, taps, scale
         return zs[nb - 1], logdets.sum(0)
 
@@ -1189,42 +1199,52 @@ class FlowStackFn(Function):
     @once_differentiable
     def backward(ctx, dz, dlogdet):
         import ctypes
-        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H = ctx.cfg
+        n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = ctx.cfg
+        fdt = torch.bfloat16 if io & 2 else torch.float32
+        adt = torch.bfloat16 if io & 1 else torch.float32
+        eF, eA = (2 if io & 2 else 4), (2 if io & 1 else 4)
         sv = list(ctx.saved_tensors)
         x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs = sv[:12]
-        drops = sv[12] if p_drop > 0 else None
+        rest = sv[12:]
+        drops = rest.pop(0) if p_drop > 0 else None
+        y0h = rest.pop(0) if io == 1 else None
         params, bplans, counts = ctx.params, ctx.bplans, ctx.counts
         nb = len(bplans)
         B, C, T = x.shape
         dev = x.device
         if not all(p.grad is not None and p.grad.is_contiguous() for p in params):
             raise RuntimeError("FlowStackFn.backward: a parameter gradient buffer disappeared between forward and backward")
-        new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)                      # noqa: E731
-        dz = dz.contiguous().float() if dz is not None else torch.zeros_like(x)
+        act = lambda *shape: torch.empty(shape, device=dev, dtype=adt)                                # noqa: E731
+        flow = lambda *shape: torch.empty(shape, device=dev, dtype=fdt)                               # noqa: E731
+        dz = dz.contiguous() if dz is not None else torch.zeros_like(x)
+        if dz.dtype != fdt:
+            dz = dz.to(fdt)
         dlogdet = dlogdet.contiguous().float() if dlogdet is not None else torch.zeros(B, device=dev)
         wgrad = _WgradStream(dev)
-        two_src = dil_rate == 1 and H % 192 == 0 and T % 4 == 0
+        two_src = (not io) and dil_rate == 1 and H % 192 == 0 and T % 4 == 0
         # per-block scratch as slices of one allocation per kind: the weight-gradient stream reads a block's scratch after the
         # chain has moved on to the next block, so nothing is shared between blocks
-        dy, dout, dxs = new(nb, B, C, T), new(nb, B, C, T), new(nb, B, C, T)
-        dskip = new(nb, B, H, T)
-        d_rs = new(nb, B, H, T) if two_src else new(nb, n_layers, B, 2 * H, T)
-        d_xin, dx_wn = new(nb, n_layers, B, 2 * H, T), new(nb, n_layers, B, H, T)
-        sC, sH = B * C * T * 4, B * H * T * 4
+        dy, dout, dxs = flow(nb, B, C, T), act(nb, B, C, T), flow(nb, B, C, T)
+        dskip = act(nb, B, H, T)
+        d_rs = act(nb, B, H, T) if two_src else act(nb, n_layers, B, 2 * H, T)
+        d_xin, dx_wn = act(nb, n_layers, B, 2 * H, T), act(nb, n_layers, B, H, T)
+        nC, nH = B * C * T, B * H * T
+        nx = max(n_layers - 1, 1)
         px, pm, pl = ptr(x), ptr(m2), ptr(x_len)
-        pz, py, po, ph, psk = ptr(zs), ptr(y), ptr(out), ptr(h0), ptr(skip)
+        pz, py, po, ph, psk, py0 = ptr(zs), ptr(y), ptr(out), ptr(h0), ptr(skip), ptr(y0h)
         pa, pts, pxs, pw = ptr(acts), ptr(ts), ptr(xs), ptr(winv)
         pdr = ptr(drops)
         pdy, pdo, pdx, pds, pdrs, pdxin, pdxw = ptr(dy), ptr(dout), ptr(dxs), ptr(dskip), ptr(d_rs), ptr(d_xin), ptr(dx_wn)
         pdz, pdl = ptr(dz), ptr(dlogdet)
-        drs_stride = sH if two_src else n_layers * 2 * sH
+        drs_stride = (nH if two_src else n_layers * 2 * nH) * eA
         side = wgrad.side.cuda_stream if wgrad.enabled else None
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + c)
         if wgrad.enabled:                                # read by the second stream after this returns
-            for t in (y, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, zs):
-                t.record_stream(wgrad.side)
+            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, zs):
+                if t is not None:
+                    t.record_stream(wgrad.side)
         for k in range(nb - 1, -1, -1):
             pk = params[offs[k]: offs[k + 1]]
             bplan = bplans[k]
@@ -1232,15 +1252,16 @@ class FlowStackFn(Function):
             tab = bplan.table(pk, n_layers)
             tab.w_inv = pw + k * (n_split * n_split + 1) * 4
             tab.logdet_w = tab.w_inv + 4 * n_split * n_split
-            bound = bplan.bind(0)
+            bound = bplan.bind(io)
             try:
-                call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * sC, pm, pl,
-                     None if pdr is None else pdr + k * n_layers * B * 2 * H * T, ctx.scale, py + k * sC, None, ph + k * sH,
-                     pxs + k * max(n_layers - 1, 1) * sH if n_layers > 1 else None, pa + k * n_layers * sH,
-                     pts + k * n_layers * 2 * sH, psk + k * sH, po + k * sC, pdz if k == nb - 1 else pdx + (k + 1) * sC, pdl,
-                     pdy + k * sC, pdo + k * sC, pds + k * sH, pdrs + k * drs_stride, pdxin + k * n_layers * 2 * sH,
-                     pdxw + k * n_layers * sH, pdx + k * sC, None, B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale),
-                     int(two_src), 0, side if on_side else None)
+                call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl,
+                     None if pdr is None else pdr + k * n_layers * 2 * nH, ctx.scale, py + k * nC * eF,
+                     None if py0 is None else py0 + k * (nC // 2) * eA, ph + k * nH * eA,
+                     pxs + k * nx * nH * eA if n_layers > 1 else None, pa + k * n_layers * nH * eA,
+                     pts + k * n_layers * 2 * nH * eA, psk + k * nH * eA, po + k * nC * 4,
+                     pdz if k == nb - 1 else pdx + (k + 1) * nC * eF, pdl, pdy + k * nC * eF, pdo + k * nC * eA, pds + k * nH * eA,
+                     pdrs + k * drs_stride, pdxin + k * n_layers * 2 * nH * eA, pdxw + k * n_layers * nH * eA, pdx + k * nC * eF, None,
+                     B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale), int(two_src), int(io), side if on_side else None)
             finally:
                 bplan.unbind(bound)
             live = [p for p in pk if p is not None]

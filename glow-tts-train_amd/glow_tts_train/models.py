@@ -180,9 +180,9 @@ class FlowSpecDecoder(nn.Module):
 
     def _stack_args(self, x, g, io, blocks, m2):
         """Arguments of convops.FlowStackFn when EVERY block of the decoder can share one autograd node: the standard
-        [ActNorm, InvConvNear, CouplingBlock] layout, fp32 tensors, no conditioning input, every block eligible for the native
+        [ActNorm, InvConvNear, CouplingBlock] layout, no conditioning input, every block eligible for the native
         executors with one common shape.  GLOWTTS_FLOW_STACK=0 keeps one node per block."""
-        if io or g is not None or not _FLOW_STACK or not blocks:
+        if g is not None or not _FLOW_STACK or not blocks:
             return None
         trip = self._blocks()
         if not trip:
@@ -195,7 +195,7 @@ class FlowSpecDecoder(nn.Module):
                 return None
             wn = c.wn
             k = (inv.n_split, bool(c.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0, wn.dilation_rate, wn.n_layers,
-                 wn.hidden_channels)
+                 wn.hidden_channels, io)
             if cfg is None:
                 cfg = k
             elif k != cfg or wn.kernel_size != wn0.kernel_size:
@@ -243,6 +243,8 @@ class FlowSpecDecoder(nn.Module):
                 x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, *params)
                 if self.n_sqz > 1:
                     x, x_mask = unsqueeze(x, x_mask, self.n_sqz, io_bf16=flow16)
+                elif flow16:
+                    x = x.float()
                 return x, logdet_tot
             i = 0
             while i < len(self.flows):

@@ -104,9 +104,13 @@ def test_flow_stack_bf16_tensors_track_fp32(G, mode, b, t, blocks, p_drop):
     r = torch.randn(b, 80, t, device="cuda")
     s = torch.randn(b, device="cuda")
     used, calls_io = [], []
-    orig = G.convops.FlowBlockFn.forward
+    orig, orig_stack = G.convops.FlowBlockFn.forward, G.convops.FlowStackFn.forward
     G.convops.FlowBlockFn.forward = staticmethod(
         lambda ctx, x, m2, xl, drop, cfg, *a, _o=orig: (used.append(x.dtype), calls_io.append(cfg[6]), _o(ctx, x, m2, xl, drop, cfg, *a))[2])
+    # (every block in ONE autograd node: convops.FlowStackFn — counted as one entry per block)
+    G.convops.FlowStackFn.forward = staticmethod(
+        lambda ctx, x, m2, xl, drop, cfg, bplans, *a, _o=orig_stack: (used.extend([x.dtype] * len(bplans)), calls_io.extend([cfg[6]] * len(bplans)),
+                                                                      _o(ctx, x, m2, xl, drop, cfg, bplans, *a))[2])
     try:
         z1, l1, dx1, g1 = _run(dec, y0, mask, r, s, mode)
         want = torch.bfloat16 if mode == "all" else torch.float32
@@ -114,9 +118,10 @@ def test_flow_stack_bf16_tensors_track_fp32(G, mode, b, t, blocks, p_drop):
         assert calls_io[-blocks:] == [3 if mode == "all" else 1] * blocks, calls_io
         used.clear()
         z0, l0, dx0, g0 = _run(dec, y0, mask, r, s, False)
-        assert used in ([torch.float32] * blocks, [])     # (fp32 tensors: one convops.FlowStackFn node for all blocks)
+        assert used == [torch.float32] * blocks
     finally:
         G.convops.FlowBlockFn.forward = orig
+        G.convops.FlowStackFn.forward = orig_stack
     assert z1.dtype == torch.float32
     assert rel_err(z1, z0) < 3e-2, rel_err(z1, z0)
     assert rel_err(l1, l0) < 2e-3, rel_err(l1, l0)
@@ -144,15 +149,19 @@ def test_flow_stack_bf16_other_mel_widths(G, mode, mels):
     r = torch.randn(b, mels, t, device="cuda")
     s = torch.randn(b, device="cuda")
     calls_io = []
-    orig = G.convops.FlowBlockFn.forward
+    orig, orig_stack = G.convops.FlowBlockFn.forward, G.convops.FlowStackFn.forward
     G.convops.FlowBlockFn.forward = staticmethod(
         lambda ctx, x, m2, xl, drop, cfg, *a, _o=orig: (calls_io.append(cfg[6]), _o(ctx, x, m2, xl, drop, cfg, *a))[1])
+    G.convops.FlowStackFn.forward = staticmethod(
+        lambda ctx, x, m2, xl, drop, cfg, bplans, *a, _o=orig_stack: (calls_io.extend([cfg[6]] * len(bplans)),
+                                                                      _o(ctx, x, m2, xl, drop, cfg, bplans, *a))[1])
     try:
         z1, l1, dx1, g1 = _run(dec, y0, mask, r, s, mode)
         assert calls_io == [3 if mode == "all" else 1] * blocks, calls_io
         z0, l0, dx0, g0 = _run(dec, y0, mask, r, s, False)
     finally:
         G.convops.FlowBlockFn.forward = orig
+        G.convops.FlowStackFn.forward = orig_stack
     assert rel_err(z1, z0) < 3e-2 and rel_err(l1, l0) < 2e-3, (rel_err(z1, z0), rel_err(l1, l0))
     assert _cos(dx1, dx0) > 0.999
     for k in g0:
