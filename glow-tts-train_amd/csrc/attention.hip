@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                     }
                 }
             }
+            mfma_settle();                             // (a uniform branch stands between these MFMAs and the strip's first read)
             __syncthreads();                           // every wave is done with this tile
             if (jt + 1 < njt) {
                 commit(B1g, (jt + 1) * 64);
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                 R = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, R, 0, 0, 0);
             }
         }
+        mfma_settle();
         float *rw = Rs + wave * 16 * 17;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) rw[(lk * 4 + reg) * 17 + lcol] = R[reg];
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
 #pragma unroll
                 for (int dt = 0; dt < DA; ++dt)
                     if (DTC || dt < DT) O[dt] = mma_bf16(av, bf4_row(Bs + (dt * 16 + lcol) * kBP + kk + 4 * lk), O[dt]);
+                if constexpr (!DTC) mfma_settle();     // (run-time head width: a branch per d tile, accumulators read at the loop head)
             }
         } else {
 #pragma unroll 4
@@ -510,8 +513,10 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                         O[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, O[dt], 0, 0, 0);
                     }
                 }
+                if constexpr (!DTC) mfma_settle();
             }
         }
+        mfma_settle();                                 // (callers branch on `jt + 1 < njt` / `rel` before O is read)
     };
     if constexpr (LONG) {
 #pragma unroll
@@ -573,6 +578,7 @@ __global__ __launch_bounds__(256) void attn_qblock_kernel(AttnParams p) {
                 }
             }
         }
+        mfma_settle();
     }
 
     ATTN_TRACE(4);

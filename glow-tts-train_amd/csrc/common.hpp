@@ -50,6 +50,21 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// Call after the LAST MFMA of a group whenever control flow (a uniform `if`, a loop exit) stands between it and the first read
+// of its accumulators.  The matrix pipe has no interlock for a VALU / LDS / memory instruction that reads a register an MFMA
+// is still writing; the compiler pads that distance — but it counts it in LAYOUT order, so a conditional branch that jumps
+// forward over a block lands on the read with the skipped block's instructions counted and not executed (ROCm 7.2;
+// tools/mfma_hazard_scan.py finds such paths in the built library, tests/test_host_cpu.py runs it).  Round 4, attn_qblock_kernel:
+// `if (jt + 1 < njt) { commit; barrier }` after the last key tile's MFMAs, the accumulator read at the join: register [3] of the
+// last 16-key tile (the last pass to land) kept the sum of the previous k step in ~25 % of launches at T = 128 / 160 / 192.
+// The scheduling barriers keep the MFMAs above the wait (they were otherwise free to sink below it — they touch no memory);
+// 16 wait states cover every 16x16 opcode (the compiler keeps 8-10); a 32x32 one (19) would need two calls.
+__device__ __forceinline__ void mfma_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // The gate of the fused conv epilogues: hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of the libm

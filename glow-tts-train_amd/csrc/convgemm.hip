@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_wd_kernel(ConvGemmParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         GLOWTTS_TRACE_POINT(2 + 2 * (c & 3));
+        mfma_settle();                              // (the loop's branches stand between the last MFMAs and the accumulators' next read)
         __syncthreads();                            // every wave is done reading the LDS image
         if (more) {
             xstore();

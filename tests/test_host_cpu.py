@@ -513,3 +513,22 @@ def test_library_has_no_packed_fp32_valu(tmp_path):
     assert mfma > 1000, "disassembly looks empty"
     assert bad == 0, f"{bad} packed-fp32 VALU instructions in libglowtts_hip.so"
     assert not aggressors, f"bf16-MFMA kernels with 64-bit LDS stores: {aggressors[:4]}"
+
+
+def test_library_has_no_early_mfma_result_read_behind_a_branch():
+    """csrc/common.hpp mfma_settle(): ROCm 7.2 pads the distance between an MFMA and the first read of its accumulators in
+    layout order; behind a TAKEN forward branch that distance can be shorter than the matrix pipe needs (no interlock), and
+    the read returns the accumulator before the last pass has landed.  tools/mfma_hazard_scan.py walks the control-flow graph
+    of every kernel of the built library; round 4's attention kernels had 185 such paths (24 kernels), wrong results in ~25 %
+    of launches at T = 128 / 160 / 192."""
+    import importlib.util
+
+    lib = os.path.join(ROOT, "glow-tts-train_amd", "lib", "libglowtts_hip.so")
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") and os.path.exists(lib)):
+        pytest.skip("needs the built library and the ROCm llvm-objdump")
+    spec = importlib.util.spec_from_file_location("mfma_hazard_scan", os.path.join(ROOT, "tools", "mfma_hazard_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    found, stats, n_kernels = scan.scan(lib)
+    assert n_kernels > 100 and len(stats["linear"]) >= 3, "disassembly looks empty"
+    assert not found, [(f[0][:60], hex(f[1]), f[2], f[6], f[7]) for f in found[:6]]
