@@ -161,27 +161,83 @@ def pmc_entry(kernel_tag, math="bf16x6+wrw"):
 
 
 def subset_from_kernel_trace(sub_bytes, survey_gb, blocks):
-    """The invertible subset's kernels in the committed rocprofv3 kernel trace (profiles/r04_kernel_stats.csv: average dispatch
-    duration over the step's launches, one launch of each per flow block and direction): ms per step and the fractions of 8 TB/s that
-    gives — beside the HIP-event figures of this run, which include each launch's latency."""
+    """The invertible subset's kernels in the committed rocprofv3 kernel trace (profiles/r04_kernel_stats.csv: total dispatch time of
+    the subset's kernels over the traced steps): ms per step and the fractions of 8 TB/s that gives — beside the HIP-event figures of
+    this run, which include each launch's latency.  Since round 4 the step launches coupling(k) fused with ActNorm + InvConv(k + 1)
+    (coupling_ai_{fwd,bwd}_kernel: 3 X and 5 X per launch where the pair moved 5 X and 7 X): `alg_GB_as_launched` counts the bytes
+    of the launches the trace holds, `frac` is on those, `frac_unfused_bytes` on the per-kernel count the un-fused step moved."""
     import csv
 
     here = os.path.dirname(os.path.abspath(__file__))
-    names = ("actnorm_invconv_fwd_kernel", "actnorm_invconv_bwd_kernel", "coupling_fwd_kernel", "coupling_bwd_kernel")
+    names = {"actnorm_invconv_fwd_kernel": 2, "actnorm_invconv_bwd_kernel": 3, "coupling_fwd_kernel": 3, "coupling_bwd_kernel": 4,
+             "coupling_ai_fwd_kernel": 3, "coupling_ai_bwd_kernel": 5}          # X per launch
     try:
         rows = list(csv.DictReader(open(os.path.join(here, "profiles", "r04_kernel_stats.csv"))))
     except Exception:
         return None
-    us = {}
-    for r in rows:
-        for n in names:
-            if "glowtts::" + n + "<" in r["Name"] and n not in us:
-                us[n] = float(r["AverageNs"]) / 1e3
-    if len(us) != len(names):
+    steps = next((int(r["Calls"]) for r in rows if "glowtts::adam_kernel<" in r["Name"]), 0)
+    if not steps:
         return None
-    ms = sum(us.values()) * blocks / 1e3
-    return {"source": "profiles/r04_kernel_stats.csv", "mean_us": {k: round(v, 2) for k, v in us.items()}, "ms_per_step": round(ms, 3),
-            "frac": round(sub_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "survey_frac": round(survey_gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+    x_bytes = sub_bytes / (12.0 * blocks)               # the un-fused subset moves 12 X per block (2 + 3 + 3 + 4)
+    ns, xs, us, calls = 0.0, 0.0, {}, {}
+    for r in rows:
+        for n, nx in names.items():
+            if "glowtts::" + n + "<" in r["Name"]:
+                ns += float(r["TotalDurationNs"])
+                xs += nx * int(r["Calls"])
+                us[n] = round(float(r["AverageNs"]) / 1e3, 2)
+                calls[n] = round(int(r["Calls"]) / steps, 2)
+    if not ns:
+        return None
+    ms = ns / steps / 1e6
+    launched = xs / steps * x_bytes
+    return {"source": "profiles/r04_kernel_stats.csv", "mean_us": us, "launches_per_step": calls, "ms_per_step": round(ms, 3),
+            "alg_GB_as_launched": round(launched / 1e9, 3),
+            "frac": round(launched / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_unfused_bytes": round(sub_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "survey_frac": round(survey_gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+
+
+def fused_flows_time(args, dev, iters=30):
+    """The two fused kernels of the flow stack as the step launches them (convops.FlowStackFn): coupling(k) + ActNorm + InvConv(k + 1)
+    forward (3 X) and ActNorm + InvConv(k + 1) + coupling(k) backward (5 X) at the benchmark's shape, HIP events on the launch
+    stream around back-to-back launches (so each figure includes a launch's latency)."""
+    from glow_tts_train import _hip
+
+    b, t, c, ns = args.batch, args.t_mel // 2, 160, 4
+    f = lambda *sh: torch.randn(*sh, device=dev)                                                       # noqa: E731
+    y_prev, out_prev, dz = f(b, c, t), f(b, c, t) * 0.1, f(b, c, t)
+    mask, x_len = torch.ones(b, t, device=dev), torch.full((b,), float(t), device=dev)
+    logs, bias, w = f(c) * 0.1, f(c) * 0.1, torch.linalg.qr(f(ns, ns))[0].contiguous()
+    w_inv, logdet_w = torch.inverse(w).contiguous(), torch.zeros(1, device=dev)
+    y, ld_prev, ld, dld = torch.empty(b, c, t, device=dev), torch.zeros(b, device=dev), torch.zeros(b, device=dev), f(b)
+    dy_prev, dout_prev = torch.empty(b, c, t, device=dev), torch.empty(b, c, t, device=dev)
+    dlogs, dbias, dw = torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.zeros(ns, ns, device=dev)
+    P = lambda x: x.data_ptr()                                                                         # noqa: E731
+    fwd = lambda: _hip.call("glowtts_coupling_actnorm_invconv_fwd", P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w),   # noqa: E731
+                            P(logdet_w), P(x_len), P(y), P(ld_prev), P(ld), b, c, t, ns, 0)
+    bwd = lambda: _hip.call("glowtts_coupling_actnorm_invconv_bwd", P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w),   # noqa: E731
+                            P(w_inv), P(dz), P(dld), P(x_len), P(dy_prev), P(dout_prev), P(dlogs), P(dbias), P(dw), b, c, t, ns, 0)
+    cur = torch.cuda.current_stream(dev)
+    res = {}
+    x_bytes = 4.0 * b * c * t
+    for name, fn, nx in (("fwd", fwd, 3), ("bwd", bwd, 5)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(iters):
+            fn()
+        e1.record(cur)
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / iters
+        res[name] = {"mean_us": round(us, 2), "alg_MB": round(nx * x_bytes / 1e6, 2),
+                     "hbm_frac": round(nx * x_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    nb = args.blocks
+    res["ms_per_step_fused_part"] = round((nb - 1) * (res["fwd"]["mean_us"] + res["bwd"]["mean_us"]) / 1e3, 3)
+    res["note"] = ("per step: blocks - 1 launches of each, plus the first block's ActNorm + InvConv and the last block's coupling "
+                   "on the un-fused kernels (timed above)")
+    return res
 
 
 def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
@@ -774,6 +830,11 @@ def main():
             dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": hbm[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
+        try:        # coupling(k) + ActNorm + InvConv(k + 1): the two kernels the step's flow stack launches between blocks
+            fused = fused_flows_time(args, dev)
+        except Exception as exc:
+            fused = None
+            log(f"fused flow timing failed ({type(exc).__name__}: {exc})")
         out["roofline"].update({
             "conv_math": default_math,
             "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
@@ -789,7 +850,8 @@ def main():
                                   "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None,
                                   # HIP events around a 6-15 us launch include its launch latency (~4 us); the committed
                                   # rocprofv3 kernel trace of this same command times the kernels themselves
-                                  "rocprofv3": subset_from_kernel_trace(sub_bytes, survey_gb, args.blocks)},
+                                  "rocprofv3": subset_from_kernel_trace(sub_bytes, survey_gb, args.blocks),
+                                  "fused_as_launched_in_the_step": fused},
             "step_ms": round(ms_per_step, 3),
             "decoder": dec,
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),

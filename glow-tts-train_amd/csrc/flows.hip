@@ -718,6 +718,211 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(const void *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 4: the affine apply of block k fused with ActNorm + InvConvNear of block k + 1 — adjacent
+// element-wise passes over the same flow tensor (reference attentions.py:128-142 followed by layers.py:182-199, 238-272).
+//   fwd : z = [y0 ; (m + e^logs' y1) mask]  (never written) ; y' = W ((bias + e^logs z) mask) mask
+//         logdet_prev[b] += sum logs' mask ; logdet[b] = (sum logs + logdet_w C/n) x_len[b]          traffic 3X (was 5X)
+//   bwd : z recomputed from (y, out) ; the ActNorm / InvConv backward of actnorm_invconv_bwd_kernel on it (dz_ai -> d z,
+//         dlogs, dbias, dW) ; then the coupling's backward on d z: dy = [dz0 ; dz1 e^logs' mask], dout = [dz1 mask ; dlogs']
+//                                                                                                    traffic 5X (was 7.5X)
+// A group of N channels holds N/2 channels of each half (invconv_channel), so both steps are local to a thread.  fp32 tensors.
+// ------------------------------------------------------------------------------------------------------------
+template <int N, int V>
+__global__ __launch_bounds__(256) void coupling_ai_fwd_kernel(const float *__restrict__ yp, const float *__restrict__ outp,
+                                                              const float *__restrict__ mask, const float *__restrict__ logs,
+                                                              const float *__restrict__ bias, const float *__restrict__ w,
+                                                              const float *__restrict__ logdet_w, const float *__restrict__ x_len,
+                                                              float *__restrict__ y, float *__restrict__ logdet_prev,
+                                                              float *__restrict__ logdet, int B, int C, int T, int sig) {
+    __shared__ float red[4];
+    const int TV = T / V, G = C / N, half = C / 2;
+    const int b = blockIdx.y;
+    const int items = G * TV;
+    float wr[N * N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+    float ld = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < items; i += gridDim.x * 256) {
+        const int g = i / TV, tv = i - g * TV;
+        const Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        Vec<V> yv[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int ch = invconv_channel<N>(k, g, C);
+            const long o = ((long)b * C + ch) * T + (long)tv * V;
+            Vec<V> z = Vec<V>::load(yp + o);
+            if (k >= N / 2) {                               // second half: the affine apply of the previous block
+                const Vec<V> m = Vec<V>::load(outp + o - (long)half * T);
+                const Vec<V> lr = Vec<V>::load(outp + o);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float l = coupling_logs(lr[j], sig != 0);
+                    z[j] = (m[j] + expf(l) * z[j]) * mv[j];
+                    ld += l * mv[j];
+                }
+            }
+            const float e = expf(logs[ch]), bi = bias[ch];
+#pragma unroll
+            for (int j = 0; j < V; ++j) yv[k][j] = (bi + e * z[j]) * mv[j];
+        }
+#pragma unroll
+        for (int o = 0; o < N; ++o) {
+            Vec<V> acc;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) s2 += wr[o * N + k] * yv[k][j];
+                acc[j] = s2 * mv[j];
+            }
+            acc.store(y + ((long)b * C + invconv_channel<N>(o, g, C)) * T + (long)tv * V);
+        }
+    }
+    ld = block_sum_256(ld, red);
+    if (threadIdx.x == 0) atomicAdd(logdet_prev + b, ld);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        __syncthreads();
+        float s2 = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s2 += logs[c];
+        s2 = block_sum_256(s2, red);
+        const float l0 = s2 + logdet_w[0] * (float)(C / N);
+        for (int bb = threadIdx.x; bb < B; bb += 256) logdet[bb] = l0 * x_len[bb];
+    }
+}
+
+template <int N, int V>
+__global__ __launch_bounds__(256) void coupling_ai_bwd_kernel(const float *__restrict__ yp, const float *__restrict__ outp,
+                                                              const float *__restrict__ mask, const float *__restrict__ logs,
+                                                              const float *__restrict__ bias, const float *__restrict__ w,
+                                                              const float *__restrict__ w_inv, const float *__restrict__ dz,
+                                                              const float *__restrict__ dlogdet, const float *__restrict__ x_len,
+                                                              float *__restrict__ dyp, float *__restrict__ doutp,
+                                                              float *__restrict__ dlogs, float *__restrict__ dbias,
+                                                              float *__restrict__ dw, int B, int C, int T, int nb, int sig) {
+    const int TV = T / V, half = C / 2;
+    const int g = blockIdx.x;
+    float wr[N * N], e[N], bi[N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) wr[q] = w[q];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int ch = invconv_channel<N>(k, g, C);
+        e[k] = expf(logs[ch]);
+        bi[k] = bias[ch];
+    }
+    float aw[N * N], al[N], ab[N];
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) aw[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { al[k] = 0.f; ab[k] = 0.f; }
+    const int i0 = blockIdx.y * nb, i1 = min(B * TV, i0 + nb);
+    for (int it = i0 + threadIdx.x; it < i1; it += 256) {
+        const int b = it / TV, tv = it - b * TV;
+        const Vec<V> mv = Vec<V>::load(mask + (long)b * T + (long)tv * V);
+        const float dld = dlogdet ? dlogdet[b] : 0.f;
+        Vec<V> xv[N], gz[N], y1[N / 2], el[N / 2], lr[N / 2];
+        long off[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            off[k] = ((long)b * C + invconv_channel<N>(k, g, C)) * T + (long)tv * V;
+            xv[k] = Vec<V>::load(yp + off[k]);
+            gz[k] = Vec<V>::load(dz + off[k]);
+        }
+#pragma unroll
+        for (int k = N / 2; k < N; ++k) {                   // z1 = (m + e^logs' y1) mask, recomputed
+            const Vec<V> m = Vec<V>::load(outp + off[k] - (long)half * T);
+            lr[k - N / 2] = Vec<V>::load(outp + off[k]);
+            y1[k - N / 2] = xv[k];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float ee = expf(coupling_logs(lr[k - N / 2][j], sig != 0));
+                el[k - N / 2][j] = ee;
+                xv[k][j] = (m[j] + ee * xv[k][j]) * mv[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) gz[k][j] *= mv[j];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            Vec<V> o;                                        // gradient of z (channel k of the group)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float yk = (bi[k] + e[k] * xv[k][j]) * mv[j];
+                float dy = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < N; ++oo) {
+                    dy += wr[oo * N + k] * gz[oo][j];
+                    aw[oo * N + k] += gz[oo][j] * yk;
+                }
+                const float dym = dy * mv[j];
+                o[j] = dym * e[k];
+                al[k] += dym * e[k] * xv[k][j];
+                ab[k] += dym;
+            }
+            if (k < N / 2) {
+                o.store(dyp + off[k]);                       // first half passes through the coupling
+            } else {
+                Vec<V> dx1, dm, dl;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float gm = o[j] * mv[j];
+                    const float ee = el[k - N / 2][j];
+                    dx1[j] = gm * ee;
+                    dm[j] = gm;
+                    float dlp = gm * ee * y1[k - N / 2][j] + dld * mv[j];
+                    if (sig) {
+                        const float sg = sigmoidf_(lr[k - N / 2][j] + 2.0f);
+                        dlp *= sg * (1.0f - sg) / (1e-6f + sg);
+                    }
+                    dl[j] = dlp;
+                }
+                dx1.store(dyp + off[k]);
+                dm.store(doutp + off[k] - (long)half * T);
+                dl.store(doutp + off[k]);
+            }
+        }
+    }
+    constexpr int NS = 2 * N + N * N;
+    constexpr int RP = 260;
+    __shared__ __attribute__((aligned(16))) float part[NS * RP + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { part[k * RP + tid] = al[k]; part[(N + k) * RP + tid] = ab[k]; }
+#pragma unroll
+    for (int q = 0; q < N * N; ++q) part[(2 * N + q) * RP + tid] = aw[q];
+    if (wave == 3) {
+        float t = 0.f;
+        if (dlogdet != nullptr)
+            for (int b = lane; b < B; b += 64) t += dlogdet[b] * x_len[b];
+        t = wave_sum(t);
+        if (lane == 0) part[NS * RP] = t;
+    }
+    __syncthreads();
+    const float tt = part[NS * RP];
+    if (wave == 0) {
+        int q; bool owner;
+        float v = row_sum_256<2 * N>(part, RP, 0, lane, q, owner);
+        if (owner) {
+            if (q < N) {
+                if (blockIdx.y == 0) v += tt;
+                atomicAdd(dlogs + invconv_channel<N>(q, g, C), v);
+            } else {
+                atomicAdd(dbias + invconv_channel<N>(q - N, g, C), v);
+            }
+        }
+    } else if (wave == 1) {
+        int r; bool owner;
+        float v = row_sum_256<N * N>(part, RP, 2 * N, lane, r, owner);
+        if (owner) {
+            if (g == 0 && blockIdx.y == 0 && dlogdet != nullptr) v += w_inv[(r % N) * N + r / N] * (float)(C / N) * tt;
+            atomicAdd(dw + r, v);
+        }
+    }
+}
+
 }  // namespace glowtts
 
 // ================================================================================================================
@@ -1004,4 +1209,66 @@ extern "C" int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, co
                                            int C, int T, int n_split, glowtts_stream_t stream) {
     return glowtts_actnorm_invconv_bwd_io(x, mask, logs, bias, w, w_inv, dz, dlogdet, x_len, dx, dlogs, dbias, dw, B, C, T,
                                           n_split, 0, stream);
+}
+
+// ---- coupling(k) fused with ActNorm + InvConvNear (k + 1): see coupling_ai_fwd_kernel ---------------------------------------
+extern "C" int glowtts_coupling_actnorm_invconv_fwd(const float *y_prev, const float *out_prev, const float *mask, const float *logs,
+                                                    const float *bias, const float *w, const float *logdet_w, const float *x_len,
+                                                    float *y, float *logdet_prev, float *logdet, int B, int C, int T, int n_split,
+                                                    int sigmoid_scale, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(y_prev && out_prev && mask && logs && bias && w && logdet_w && x_len && y && logdet_prev && logdet,
+                      "glowtts_coupling_actnorm_invconv_fwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_coupling_actnorm_invconv_fwd: n_split=%d (fused path: 2 or 4)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0 && C % 2 == 0, "glowtts_coupling_actnorm_invconv_fwd: bad shape");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {y_prev, out_prev, mask, y});
+    const long items = (long)(C / n_split) * (v4 ? T / 4 : T);
+    int gx = cdiv(items, 256);
+    if (gx > 8) gx = 8;                                 // one logdet_prev[b] atomic per workgroup; 8 x B workgroups of ~2 items per
+                                                        // thread: 7.3 us at config 2 where 16 x B (one item per thread) took 8.9
+    dim3 grid(gx, B);
+#define GLOWTTS_CAF(NN)                                                                                                          \
+    do {                                                                                                                          \
+        if (v4) hipLaunchKernelGGL((coupling_ai_fwd_kernel<NN, 4>), grid, dim3(256), 0, s, y_prev, out_prev, mask, logs, bias, w, \
+                                   logdet_w, x_len, y, logdet_prev, logdet, B, C, T, sigmoid_scale);                              \
+        else    hipLaunchKernelGGL((coupling_ai_fwd_kernel<NN, 1>), grid, dim3(256), 0, s, y_prev, out_prev, mask, logs, bias, w, \
+                                   logdet_w, x_len, y, logdet_prev, logdet, B, C, T, sigmoid_scale);                              \
+    } while (0)
+    if (n_split == 4) GLOWTTS_CAF(4); else GLOWTTS_CAF(2);
+#undef GLOWTTS_CAF
+    GLOWTTS_LAUNCH_CHECK("glowtts_coupling_actnorm_invconv_fwd");
+}
+
+extern "C" int glowtts_coupling_actnorm_invconv_bwd(const float *y_prev, const float *out_prev, const float *mask, const float *logs,
+                                                    const float *bias, const float *w, const float *w_inv, const float *dz,
+                                                    const float *dlogdet, const float *x_len, float *dy_prev, float *dout_prev,
+                                                    float *dlogs, float *dbias, float *dw, int B, int C, int T, int n_split,
+                                                    int sigmoid_scale, glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(y_prev && out_prev && mask && logs && bias && w && dz && dy_prev && dout_prev && dlogs && dbias && dw,
+                      "glowtts_coupling_actnorm_invconv_bwd: null pointer");
+    GLOWTTS_CHECK_ARG(n_split == 2 || n_split == 4, "glowtts_coupling_actnorm_invconv_bwd: n_split=%d (fused path: 2 or 4)", n_split);
+    GLOWTTS_CHECK_ARG(B >= 0 && C > 0 && T >= 0 && C % n_split == 0 && C % 2 == 0, "glowtts_coupling_actnorm_invconv_bwd: bad shape");
+    GLOWTTS_CHECK_ARG(!dlogdet || (w_inv && x_len), "glowtts_coupling_actnorm_invconv_bwd: dlogdet given without w_inv/x_len");
+    if ((long)B * C * T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = can_vec4(T, {y_prev, out_prev, mask, dz, dy_prev, dout_prev});
+    const int G = C / n_split;
+    const int items = B * (v4 ? T / 4 : T);
+    int slabs = (200 + G - 1) / G;                      // (120 .. 800 workgroups measured: 200 is the fastest, 13.2 us at config 2)
+    const int max_slabs = (items + 255) / 256;
+    if (slabs > max_slabs) slabs = max_slabs;
+    if (slabs < 1) slabs = 1;
+    const int nb = (items + slabs - 1) / slabs;
+    dim3 grid(G, (items + nb - 1) / nb);
+#define GLOWTTS_CAB(NN)                                                                                                            \
+    do {                                                                                                                            \
+        if (v4) hipLaunchKernelGGL((coupling_ai_bwd_kernel<NN, 4>), grid, dim3(256), 0, s, y_prev, out_prev, mask, logs, bias, w, w_inv, \
+                                   dz, dlogdet, x_len, dy_prev, dout_prev, dlogs, dbias, dw, B, C, T, nb, sigmoid_scale);             \
+        else    hipLaunchKernelGGL((coupling_ai_bwd_kernel<NN, 1>), grid, dim3(256), 0, s, y_prev, out_prev, mask, logs, bias, w, w_inv, \
+                                   dz, dlogdet, x_len, dy_prev, dout_prev, dlogs, dbias, dw, B, C, T, nb, sigmoid_scale);             \
+    } while (0)
+    if (n_split == 4) GLOWTTS_CAB(4); else GLOWTTS_CAB(2);
+#undef GLOWTTS_CAB
+    GLOWTTS_LAUNCH_CHECK("glowtts_coupling_actnorm_invconv_bwd");
 }

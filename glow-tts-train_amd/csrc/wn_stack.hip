@@ -311,8 +311,14 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
                                          void *acts, void *ts, void *skip, float *out, void *z, float *logdet, int B, int C,
                                          int H, int T, int taps, int dil_rate, int n_split, int sigmoid_scale, int io,
                                          glowtts_stream_t stream) {
+    // io bits 8 / 9 (round 4, convops.FlowStackFn with fp32 tensors): the caller has produced y itself (the previous block's affine
+    // apply fused with this block's ActNorm + InvConv: glowtts_coupling_actnorm_invconv_fwd, which also needs W^-1 / log det W made
+    // beforehand) / the caller runs this block's affine apply itself, fused into the next block: `z` is not written
+    const bool skip_head = (io & 256) != 0, skip_tail = (io & 512) != 0;
+    io &= 255;
     const int io_h = io & 1, io_f = (io >> 1) & 1;
     GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
+    GLOWTTS_CHECK_ARG(!(skip_head || skip_tail) || io == 0, "glowtts_flow_block_fwd: the fused-flow flags go with fp32 tensors");
     GLOWTTS_CHECK_ARG(io != 1 || y0h, "glowtts_flow_block_fwd: io = 1 needs the y0h buffer");
     const void *start_in = io == 1 ? y0h : y;
     const long start_bs = io == 1 ? (long)(C / 2) * T : (long)C * T;
@@ -327,10 +333,12 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     // e.g. because it also refreshes bf16 planes of the packed weights); W^-1 and log det W of the invertible 1x1
     if (blk->pack_desc)
         WN_TRY(glowtts_pack_weight_multi(blk->pack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, stream));
-    WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
-    // flows 3i, 3i+1: y = W ((bias + e^logs x) mask) mask ; logdet = (sum logs + log det W * C/n) x_len
-    WN_TRY(glowtts_actnorm_invconv_fwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet,
-                                          io == 1 ? y0h : nullptr, B, C, T, n_split, io_f, stream));
+    if (!skip_head) {
+        WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
+        // flows 3i, 3i+1: y = W ((bias + e^logs x) mask) mask ; logdet = (sum logs + log det W * C/n) x_len
+        WN_TRY(glowtts_actnorm_invconv_fwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet,
+                                              io == 1 ? y0h : nullptr, B, C, T, n_split, io_f, stream));
+    }
     // flow 3i+2: h = start(y[:, :C/2]) mask  ->  WN  ->  out = end(h)  ->  z = [y0 ; (m + e^logs y1) mask], logdet += sum logs mask
     WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1,
                                0, io_h, io_h, stream));
@@ -338,6 +346,7 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
                              io_h, stream));
     WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
                                stream));
+    if (skip_tail) return 0;
     return glowtts_coupling_fwd_io(y, out, mask, z, logdet, B, C, T, sigmoid_scale, 0, io_f, stream);
 }
 
@@ -361,7 +370,13 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
                       d_xin && dx_wn && dx, "glowtts_flow_block_bwd: null pointer");
     GLOWTTS_CHECK_ARG(blk->layers && blk->n_layers >= 1 && blk->unpack_desc && blk->pack_prefix && blk->dwp_all && blk->dlogs &&
                       blk->dbias && blk->dw, "glowtts_flow_block_bwd: incomplete block table");
+    // io bits 8 / 9 (see glowtts_flow_block_fwd_io): the ActNorm + InvConv backward at the END of this block's chain is left to the
+    // caller (fused with the previous block's coupling backward: glowtts_coupling_actnorm_invconv_bwd) / dy and dout have been
+    // produced by the caller (the same fused kernel one block later in the flow): no coupling backward at the start
+    const bool skip_ai = (io & 256) != 0, skip_cpl = (io & 512) != 0;
+    io &= 255;
     GLOWTTS_CHECK_ARG(!io || !two_source, "glowtts_flow_block_bwd: bf16 tensors use the d_rs form");
+    GLOWTTS_CHECK_ARG(!(skip_ai || skip_cpl) || io == 0, "glowtts_flow_block_bwd: the fused-flow flags go with fp32 tensors");
     const int io_h = io & 1, io_f = (io >> 1) & 1;
     GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
     GLOWTTS_CHECK_ARG(io != 1 || y0h, "glowtts_flow_block_bwd: io = 1 needs the y0h buffer");
@@ -374,7 +389,7 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ms);
     if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
-    WN_TRY(glowtts_coupling_bwd_io(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, io_f, io_h, stream));
+    if (!skip_cpl) WN_TRY(glowtts_coupling_bwd_io(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, io_f, io_h, stream));
     // end conv (H -> C, 1x1): weight gradient on the second stream, d(skip) on the chain.
     // Round 4, two-source form: the block's SIX 1x1 weight gradients (end conv, start conv, the stack's last and two-source
     // res/skip convs) are one launch behind the block's chain (glowtts_conv_wrw1_multi: 9 tiles of 192 x 192 sharing the compute
@@ -427,8 +442,9 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     WN_TRY(glowtts_conv_fwd_io(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, io_h, io_f,
                                stream));
     // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets
-    WN_TRY(glowtts_actnorm_invconv_bwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,
-                                          blk->dbias, blk->dw, B, C, T, n_split, io_f, stream));
+    if (!skip_ai)
+        WN_TRY(glowtts_actnorm_invconv_bwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,
+                                              blk->dbias, blk->dw, B, C, T, n_split, io_f, stream));
     // the second stream finishes the block: after this point on `ws` EVERY parameter gradient of the block is complete
     // (the three ActNorm / InvConv gradients were produced on the chain, hence the ordering edge)
     WN_TRY(order_after(ms, ws));

@@ -1169,6 +1169,9 @@ class FlowStackFn(Function):
         pa, pts, pxs, pld, pw = ptr(acts), ptr(ts), ptr(xs), ptr(logdets), ptr(winv)
         pdr = ptr(drops)
         taps = params[8].shape[2]
+        # fp32 tensors: block k's affine apply runs fused with block k + 1's ActNorm + InvConv (one pass over the flow tensor
+        # instead of two; z_k is never written) — the block executors are told to leave those launches out (io bits 8 / 9)
+        fuse = _FUSE_FLOWS and io == 0 and nb > 1 and n_split in (2, 4)      # (the fused kernels keep a group in registers: N <= 4)
         off = 0
         for k in range(nb):
             pk = params[off: off + counts[k]]
@@ -1182,17 +1185,26 @@ class FlowStackFn(Function):
                 tab = bplan.table(pk, n_layers)
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
+                flags = int(io)
+                if fuse and k > 0:
+                    call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
+                    call("glowtts_coupling_actnorm_invconv_fwd", py + (k - 1) * nC * 4, po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]),
+                         ptr(pk[2]), tab.logdet_w, pl, py + k * nC * 4, pld + (k - 1) * B * 4, pld + k * B * 4, B, C, T, n_split,
+                         int(sigmoid_scale))
+                    flags |= 256
+                if fuse and k < nb - 1:
+                    flags |= 512
                 call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl, None,
                      None if pdr is None else pdr + k * n_layers * 2 * nH, scale, py + k * nC * eF,
                      None if py0 is None else py0 + k * (nC // 2) * eA, ph + k * nH * eA,
                      pxs + k * nx * nH * eA if n_layers > 1 else None, pa + k * n_layers * nH * eA,
                      pts + k * n_layers * 2 * nH * eA, psk + k * nH * eA, po + k * nC * 4, pz + k * nC * eF, pld + k * B * 4, B, C, H, T,
-                     taps, dil_rate, n_split, int(sigmoid_scale), int(io))
+                     taps, dil_rate, n_split, int(sigmoid_scale), flags)
             finally:
                 bplan.unbind(bound)
         ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]),
                               *([] if y0h is None else [y0h]))
-        ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale = cfg, bplans, counts, params, taps, scale
+        ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale, ctx.fuse = cfg, bplans, counts, params, taps, scale, fuse
         return zs[nb - 1], logdets.sum(0)
 
     @staticmethod
@@ -1252,6 +1264,8 @@ class FlowStackFn(Function):
             tab = bplan.table(pk, n_layers)
             tab.w_inv = pw + k * (n_split * n_split + 1) * 4
             tab.logdet_w = tab.w_inv + 4 * n_split * n_split
+            fuse = ctx.fuse
+            flags = int(io) | (256 if fuse and k > 0 else 0) | (512 if fuse and k < nb - 1 else 0)
             bound = bplan.bind(io)
             try:
                 call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl,
@@ -1261,21 +1275,30 @@ class FlowStackFn(Function):
                      pts + k * n_layers * 2 * nH * eA, psk + k * nH * eA, po + k * nC * 4,
                      pdz if k == nb - 1 else pdx + (k + 1) * nC * eF, pdl, pdy + k * nC * eF, pdo + k * nC * eA, pds + k * nH * eA,
                      pdrs + k * drs_stride, pdxin + k * n_layers * 2 * nH * eA, pdxw + k * n_layers * nH * eA, pdx + k * nC * eF, None,
-                     B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale), int(two_src), int(io), side if on_side else None)
+                     B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale), int(two_src), flags, side if on_side else None)
             finally:
                 bplan.unbind(bound)
             live = [p for p in pk if p is not None]
             _mark_direct(live, True)
+            ai_late = fuse and k > 0                     # logs / bias / W of this block: their gradients come from the fused kernel below
+            conv_live = live[3:] if ai_late else live
             if on_side:
                 with torch.cuda.stream(wgrad.side):      # every gradient of the block is complete at this point of THAT stream
-                    _notify(live)
+                    _notify(conv_live)
             else:
-                _notify(live)
+                _notify(conv_live)
+            if ai_late:
+                # block k's ActNorm + InvConv backward fused with block k - 1's coupling backward: dy_k -> dy_{k-1}, dout_{k-1}
+                call("glowtts_coupling_actnorm_invconv_bwd", py + (k - 1) * nC * 4, po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]),
+                     ptr(pk[2]), tab.w_inv, pdy + k * nC * 4, pdl, pl, pdy + (k - 1) * nC * 4, pdo + (k - 1) * nC * 4, ptr(pk[0].grad),
+                     ptr(pk[1].grad), ptr(pk[2].grad), B, C, T, n_split, int(sigmoid_scale))
+                _notify(live[:3])
         return (dxs[0], None, None, None, None, None, None) + (None,) * len(params)
 
 
 # ----------------------------------------------------------------------------------------------------------------
 _ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
+_FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn: coupling(k) fused with ActNorm + InvConv (k + 1)
 
 
 def _enc_layer_table(group, attn, ffn, norm1, norm2):

@@ -139,6 +139,24 @@ int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *
                                 const float *w, const float *w_inv, const float *dz, const float *dlogdet,
                                 const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B, int C,
                                 int T, int n_split, glowtts_stream_t stream);
+/* ---- the affine apply of block k fused with ActNorm + InvConvNear of block k + 1 (round 4; attentions.py:128-142 followed by
+ * layers.py:182-199, 238-272): adjacent element-wise passes over the same flow tensor.  fp32 tensors, n_split in {2, 4}.
+ * fwd: z = [y0 ; (m + e^logs' y1) mask] with (m, logs') = out_prev is formed in registers and never written;
+ *      y = W ((bias + e^logs z) mask) mask ; logdet_prev[b] += sum logs' mask (accumulated) ; logdet[b] = (sum logs + logdet_w C/n)
+ *      x_len[b] (written).  logdet_w / w_inv from glowtts_invconv_prepare.
+ * bwd: dz = gradient of y.  z is recomputed from (y_prev, out_prev); dlogs / dbias / dw accumulated as by
+ *      glowtts_actnorm_invconv_bwd; then the coupling's backward on the gradient of z: dy_prev = [dz0 ; dz1 e^logs' mask] (written;
+ *      the start conv's input gradient is added to its first half afterwards), dout_prev = [dz1 mask ; d logs'] (written). */
+int glowtts_coupling_actnorm_invconv_fwd(const float *y_prev, const float *out_prev, const float *mask, const float *logs,
+                                         const float *bias, const float *w, const float *logdet_w, const float *x_len, float *y,
+                                         float *logdet_prev, float *logdet, int B, int C, int T, int n_split, int sigmoid_scale,
+                                         glowtts_stream_t stream);
+int glowtts_coupling_actnorm_invconv_bwd(const float *y_prev, const float *out_prev, const float *mask, const float *logs,
+                                         const float *bias, const float *w, const float *w_inv, const float *dz,
+                                         const float *dlogdet, const float *x_len, float *dy_prev, float *dout_prev, float *dlogs,
+                                         float *dbias, float *dw, int B, int C, int T, int n_split, int sigmoid_scale,
+                                         glowtts_stream_t stream);
+
 
 /* ---- affine coupling apply (attentions.py:128-142) ----------------------------------------------------------
  * x   : (B, C, T) flow input; out : (B, C, T) = end-conv output, rows [0,C/2) = m, [C/2,C) = logs
@@ -228,7 +246,8 @@ int glowtts_conv_wrw_batch(int n, const float *const *x, long x_bs, const float 
  * and attentions.py:97-113, 128-129 — a flow block's three two-source res/skip gradients, its last layer's, the start conv's and
  * the end conv's — and of the encoder's q / k / v / o projections, attentions.py:204-211): problem q is glowtts_conv_wrw (d2 ==
  * NULL; mask_d multiplies d, mask_x multiplies x, either may be NULL) or glowtts_conv_wrw2 (rows [d_split, M) of the output
- * gradient from d2, d_split % 64 == 0, no masks) with taps = 1; all problems share B and T (T % 4 == 0, 16-byte aligned rows).
+ * gradient from d2, d_split % 64 == 0, T % 4 == 0, no masks) with taps = 1; all problems share B and T (the one-launch form needs
+ * T % 4 == 0 and 16-byte aligned rows; otherwise the problems are launched one by one).
  * `problems` is a HOST array.  In the bf16-plane arithmetic (glowtts_conv_math weight-gradient mode 3) the problems' 192 x 192
  * tiles share one round of workgroups (csrc/convwrw1.hip); otherwise they are launched one by one: same results either way. */
 typedef struct glowtts_wrw1_problem {
@@ -477,7 +496,11 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       in the gate-backward kernel's epilogue (conv_gate_bwd_io's dcond: one layer's (B, 2H))
  *   flow_block_*_io : io bit 0 = the coupling network's hidden tensors (h0, xs, acts, ts, skip, their gradients, dout), bit 1
  *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
- *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads */
+ *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads.
+ *       fp32 tensors only (io & 3 == 0), for a caller that fuses a block's affine apply with the next block's ActNorm + InvConv
+ *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
+ *       ActNorm + InvConv launch) / backward: no ActNorm + InvConv backward at the end (dx is not written); bit 9 = forward: no
+ *       affine apply at the end (z is not written) / backward: dy and dout have been written by the caller (no coupling backward) */
 int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);
 int glowtts_conv_fwd_io(const void *x, long x_bs, const float *wp, const float *bias, const float *mask, const void *addend,
                         long addend_bs, void *y, long y_bs, int B, int Cin, int M, int T, int taps, int dil, int pad,

@@ -377,6 +377,8 @@ def test_multi_problem_1x1_weight_gradient_against_fp64(M, mode, b, t):
     specs = [(192, 384, 192, False, False, None), (192, 192, 0, False, False, None), (80, 192, 0, True, False, wide),
              (192, 160, 0, False, False, None), (48, 16, 0, False, True, None), (200, 200, 0, True, True, None),
              (192, 384, 192, False, False, None), (64, 320, 64, False, False, None)]
+    if t % 4:                                          # (the two-source form needs 16-byte rows, as glowtts_conv_wrw2 does)
+        specs = [sp for sp in specs if not sp[2]]
     probs = (M.hip.Wrw1Problem * len(specs))()
     keep, want = [], []
     for j, (cin, m, split, md, mx, xt) in enumerate(specs):
