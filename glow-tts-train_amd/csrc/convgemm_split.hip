@@ -87,9 +87,18 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lrow = lane & 15, lk = lane >> 4;
     const int ntile_t = (p.T + NT - 1) / NT;
-    const int b = blockIdx.x / ntile_t;
-    const int t0 = (blockIdx.x - b * ntile_t) * NT;
-    const int tile_m = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.wg_order) {
+        // workgroup ids are dealt round-robin over the 8 XCDs in id order = (x, then y): the R row tiles of a frame tile — which read
+        // the same activation tile — land on one XCD (gridDim.x % 8 == 0) but a whole grid row apart in dispatch order.  Re-numbered:
+        // ids i, i + 8, .., i + 8 (R - 1) are the R row tiles of one frame tile (same XCD, dispatched back to back)
+        const int id = blockIdx.x + blockIdx.y * gridDim.x, R = gridDim.y;
+        by = (id >> 3) % R;
+        bx = (id / (8 * R)) * 8 + (id & 7);
+    }
+    const int b = bx / ntile_t;
+    const int t0 = (bx - b * ntile_t) * NT;
+    const int tile_m = by;
     const int off = (4 - (p.pad & 3)) & 3;
     const int ts = t0 - p.pad - off;
     const int G = (p.Cin + 15) / 16;
@@ -863,6 +872,7 @@ static int launch_split(ConvGemmParams &p, const unsigned short *planes, long st
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
     dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
+    p.wg_order = (grid.y > 1 && grid.x % 8 == 0 && env_knob("GLOWTTS_CONV_ROW_ADJ", 1) == 1) ? 1 : 0;
     hipLaunchKernelGGL((convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS, IOB, NSA>), grid, dim3(256), lds, s, p, planes, stride);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv (split)");
 }

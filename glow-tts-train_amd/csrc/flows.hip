@@ -137,8 +137,15 @@ __global__ __launch_bounds__(256) void actnorm_stats_kernel(const float *__restr
 // One wavefront: lane (r, c) = (lane >> 3, lane & 7) holds A[r][c] and Inv[r][c] of an 8x8 frame whose top-left
 // n x n block is W (identity elsewhere).  Gauss-Jordan with partial pivoting, rows exchanged by lane shuffles;
 // fp64 internally (a few hundred flops), so log|det| and W^-1 are at least as accurate as torch's fp32 LU.
+// (multi form: blockIdx.x = problem; w from `w_table`, results at w_inv + blockIdx.x * out_stride, log|det| right behind W^-1)
 __global__ __launch_bounds__(64) void invconv_prepare_kernel(const float *__restrict__ w, float *__restrict__ w_inv,
-                                                             float *__restrict__ logdet_w, int n) {
+                                                             float *__restrict__ logdet_w, int n,
+                                                             const long long *__restrict__ w_table, long out_stride) {
+    if (w_table) {
+        w = reinterpret_cast<const float *>(w_table[blockIdx.x]);
+        w_inv += (long)blockIdx.x * out_stride;
+        logdet_w = w_inv + n * n;
+    }
     const int lane = threadIdx.x;
     const int r = lane >> 3, c = lane & 7;
     double a = (r < n && c < n) ? (double)w[r * n + c] : (r == c ? 1.0 : 0.0);
@@ -303,7 +310,13 @@ __device__ __forceinline__ int invconv_channel_rt(int k, int g, int C, int N) {
 
 // Gauss-Jordan with partial pivoting in LDS, fp64; thread r owns row r
 __global__ __launch_bounds__(64) void invconv_prepare_generic_kernel(const float *__restrict__ w, float *__restrict__ w_inv,
-                                                                     float *__restrict__ logdet_w, int n) {
+                                                                     float *__restrict__ logdet_w, int n,
+                                                                     const long long *__restrict__ w_table, long out_stride) {
+    if (w_table) {
+        w = reinterpret_cast<const float *>(w_table[blockIdx.x]);
+        w_inv += (long)blockIdx.x * out_stride;
+        logdet_w = w_inv + n * n;
+    }
     __shared__ double a[kInvConvMaxN][kInvConvMaxN + 1], inv[kInvConvMaxN][kInvConvMaxN + 1];
     __shared__ int piv_row;
     __shared__ double logabs;
@@ -1001,10 +1014,25 @@ extern "C" int glowtts_invconv_prepare(const float *w, float *w_inv, float *logd
     GLOWTTS_CHECK_ARG(w && w_inv && logdet_w, "glowtts_invconv_prepare: null pointer");
     GLOWTTS_CHECK_ARG(n >= 1 && n <= kInvConvMaxN, "glowtts_invconv_prepare: n_split=%d not in [1,%d]", n, kInvConvMaxN);
     if (n <= 8)
-        hipLaunchKernelGGL(invconv_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
+        hipLaunchKernelGGL(invconv_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n, nullptr, 0L);
     else
-        hipLaunchKernelGGL(invconv_prepare_generic_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n);
+        hipLaunchKernelGGL(invconv_prepare_generic_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, w_inv, logdet_w, n, nullptr, 0L);
     GLOWTTS_LAUNCH_CHECK("glowtts_invconv_prepare");
+}
+
+extern "C" int glowtts_invconv_prepare_multi(const long long *w_table, float *w_inv, long out_stride, int n_problems, int n,
+                                             glowtts_stream_t stream) {
+    GLOWTTS_CHECK_ARG(w_table && w_inv && n_problems >= 0, "glowtts_invconv_prepare_multi: bad argument");
+    GLOWTTS_CHECK_ARG(n >= 1 && n <= kInvConvMaxN, "glowtts_invconv_prepare_multi: n_split=%d not in [1,%d]", n, kInvConvMaxN);
+    GLOWTTS_CHECK_ARG(out_stride >= (long)n * n + 1, "glowtts_invconv_prepare_multi: out_stride %ld < n * n + 1", out_stride);
+    if (n_problems == 0) return 0;
+    if (n <= 8)
+        hipLaunchKernelGGL(invconv_prepare_kernel, dim3(n_problems), dim3(64), 0, (hipStream_t)stream, nullptr, w_inv, nullptr, n,
+                           w_table, out_stride);
+    else
+        hipLaunchKernelGGL(invconv_prepare_generic_kernel, dim3(n_problems), dim3(64), 0, (hipStream_t)stream, nullptr, w_inv, nullptr,
+                           n, w_table, out_stride);
+    GLOWTTS_LAUNCH_CHECK("glowtts_invconv_prepare_multi");
 }
 
 #define INVCONV_DISPATCH(KERNEL, GRID, ...)                                                              \

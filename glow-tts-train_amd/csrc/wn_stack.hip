@@ -314,7 +314,8 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     // io bits 8 / 9 (round 4, convops.FlowStackFn with fp32 tensors): the caller has produced y itself (the previous block's affine
     // apply fused with this block's ActNorm + InvConv: glowtts_coupling_actnorm_invconv_fwd, which also needs W^-1 / log det W made
     // beforehand) / the caller runs this block's affine apply itself, fused into the next block: `z` is not written
-    const bool skip_head = (io & 256) != 0, skip_tail = (io & 512) != 0;
+    // io bit 10: W^-1 and log det W of this block are in place already (glowtts_invconv_prepare_multi: one launch for the stack)
+    const bool skip_head = (io & 256) != 0, skip_tail = (io & 512) != 0, w_ready = (io & 1024) != 0;
     io &= 255;
     const int io_h = io & 1, io_f = (io >> 1) & 1;
     GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
@@ -334,7 +335,7 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     if (blk->pack_desc)
         WN_TRY(glowtts_pack_weight_multi(blk->pack_desc, blk->pack_prefix, blk->n_conv, blk->total_rows, stream));
     if (!skip_head) {
-        WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
+        if (!w_ready) WN_TRY(glowtts_invconv_prepare(blk->w, blk->w_inv, blk->logdet_w, n_split, stream));
         // flows 3i, 3i+1: y = W ((bias + e^logs x) mask) mask ; logdet = (sum logs + log det W * C/n) x_len
         WN_TRY(glowtts_actnorm_invconv_fwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->logdet_w, x_len, y, logdet,
                                               io == 1 ? y0h : nullptr, B, C, T, n_split, io_f, stream));
@@ -385,8 +386,10 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     hipStream_t ms = (hipStream_t)stream;
     hipStream_t ws = wgrad_stream ? (hipStream_t)wgrad_stream : ms;
     const long CT = (long)C * T, HT = (long)H * T;
-    // every packed weight-gradient accumulator of the block in one fill (the kernels add into it with atomics)
-    hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ms);
+    // every packed weight-gradient accumulator of the block in one fill (the kernels add into it with atomics) — on the stream the
+    // weight-gradient kernels run on: nothing else touches the accumulators (the previous step's un-pack is earlier on that stream),
+    // and on the chain the fill was 5 us per block between two backward-data launches
+    hipError_t e = hipMemsetAsync(blk->dwp_all, 0, (size_t)blk->dwp_floats * sizeof(float), ws);
     if (e != hipSuccess) { set_error("glowtts_flow_block_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     // affine apply backwards: dy = [dz0 ; dz1 e^logs mask], dout = [dm ; dlogs]
     if (!skip_cpl) WN_TRY(glowtts_coupling_bwd_io(y, out, mask, dz, dlogdet, dy, dout, B, C, T, sigmoid_scale, io_f, io_h, stream));
@@ -519,7 +522,7 @@ extern "C" int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float
     glowtts_stream_t wss = (glowtts_stream_t)ws;
     const long HT = (long)H * T, FT = (long)F * T;
     const int pad = (taps - 1) / 2, dk = H / heads;
-    hipError_t e = hipMemsetAsync(L->dwp_all, 0, (size_t)L->dwp_floats * sizeof(float), ms);
+    hipError_t e = hipMemsetAsync(L->dwp_all, 0, (size_t)L->dwp_floats * sizeof(float), ws);   // (on the weight-gradient stream: see glowtts_flow_block_bwd_io)
     if (e != hipSuccess) { set_error("glowtts_encoder_layer_bwd: memset: %s", hipGetErrorString(e)); return (int)e; }
     // LN2 backwards: dx1a = d(x1) through the residual path, dy2 = d(y2) through the dropout
     WN_TRY(glowtts_chan_layernorm_bwd_ex(x1, y2, nullptr, drop_2, drop_scale, L->gamma2, stats2, dx2, dx1a, drop_2 ? dy2 : nullptr,

@@ -409,13 +409,25 @@ class WNPackPlan:
         self.key = None
         self.gkey = None
         self.want_planes = want_planes       # only a WN stack's convolutions have bf16-plane kernels (convgemm_split.hip)
+        self.shared = None                   # StackArena this plan's packed weights live in (one pack launch per stack), or None
 
-    def ensure(self, params, n_layers=None, n_convs=None):
-        """params: (v, g, bias) per convolution; a WN stack passes n_layers (2 convolutions per layer)."""
+    @staticmethod
+    def make_key(params):
+        return tuple(0 if p is None else p.data_ptr() for p in params) + tuple(None if p is None else tuple(p.shape) for p in params)
+
+    @staticmethod
+    def arena_floats(params, n_convs):
+        shapes = [tuple(params[3 * i].shape) for i in range(n_convs)]
+        return sum(t * ((ci + 15) // 16) * co * 16 + t * ((co + 15) // 16) * ci * 16 for co, ci, t in shapes)
+
+    def ensure(self, params, n_layers=None, n_convs=None, arena=None, shared=None):
+        """params: (v, g, bias) per convolution; a WN stack passes n_layers (2 convolutions per layer).  `arena` / `shared`: the
+        slice of a StackArena's buffer this plan packs into (StackArena.ensure) instead of a buffer of its own."""
         n_convs = 2 * n_layers if n_convs is None else n_convs
-        key = tuple(0 if p is None else p.data_ptr() for p in params) + tuple(None if p is None else tuple(p.shape) for p in params)
-        if key == self.key:
+        key = self.make_key(params)
+        if key == self.key and arena is None:
             return
+        self.shared = shared                 # (a plan whose parameters moved leaves its stack's buffer: the stack rebuilds)
         dev = params[0].device
         self.convs = []          # (v, g, wp_f, wp_b, inv, cout, cin, taps, dwp_offset)
         rows, off = [0], 0
@@ -423,7 +435,8 @@ class WNPackPlan:
         # zero), so the optional split into bf16 planes (glowtts_conv_math) is one launch over it
         shapes = [tuple(params[3 * i].shape) for i in range(n_convs)]
         sizes = [(t * ((ci + 15) // 16) * co * 16, t * ((co + 15) // 16) * ci * 16) for co, ci, t in shapes]
-        self.wp_arena = torch.zeros(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
+        self.wp_arena = torch.zeros(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32) if arena is None else arena
+        assert self.wp_arena.numel() == sum(a + b for a, b in sizes)
         self.wp_planes = None                # bf16 planes of wp_arena (3 x n uint16), made on first use of a split mode
         cursor = 0
         for i in range(n_convs):
@@ -440,27 +453,37 @@ class WNPackPlan:
         self.dwp = torch.empty(off, device=dev, dtype=torch.float32)
         self.total_rows = rows[-1]
         self.prefix = torch.tensor(rows, dtype=torch.int32).to(dev)
+        self.rows = rows
         self.desc = torch.tensor(
             [[v.data_ptr(), 0 if g is None else g.data_ptr(), f.data_ptr(), b.data_ptr(), 0 if inv is None else inv.data_ptr(),
               cout, cin, taps] for (v, g, f, b, inv, cout, cin, taps, _) in self.convs], dtype=torch.int64).to(dev)
         self.key, self.gkey = key, None
         self.version = getattr(self, "version", 0) + 1
 
+    def _plane_home(self, make: bool):
+        """(packed buffer, its bf16 planes) this plan's planes are addressed in: its own, or its stack's."""
+        if self.shared is not None:
+            return self.shared.arena, self.shared.planes_buffer(make)
+        if make and self.wp_planes is None:       # (zeros: the k positions no packing covers must read as zero in every plane)
+            self.wp_planes = torch.zeros(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
+        return self.wp_arena, self.wp_planes
+
     def pack(self):
         self.pack_count = getattr(self, "pack_count", 0) + 1      # (planes made from the packed weights go stale here)
         if _SPLIT_MATH[0] and self.want_planes:   # bf16-plane arithmetic is on: the planes of the new weights in the same pass
-            if self.wp_planes is None:            # (zeros: the k positions no packing covers must read as zero in every plane)
-                self.wp_planes = torch.zeros(3 * self.wp_arena.numel(), device=self.wp_arena.device, dtype=torch.int16)
+            arena, planes = self._plane_home(True)
             call("glowtts_pack_weight_planes_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows,
-                 ptr(self.wp_arena), self.wp_arena.numel(), ptr(self.wp_planes))
+                 ptr(arena), arena.numel(), ptr(planes))
         else:
             call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
 
     def bind(self) -> bool:
         """Hand this stack's planes to the calling thread's next convolution launches (no-op in native fp32 mode)."""
-        if _SPLIT_MATH[0] and self.wp_planes is not None:
-            conv_bind_planes(self.wp_arena, self.wp_planes)
-            return True
+        if _SPLIT_MATH[0]:
+            arena, planes = self._plane_home(False)
+            if planes is not None:
+                conv_bind_planes(arena, planes)
+                return True
         return False
 
     @staticmethod
@@ -512,6 +535,49 @@ class WNPackPlan:
         if gkey != self.gkey:
             self._build_gdesc(params, gkey)
         call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
+
+
+class StackArena:
+    """ONE packed-weight buffer and ONE set of bf16 planes for all blocks of a flow stack (round 4): weight norm + packing + plane
+    split of the whole decoder is one launch per step where every block launched its own (17 us each, twelve of them on the
+    decoder's chain at config 2).  The blocks' plans keep their tables; their buffers are slices of this one, their plane bindings
+    point at it.  A plan whose parameters moved drops out (WNPackPlan.ensure) and the next `pack` rebuilds the stack."""
+
+    def __init__(self):
+        self.keys = None
+        self.planes = None
+
+    def planes_buffer(self, make: bool):
+        if make and self.planes is None:          # (zeros: the k positions no packing covers must read as zero in every plane)
+            self.planes = torch.zeros(3 * self.arena.numel(), device=self.arena.device, dtype=torch.int16)
+        return self.planes
+
+    def pack(self, plans, conv_params, n_convs):
+        keys = tuple(WNPackPlan.make_key(cp) for cp in conv_params)
+        if keys != self.keys or any(p.shared is not self for p in plans):
+            sizes = [WNPackPlan.arena_floats(cp, n_convs) for cp in conv_params]
+            self.arena = torch.zeros(sum(sizes), device=conv_params[0][0].device, dtype=torch.float32)
+            self.planes = None
+            off, rows = 0, [0]
+            for p, cp, n in zip(plans, conv_params, sizes):
+                p.ensure(cp, n_convs=n_convs, arena=self.arena[off: off + n], shared=self)
+                off += n
+                base = rows[-1]
+                rows += [base + r for r in p.rows[1:]]
+            self.desc = torch.cat([p.desc for p in plans]).contiguous()
+            self.prefix = torch.tensor(rows, dtype=torch.int32).to(self.arena.device)
+            self.n_conv, self.total_rows, self.keys = self.desc.shape[0], rows[-1], keys
+        for p in plans:
+            p.pack_count = getattr(p, "pack_count", 0) + 1
+        if _SPLIT_MATH[0] and plans[0].want_planes:
+            call("glowtts_pack_weight_planes_multi", ptr(self.desc), ptr(self.prefix), self.n_conv, self.total_rows, ptr(self.arena),
+                 self.arena.numel(), ptr(self.planes_buffer(True)))
+        else:
+            call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), self.n_conv, self.total_rows)
+
+
+# FlowStackFn: one weight-pack launch and one W^-1 / log det W launch for the whole stack (0: one of each per block)
+_STACK_PACK = os.environ.get("GLOWTTS_STACK_PACK", "1") != "0"
 
 
 # WN stack executor (csrc/wn_stack.hip queues a stack's whole launch sequence from C): "both" (default) = forward and
@@ -1172,22 +1238,45 @@ class FlowStackFn(Function):
         # fp32 tensors: block k's affine apply runs fused with block k + 1's ActNorm + InvConv (one pass over the flow tensor
         # instead of two; z_k is never written) — the block executors are told to leave those launches out (io bits 8 / 9)
         fuse = _FUSE_FLOWS and io == 0 and nb > 1 and n_split in (2, 4)      # (the fused kernels keep a group in registers: N <= 4)
+        stack_pack = _STACK_PACK and nb > 1
+        if stack_pack:                                            # every block's weight norm + packing (+ planes) in ONE launch
+            st = getattr(bplans[0], "_stack_arena", None)
+            if st is None:
+                st = bplans[0]._stack_arena = StackArena()
+            cps, o2 = [], 0
+            for k in range(nb):
+                cps.append(FlowBlockPlan.conv_params(params[o2: o2 + counts[k]], n_layers))
+                o2 += counts[k]
+            st.pack([bp.plan for bp in bplans], cps, 2 + 2 * n_layers)
+        # W^-1 and log det W of every block's invertible 1x1 convolution: one launch (a table of the weights' addresses, cached)
+        stack_prep = _STACK_PACK and nb > 1
+        if stack_prep:
+            o2, wkey = 0, []
+            for k in range(nb):
+                wkey.append(params[o2 + 2].data_ptr())
+                o2 += counts[k]
+            wtab = getattr(bplans[0], "_w_table", None)
+            if wtab is None or wtab[0] != wkey:
+                wtab = bplans[0]._w_table = (wkey, torch.tensor(wkey, dtype=torch.int64).to(dev))
+            call("glowtts_invconv_prepare_multi", ptr(wtab[1]), pw, n_split * n_split + 1, nb, n_split)
         off = 0
         for k in range(nb):
             pk = params[off: off + counts[k]]
             off += counts[k]
             bplan = bplans[k]
             plan = bplan.plan
-            plan.ensure(FlowBlockPlan.conv_params(pk, n_layers), n_convs=2 + 2 * n_layers)
-            plan.pack()
+            if not stack_pack:
+                plan.ensure(FlowBlockPlan.conv_params(pk, n_layers), n_convs=2 + 2 * n_layers)
+                plan.pack()
             bound = bplan.bind(io)
             try:
                 tab = bplan.table(pk, n_layers)
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
-                flags = int(io)
+                flags = int(io) | (1024 if stack_prep else 0)
                 if fuse and k > 0:
-                    call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
+                    if not stack_prep:
+                        call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
                     call("glowtts_coupling_actnorm_invconv_fwd", py + (k - 1) * nC * 4, po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]),
                          ptr(pk[2]), tab.logdet_w, pl, py + k * nC * 4, pld + (k - 1) * B * 4, pld + k * B * 4, B, C, T, n_split,
                          int(sigmoid_scale))

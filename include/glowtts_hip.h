@@ -27,6 +27,10 @@
  *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
  *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip; read at
  *                                                     every launch)
+ *                                 GLOWTTS_CONV_ROW_ADJ [1]    0 = the bf16-plane convolution kernels take their workgroups in grid order
+ *                                                     (all frame tiles of row tile 0, then row tile 1, ..) instead of numbering the
+ *                                                     row tiles of one frame tile into consecutive slots of one XCD
+ *                                                     (csrc/convgemm_split.hip; read at every launch)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
@@ -139,6 +143,13 @@ int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *
                                 const float *w, const float *w_inv, const float *dz, const float *dlogdet,
                                 const float *x_len, float *dx, float *dlogs, float *dbias, float *dw, int B, int C,
                                 int T, int n_split, glowtts_stream_t stream);
+/* W^-1 and log|det W| of `n_problems` invertible 1x1 convolutions in ONE launch (round 4: convops.FlowStackFn, one launch per
+ * step instead of one per flow block): w_table[i] = device address of the i-th (n, n) fp32 weight; results at
+ * w_inv + i * out_stride: n * n floats of W^-1 followed by log|det W| (out_stride >= n * n + 1).  Same arithmetic as
+ * glowtts_invconv_prepare (fp64 Gauss-Jordan with partial pivoting; NaN log-det for a negative determinant). */
+int glowtts_invconv_prepare_multi(const long long *w_table, float *w_inv, long out_stride, int n_problems, int n,
+                                  glowtts_stream_t stream);
+
 /* ---- the affine apply of block k fused with ActNorm + InvConvNear of block k + 1 (round 4; attentions.py:128-142 followed by
  * layers.py:182-199, 238-272): adjacent element-wise passes over the same flow tensor.  fp32 tensors, n_split in {2, 4}.
  * fwd: z = [y0 ; (m + e^logs' y1) mask] with (m, logs') = out_prev is formed in registers and never written;
@@ -498,7 +509,7 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
  *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads.
  *       fp32 tensors only (io & 3 == 0), for a caller that fuses a block's affine apply with the next block's ActNorm + InvConv
- *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
+ *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bit 10 = forward: W^-1 / log det W are in place (glowtts_invconv_prepare_multi); bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
  *       ActNorm + InvConv launch) / backward: no ActNorm + InvConv backward at the end (dx is not written); bit 9 = forward: no
  *       affine apply at the end (z is not written) / backward: dy and dout have been written by the caller (no coupling backward) */
 int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);
