@@ -835,6 +835,16 @@ def main():
         except Exception as exc:
             fused = None
             log(f"fused flow timing failed ({type(exc).__name__}: {exc})")
+        if fused:
+            # the subset as the step launches it, all by HIP events: the fused pair between blocks (timed just above) plus the first
+            # block's ActNorm + InvConv and the last block's coupling on the un-fused kernels (instrumented pass of this run)
+            ends = sum(hbm[k]["mean_us"] for k in ("glowtts_actnorm_invconv_fwd", "glowtts_actnorm_invconv_bwd", "glowtts_coupling_fwd",
+                                                   "glowtts_coupling_bwd") if k in hbm)
+            ms_l = fused["ms_per_step_fused_part"] + ends / 1e3
+            gb_l = sub_bytes / 1e9 * (8.0 * (args.blocks - 1) + 12.0) / (12.0 * args.blocks)     # 3X + 5X per pair, 12X for the two ends
+            fused.update({"ms_per_step": round(ms_l, 3), "alg_GB_as_launched": round(gb_l, 3),
+                          "frac": round(gb_l / (ms_l * 1e-3) / HBM_PEAK_GBS, 4),
+                          "survey_frac": round(survey_gb / (ms_l * 1e-3) / HBM_PEAK_GBS, 4)})
         out["roofline"].update({
             "conv_math": default_math,
             "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
