@@ -315,7 +315,11 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     // apply fused with this block's ActNorm + InvConv: glowtts_coupling_actnorm_invconv_fwd, which also needs W^-1 / log det W made
     // beforehand) / the caller runs this block's affine apply itself, fused into the next block: `z` is not written
     // io bit 10: W^-1 and log det W of this block are in place already (glowtts_invconv_prepare_multi: one launch for the stack)
+    // io bits 11 / 12: the end conv (needs bit 9) / the start conv (needs bit 8) are the caller's as well — glowtts_flow_boundary_fwd
+    // runs end conv(k), the flows between and start conv(k + 1) in one launch; this call is then the WN stack alone
     const bool skip_head = (io & 256) != 0, skip_tail = (io & 512) != 0, w_ready = (io & 1024) != 0;
+    const bool skip_end = (io & 2048) != 0, skip_start = (io & 4096) != 0;
+    GLOWTTS_CHECK_ARG((!skip_end || skip_tail) && (!skip_start || skip_head), "glowtts_flow_block_fwd: io bits 11 / 12 need bits 9 / 8");
     io &= 255;
     const int io_h = io & 1, io_f = (io >> 1) & 1;
     GLOWTTS_CHECK_ARG(io_h || !io_f, "glowtts_flow_block: a bf16 flow tensor needs bf16 hidden tensors (io = 0, 1 or 3)");
@@ -341,12 +345,14 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
                                               io == 1 ? y0h : nullptr, B, C, T, n_split, io_f, stream));
     }
     // flow 3i+2: h = start(y[:, :C/2]) mask  ->  WN  ->  out = end(h)  ->  z = [y0 ; (m + e^logs y1) mask], logdet += sum logs mask
-    WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0, 1,
-                               0, io_h, io_h, stream));
+    if (!skip_start)
+        WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0,
+                                   1, 0, io_h, io_h, stream));
     WN_TRY(glowtts_wn_fwd_io(blk->layers, blk->n_layers, h0, mask, cond, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
                              io_h, stream));
-    WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
-                               stream));
+    if (!skip_end)
+        WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
+                                   stream));
     if (skip_tail) return 0;
     return glowtts_coupling_fwd_io(y, out, mask, z, logdet, B, C, T, sigmoid_scale, 0, io_f, stream);
 }

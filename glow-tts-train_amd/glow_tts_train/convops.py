@@ -1238,6 +1238,9 @@ class FlowStackFn(Function):
         # fp32 tensors: block k's affine apply runs fused with block k + 1's ActNorm + InvConv (one pass over the flow tensor
         # instead of two; z_k is never written) — the block executors are told to leave those launches out (io bits 8 / 9)
         fuse = _FUSE_FLOWS and io == 0 and nb > 1 and n_split in (2, 4)      # (the fused kernels keep a group in registers: N <= 4)
+        # ... and, where the shapes allow, end conv(k) + those flows + start conv(k + 1) as ONE launch (csrc/flow_boundary.hip)
+        boundary = fuse and _FLOW_BOUNDARY and T % 4 == 0 and C <= 192 and C // n_split <= 64 and H <= 192
+        prev_tab = None
         stack_pack = _STACK_PACK and nb > 1
         if stack_pack:                                            # every block's weight norm + packing (+ planes) in ONE launch
             st = getattr(bplans[0], "_stack_arena", None)
@@ -1274,15 +1277,22 @@ class FlowStackFn(Function):
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
                 flags = int(io) | (1024 if stack_prep else 0)
-                if fuse and k > 0:
-                    if not stack_prep:
-                        call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
+                if fuse and k > 0 and not stack_prep:
+                    call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
+                if boundary and k > 0:
+                    call("glowtts_flow_boundary_fwd", psk + (k - 1) * nH * 4, prev_tab.wf_end, prev_tab.b_end, py + (k - 1) * nC * 4, pm,
+                         ptr(pk[0]), ptr(pk[1]), ptr(pk[2]), tab.logdet_w, pl, tab.wf_start, tab.b_start, po + (k - 1) * nC * 4,
+                         py + k * nC * 4, ph + k * nH * 4, pld + (k - 1) * B * 4, pld + k * B * 4, B, C, H, T, n_split,
+                         int(sigmoid_scale))
+                    flags |= 256 | 4096
+                elif fuse and k > 0:
                     call("glowtts_coupling_actnorm_invconv_fwd", py + (k - 1) * nC * 4, po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]),
                          ptr(pk[2]), tab.logdet_w, pl, py + k * nC * 4, pld + (k - 1) * B * 4, pld + k * B * 4, B, C, T, n_split,
                          int(sigmoid_scale))
                     flags |= 256
                 if fuse and k < nb - 1:
-                    flags |= 512
+                    flags |= 512 | (2048 if boundary else 0)
+                prev_tab = tab
                 call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl, None,
                      None if pdr is None else pdr + k * n_layers * 2 * nH, scale, py + k * nC * eF,
                      None if py0 is None else py0 + k * (nC // 2) * eA, ph + k * nH * eA,
@@ -1388,6 +1398,7 @@ class FlowStackFn(Function):
 # ----------------------------------------------------------------------------------------------------------------
 _ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
 _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn: coupling(k) fused with ActNorm + InvConv (k + 1)
+_FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
 
 
 def _enc_layer_table(group, attn, ffn, norm1, norm2):

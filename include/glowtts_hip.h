@@ -150,6 +150,20 @@ int glowtts_actnorm_invconv_bwd(const float *x, const float *mask, const float *
 int glowtts_invconv_prepare_multi(const long long *w_table, float *w_inv, long out_stride, int n_problems, int n,
                                   glowtts_stream_t stream);
 
+/* Everything between the WN stacks of two consecutive flow blocks in ONE launch (round 4, csrc/flow_boundary.hip; fp32 tensors):
+ *   out = end_k(skip_k) (attentions.py:131-133) ; z = [y_k0 ; (m + e^logs' y_k1) mask], logdet_prev += sum logs' mask (135-142) ;
+ *   y = W ((bias + e^logs z) mask) mask, logdet = (sum logs + logdet_w C / n_split) x_len (layers.py:182-199, 238-272) ;
+ *   h0 = (start_{k+1}(y[:, :C/2]) + b_start) mask (attentions.py:122-123).
+ * skip (B, H, T): block k's WN output; wp_end / wp_start: the convolutions' packed fp32 weights ([G][M][16], as glowtts_pack_weight*
+ * writes them); logs, bias, w, logdet_w: block k + 1's ActNorm / InvConvNear (logdet_w from glowtts_invconv_prepare*).
+ * Written: out (B, C, T), y (B, C, T), h0 (B, H, T), logdet (B); logdet_prev (B) is accumulated.  z is never written.
+ * The matrix products are convgemm_wd_kernel's (fp32 MFMA, same order): results equal those of the three launches it replaces.
+ * Limits: C <= 192, H <= 192, T % 4 == 0, n_split 2 or 4, 16-byte aligned tensors (anything else: argument error). */
+int glowtts_flow_boundary_fwd(const float *skip, const float *wp_end, const float *b_end, const float *y_prev, const float *mask,
+                              const float *logs, const float *bias, const float *w, const float *logdet_w, const float *x_len,
+                              const float *wp_start, const float *b_start, float *out, float *y, float *h0, float *logdet_prev,
+                              float *logdet, int B, int C, int H, int T, int n_split, int sigmoid_scale, glowtts_stream_t stream);
+
 /* ---- the affine apply of block k fused with ActNorm + InvConvNear of block k + 1 (round 4; attentions.py:128-142 followed by
  * layers.py:182-199, 238-272): adjacent element-wise passes over the same flow tensor.  fp32 tensors, n_split in {2, 4}.
  * fwd: z = [y0 ; (m + e^logs' y1) mask] with (m, logs') = out_prev is formed in registers and never written;
@@ -509,7 +523,7 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
  *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads.
  *       fp32 tensors only (io & 3 == 0), for a caller that fuses a block's affine apply with the next block's ActNorm + InvConv
- *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bit 10 = forward: W^-1 / log det W are in place (glowtts_invconv_prepare_multi); bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
+ *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bits 11 / 12 = forward: the end conv (with bit 9) / the start conv (with bit 8) are the caller's too (glowtts_flow_boundary_fwd); bit 10 = forward: W^-1 / log det W are in place (glowtts_invconv_prepare_multi); bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
  *       ActNorm + InvConv launch) / backward: no ActNorm + InvConv backward at the end (dx is not written); bit 9 = forward: no
  *       affine apply at the end (z is not written) / backward: dy and dout have been written by the caller (no coupling backward) */
 int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);

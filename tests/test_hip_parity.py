@@ -1871,3 +1871,48 @@ def test_keep_mask_kernel_statistics_and_repeatability(G):
         assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 2e-3, "another seed: an independent mask"
     m = G.ops.keep_mask((3, 5, 7), 0.25, "cuda")
     assert m.shape == (3, 5, 7) and m.dtype == torch.uint8
+
+
+@pytest.mark.parametrize("b,c,h,t,ns,sig", [(3, 160, 192, 400, 4, 0), (2, 160, 192, 52, 4, 1), (2, 64, 96, 36, 2, 0), (1, 192, 192, 128, 4, 0)])
+def test_flow_boundary_kernel_equals_its_three_launches(G, b, c, h, t, ns, sig):
+    """csrc/flow_boundary.hip: end conv(k) + coupling(k) + ActNorm / InvConv(k + 1) + start conv(k + 1) in one launch against the
+    three launches it replaces (1x1 conv, glowtts_coupling_actnorm_invconv_fwd, 1x1 conv with masked output): the matrix products
+    are the same fp32 MFMAs in the same order, so out / y / h0 must agree bit for bit; the log-determinants to fp32 summation order.
+    Ragged lengths, a last frame tile of 4 / 16 / 20 frames, channel counts that leave row tiles and k groups partly empty."""
+    from glow_tts_train._hip import call
+
+    P = lambda x: x.data_ptr()                                             # noqa: E731
+    torch.manual_seed(c + t)
+    f = lambda *s: torch.randn(*s, device="cuda")                          # noqa: E731
+    lens = torch.tensor([t, max(1, t - 7), max(1, t // 2)][:b], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().contiguous()
+    x_len = lens.float()
+    skip, y_prev = f(b, h, t) * mask[:, None], f(b, c, t) * mask[:, None]
+    logs, bias, w = f(c) * 0.1, f(c) * 0.1, torch.linalg.qr(f(ns, ns))[0].contiguous()
+    if float(torch.det(w)) < 0:                                            # (layers.py:232-234: the reference's init does the same)
+        w[:, 0] = -w[:, 0]
+    w_inv, logdet_w = torch.empty(ns * ns + 1, device="cuda"), None
+    call("glowtts_invconv_prepare", P(w), P(w_inv), P(w_inv) + 4 * ns * ns, ns)
+    logdet_w = w_inv[ns * ns:]
+    gh, gs = (h + 15) // 16, (c // 2 + 15) // 16
+    # packed weights [G][M][16] with zeros at the k positions beyond the channel count, as glowtts_pack_weight* leaves them
+    wp_end = torch.zeros(gh, c, 16, device="cuda")
+    wp_end.view(gh, c, 16).copy_((f(gh, c, 16) * 0.05) * (torch.arange(gh * 16, device="cuda").view(gh, 1, 16) < h))
+    wp_start = torch.zeros(gs, h, 16, device="cuda")
+    wp_start.copy_((f(gs, h, 16) * 0.05) * (torch.arange(gs * 16, device="cuda").view(gs, 1, 16) < c // 2))
+    b_end, b_start = f(c) * 0.1, f(h) * 0.1
+    got = [torch.full((b, c, t), float("nan"), device="cuda"), torch.full((b, c, t), float("nan"), device="cuda"),
+           torch.full((b, h, t), float("nan"), device="cuda"), torch.ones(b, device="cuda"), torch.full((b,), float("nan"), device="cuda")]
+    want = [x.clone() for x in got]
+    call("glowtts_flow_boundary_fwd", P(skip), P(wp_end), P(b_end), P(y_prev), P(mask), P(logs), P(bias), P(w), P(logdet_w), P(x_len),
+         P(wp_start), P(b_start), P(got[0]), P(got[1]), P(got[2]), P(got[3]), P(got[4]), b, c, h, t, ns, sig)
+    call("glowtts_conv_fwd", P(skip), h * t, P(wp_end), P(b_end), None, None, 0, P(want[0]), c * t, b, h, c, t, 1, 1, 0, 0, 0, 0)
+    call("glowtts_coupling_actnorm_invconv_fwd", P(y_prev), P(want[0]), P(mask), P(logs), P(bias), P(w), P(logdet_w), P(x_len),
+         P(want[1]), P(want[3]), P(want[4]), b, c, t, ns, sig)
+    call("glowtts_conv_fwd", P(want[1]), c * t, P(wp_start), P(b_start), P(mask), None, 0, P(want[2]), h * t, b, c // 2, h, t, 1, 1, 0,
+         0, 1, 0)
+    torch.cuda.synchronize()
+    for name, a, e in zip(("out", "y", "h0"), got, want):
+        assert torch.equal(a, e), (name, float((a - e).abs().max()))
+    assert_close(got[3], want[3], what="logdet_prev", rtol=1e-5, atol=1e-4 * max(1.0, float(want[3].abs().max())))
+    assert_close(got[4], want[4], what="logdet", rtol=1e-6, atol=1e-6)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of host-side switches in ONE process (boxes differ by several percent): alternating blocks of training steps.
 Usage: python tools/ab_flags.py NAME=VALUE_A,VALUE_B [steps_per_block] [blocks]
-  NAME in: stackpack (0|1: one weight-pack and one W^-1 launch for the flow stack), fuseflows (0|1: coupling(k) fused with ActNorm + InvConv(k + 1) in FlowStackFn), enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
+  NAME in: boundary (0|1: one launch between the WN stacks of consecutive blocks), stackpack (0|1: one weight-pack and one W^-1 launch for the flow stack), fuseflows (0|1: coupling(k) fused with ActNorm + InvConv(k + 1) in FlowStackFn), enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
   whole-layer executors vs the per-operator path), io (fp32|all|hidden), fused (0|1: layer-resident WN forward kernel),
   envs (library knobs that are read on every launch: envs=GLOWTTS_A:0+GLOWTTS_B:4,GLOWTTS_A:1+GLOWTTS_B:2)"""
 import os
@@ -37,6 +37,8 @@ def apply(v):
         _hip.wn_fused(v == "1")
     elif name == "fuseflows":                               # FlowStackFn: coupling(k) fused with ActNorm + InvConv(k + 1) on / off
         convops._FUSE_FLOWS = v == "1"
+    elif name == "boundary":                                # FlowStackFn: end conv(k) + flows + start conv(k + 1) in one launch on / off
+        convops._FLOW_BOUNDARY = v == "1"
     elif name == "stackpack":                               # FlowStackFn: one weight-pack launch per stack (1) or one per block (0)
         convops._STACK_PACK = v == "1"
     elif name == "nopack":                                  # TIMING ONLY (wrong numerics): the decoder's weight packs left out
