@@ -34,7 +34,7 @@ __device__ __forceinline__ float bnd_coupling_logs(float raw, bool sig) { return
 template <int N>
 __device__ __forceinline__ int bnd_channel(int k, int g, int C) { return (k / (N / 2)) * (C / 2) + g * (N / 2) + (k % (N / 2)); }
 
-constexpr int kBndNT = 32, kBndKP = 20, kBndOP = 33, kBndMaxG = 12, kBndRT = 3;
+constexpr int kBndKP = 20, kBndMaxG = 12, kBndRT = 3;
 
 // D[rows of this wave's tiles][32 frames] = W X: X k-packed in LDS ([g][32][kBndKP]), W packed [g][M][16] in global memory.
 // wave w owns row tiles w, w + 4, w + 8 (rows beyond M: zero weights through the buffer descriptor's range check)
@@ -51,24 +51,26 @@ __device__ __forceinline__ void bnd_wload(const float *__restrict__ wp, int M, i
     }
 }
 
+template <int NT>
 __device__ __forceinline__ void bnd_gemm(const float *__restrict__ wp, int M, int G, const float *Xs, int wave, int lrow, int lk,
-                                         f32x4 (&a)[2][kBndRT], f32x4 (&acc)[kBndRT][2]) {      // a[0]: group 0, loaded by the caller
+                                         f32x4 (&a)[2][kBndRT], f32x4 (&acc)[kBndRT][NT / 16]) {      // a[0]: group 0, loaded by the caller
+    constexpr int NC = NT / 16;
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto wload = [&](int g, int slot) { bnd_wload(wp, M, G, g, wave, lrow, lk, a[slot]); };
     const float *xd = Xs + lrow * kBndKP + lk * 4;
     auto step = [&](int g, const f32x4 (&aw)[kBndRT]) {
-        f32x4 bv[2];
+        f32x4 bv[NC];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(xd + (g * kBndNT + c * 16) * kBndKP);
+        for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4 *>(xd + (g * NT + c * 16) * kBndKP);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < kBndRT; ++r)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NC; ++c)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[r][j], bv[c][j], acc[r][c], 0, 0, 0);
     };
     for (int g = 0; g < G; g += 2) {                     // (two steps per trip: the weight ring's slots stay compile-time)
@@ -80,13 +82,16 @@ __device__ __forceinline__ void bnd_gemm(const float *__restrict__ wp, int M, in
     mfma_settle();
 }
 
-template <int N>
-__global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParams p) {
+template <int N, int NT>
+__global__ __launch_bounds__(256, NT == 16 ? 3 : 2) void flow_boundary_fwd_kernel(BoundaryParams p) {
+    constexpr int kBndNT = NT, kBndOP = NT + 1, NC = NT / 16, NQ = NT / 4;      // frames, LDS pitch of the row-major tiles, 16-frame column tiles, frame quads
+    constexpr int NSEL = 256 / (16 * NQ), NGI = kBndMaxG / NSEL;                // staging: group = gsel + NSEL gi
+    static_assert(NT == 16 || NT == 32, "16 or 32 frames per workgroup");
     extern __shared__ __align__(16) float smem[];
     const int C = p.C, H = p.H, T = p.T, half = C / 2;
     const int GH = (H + 15) / 16, GS = (half + 15) / 16;
     float *Xs = smem;                                    // [GH][32][kBndKP]   skip tile, k-packed
-    float *Os = Xs + kBndMaxG * kBndNT * kBndKP;         // [192][kBndOP]      out tile, later the h0 tile
+    float *Os = Xs + kBndMaxG * kBndNT * kBndKP;         // [192][NT + 1]      out tile, later the h0 tile
     float *Ys = Os + 192 * kBndOP;                       // [6][32][kBndKP]    y'[:, :C/2] tile, k-packed
     float *Ms = Ys + 6 * kBndNT * kBndKP;                // [32]               mask
     float *red = Ms + kBndNT;                            // [4]
@@ -101,8 +106,8 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
     float4 yin[2][N];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int i = tid + 256 * u, g = i >> 3, q = i & 7;
-        const bool ok = i < G * 8 && t0 + q * 4 < T;
+        const int i = tid + 256 * u, g = i / NQ, q = i % NQ;
+        const bool ok = i < G * NQ && t0 + q * 4 < T;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             yin[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -112,30 +117,30 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
 
     // ---- phase 0: skip tile and mask into LDS ---------------------------------------------------------------------------
     {
-        const int kk = tid & 15, qq = (tid >> 4) & 7, gsel = tid >> 7;
+        const int kk = tid & 15, qq = (tid >> 4) % NQ, gsel = tid / (16 * NQ);
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(p.skip + (long)b * H * T), 0, H * T * 4, 0x00020000);
         const bool tok = t0 + qq * 4 < T;
-        f32x4 v[kBndMaxG / 2];
+        f32x4 v[NGI];
 #pragma unroll
-        for (int gi = 0; gi < kBndMaxG / 2; ++gi) {
-            const int ch = (gsel + 2 * gi) * 16 + kk;
+        for (int gi = 0; gi < NGI; ++gi) {
+            const int ch = (gsel + NSEL * gi) * 16 + kk;
             v[gi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                   xrs, (tok && ch < H) ? (ch * T + t0 + qq * 4) * 4 : 0x7fffffff, 0, 0));
         }
         if (tid < kBndNT) Ms[tid] = t0 + tid < T ? p.mask[(long)b * T + t0 + tid] : 0.f;
         for (int i = tid; i < 6 * kBndNT * kBndKP; i += 256) Ys[i] = 0.f;      // (channels beyond C/2 of the last group: zeros)
 #pragma unroll
-        for (int gi = 0; gi < kBndMaxG / 2; ++gi) {
-            float *d = Xs + ((gsel + 2 * gi) * kBndNT + qq * 4) * kBndKP + kk;
+        for (int gi = 0; gi < NGI; ++gi) {
+            float *d = Xs + ((gsel + NSEL * gi) * kBndNT + qq * 4) * kBndKP + kk;
             d[0] = v[gi][0]; d[kBndKP] = v[gi][1]; d[2 * kBndKP] = v[gi][2]; d[3 * kBndKP] = v[gi][3];
         }
     }
     __syncthreads();
 
     // ---- phase 1: out = W_end skip + b_end -> LDS [C][33] -------------------------------------------------------------
-    f32x4 acc[kBndRT][2];
-    bnd_gemm(p.wp_end, C, (p.exp & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
+    f32x4 acc[kBndRT][NC];
+    bnd_gemm<NT>(p.wp_end, C, (p.exp & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
     bnd_wload(p.wp_start, H, GS, 0, wave, lrow, lk, aw[0]);          // (the start conv's first weights: under phase 2)
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
@@ -146,15 +151,15 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
             if (row < C) {
                 const float bb = p.b_end[row];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) Os[row * kBndOP + c * 16 + lrow] = acc[r][c][reg] + bb;
+                for (int c = 0; c < NC; ++c) Os[row * kBndOP + c * 16 + lrow] = acc[r][c][reg] + bb;
             }
         }
     }
     __syncthreads();
 
     // ---- phase 2: out leaves; coupling of block k, ActNorm + InvConv of block k + 1 per (group, frame quad) -----------------
-    for (int i = tid; i < C * 8; i += 256) {               // out tile -> global, 16-byte stores along t
-        const int row = i >> 3, q = i & 7;
+    for (int i = tid; i < C * NQ; i += 256) {              // out tile -> global, 16-byte stores along t
+        const int row = i / NQ, q = i % NQ;
         if (t0 + q * 4 < T) {
             const float *s = Os + row * kBndOP + q * 4;
             *reinterpret_cast<float4 *>(p.out + ((long)b * C + row) * T + t0 + q * 4) = make_float4(s[0], s[1], s[2], s[3]);
@@ -167,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                          // (G * 8 <= 512 items: C <= 192, n_split >= 2 ... checked on the host)
         const int i = tid + 256 * u;
-        const int g = i >> 3, q = i & 7;
-        if (i >= G * 8 || t0 + q * 4 >= T || (p.exp & 4)) continue;
+        const int g = i / NQ, q = i % NQ;
+        if (i >= G * NQ || t0 + q * 4 >= T || (p.exp & 4)) continue;
         const float *mq = Ms + q * 4;
         float yv[N][4];
 #pragma unroll
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
     }
 
     // ---- phase 3: h0 = (W_start y'0 + b_start) mask ------------------------------------------------------------------------
-    bnd_gemm(p.wp_start, H, (p.exp & 2) ? 0 : GS, Ys, wave, lrow, lk, aw, acc);
+    bnd_gemm<NT>(p.wp_start, H, (p.exp & 2) ? 0 : GS, Ys, wave, lrow, lk, aw, acc);
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
         const int row0 = (wave + 4 * r) * 16 + lk * 4;
@@ -229,13 +234,13 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_fwd_kernel(BoundaryParam
             if (row < H) {
                 const float bb = p.b_start[row];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) Os[row * kBndOP + c * 16 + lrow] = (acc[r][c][reg] + bb) * Ms[c * 16 + lrow];
+                for (int c = 0; c < NC; ++c) Os[row * kBndOP + c * 16 + lrow] = (acc[r][c][reg] + bb) * Ms[c * 16 + lrow];
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < H * 8; i += 256) {
-        const int row = i >> 3, q = i & 7;
+    for (int i = tid; i < H * NQ; i += 256) {
+        const int row = i / NQ, q = i % NQ;
         if (t0 + q * 4 < T) {
             const float *s = Os + row * kBndOP + q * 4;
             *reinterpret_cast<float4 *>(p.h0 + ((long)b * H + row) * T + t0 + q * 4) = make_float4(s[0], s[1], s[2], s[3]);
@@ -265,15 +270,18 @@ extern "C" int glowtts_flow_boundary_fwd(const float *skip, const float *wp_end,
     if ((long)B * T == 0) return 0;
     BoundaryParams p{skip, wp_end, b_end, y_prev, mask, logs, bias, w, logdet_w, x_len, wp_start, b_start,
                      out, y, h0, logdet_prev, logdet, B, C, H, T, sigmoid_scale, env_knob("GLOWTTS_BND_EXP", 0)};
-    constexpr size_t lds = ((size_t)kBndMaxG * kBndNT * kBndKP + 192 * kBndOP + 6 * kBndNT * kBndKP + kBndNT + 4) * sizeof(float);
-    const dim3 grid(B * ((T + kBndNT - 1) / kBndNT));
+    // 32 frames per workgroup (400 workgroups at config 2).  16-frame tiles (800 workgroups, three per CU) were measured: 36 us against
+    // 28 — every workgroup streams both weight matrices from L2, and halving the tile halves the use of each weight register
+    constexpr int nt = 32;
+    constexpr size_t lds = ((size_t)kBndMaxG * nt * kBndKP + 192 * (nt + 1) + 6 * nt * kBndKP + nt + 4) * sizeof(float);
+    const dim3 grid(B * ((T + nt - 1) / nt));
     static LdsLimit lim[2];
     if (n_split == 4) {
-        if (int rc_ = lim[0].ensure(reinterpret_cast<const void *>(&flow_boundary_fwd_kernel<4>), lds, "glowtts_flow_boundary_fwd")) return rc_;
-        hipLaunchKernelGGL(flow_boundary_fwd_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
+        if (int rc_ = lim[0].ensure(reinterpret_cast<const void *>(&flow_boundary_fwd_kernel<4, nt>), lds, "glowtts_flow_boundary_fwd")) return rc_;
+        hipLaunchKernelGGL((flow_boundary_fwd_kernel<4, nt>), grid, dim3(256), lds, (hipStream_t)stream, p);
     } else {
-        if (int rc_ = lim[1].ensure(reinterpret_cast<const void *>(&flow_boundary_fwd_kernel<2>), lds, "glowtts_flow_boundary_fwd")) return rc_;
-        hipLaunchKernelGGL(flow_boundary_fwd_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+        if (int rc_ = lim[1].ensure(reinterpret_cast<const void *>(&flow_boundary_fwd_kernel<2, nt>), lds, "glowtts_flow_boundary_fwd")) return rc_;
+        hipLaunchKernelGGL((flow_boundary_fwd_kernel<2, nt>), grid, dim3(256), lds, (hipStream_t)stream, p);
     }
     GLOWTTS_LAUNCH_CHECK("glowtts_flow_boundary_fwd");
 }
