@@ -380,7 +380,11 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     // io bits 8 / 9 (see glowtts_flow_block_fwd_io): the ActNorm + InvConv backward at the END of this block's chain is left to the
     // caller (fused with the previous block's coupling backward: glowtts_coupling_actnorm_invconv_bwd) / dy and dout have been
     // produced by the caller (the same fused kernel one block later in the flow): no coupling backward at the start
+    // io bits 11 / 12 (glowtts_flow_boundary_bwd): dskip has been produced by the caller too (with bit 9: no end-conv backward-data
+    // here) / the start conv's backward-data is the caller's (with bit 8: this call ends with the WN stack's dx_wn)
     const bool skip_ai = (io & 256) != 0, skip_cpl = (io & 512) != 0;
+    const bool skip_end_bd = (io & 2048) != 0, skip_start_bd = (io & 4096) != 0;
+    GLOWTTS_CHECK_ARG((!skip_end_bd || skip_cpl) && (!skip_start_bd || skip_ai), "glowtts_flow_block_bwd: io bits 11 / 12 need bits 9 / 8");
     io &= 255;
     GLOWTTS_CHECK_ARG(!io || !two_source, "glowtts_flow_block_bwd: bf16 tensors use the d_rs form");
     GLOWTTS_CHECK_ARG(!(skip_ai || skip_cpl) || io == 0, "glowtts_flow_block_bwd: the fused-flow flags go with fp32 tensors");
@@ -410,8 +414,9 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
     }
     // (two-source form: dskip leaves this conv masked, which is the last WN layer's d_rs — see glowtts_wn_bwd_io)
     const int pre_mask = (two_source && !io) ? 1 : 0;
-    WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, pre_mask ? mask : nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0,
-                               pre_mask, 0, io_h, io_h, stream));
+    if (!skip_end_bd)
+        WN_TRY(glowtts_conv_fwd_io(dout, CT, blk->wb_end, nullptr, pre_mask ? mask : nullptr, nullptr, 0, dskip, HT, B, C, H, T, 1, 1, 0, 0,
+                                   pre_mask, 0, io_h, io_h, stream));
     // the gated conv stack (its weight gradients go to the second stream as well; un-packing is done below for the block).
     // With bf16 tensors the stack masks its own input gradient: the start conv's weight gradient then needs no mask.
     WN_TRY(glowtts_wn_bwd_io(blk->layers, blk->n_layers, h0, xs, acts, ts, mask, drop, drop_scale, dskip, d_rs, d_xin, dx_wn, dcond,
@@ -448,8 +453,9 @@ extern "C" int glowtts_flow_block_bwd_io(const glowtts_flow_block *blk, const vo
         WN_TRY(wrw_any(start_in, start_bs, dx_wn, HT, io_h ? nullptr : mask, blk->dwp_start, blk->db_start, B, C / 2, H, T, 1, 1, 0, io_h,
                        (glowtts_stream_t)ws));
     }
-    WN_TRY(glowtts_conv_fwd_io(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, io_h, io_f,
-                               stream));
+    if (!skip_start_bd)
+        WN_TRY(glowtts_conv_fwd_io(dx_wn, HT, blk->wb_start, nullptr, mask, dy, CT, dy, CT, B, H, C / 2, T, 1, 1, 0, 1, 0, 0, io_h, io_f,
+                                   stream));
     // flows 3i+1, 3i backwards in one pass; parameter gradients accumulate straight into their targets
     if (!skip_ai)
         WN_TRY(glowtts_actnorm_invconv_bwd_io(x, mask, blk->logs, blk->bias, blk->w, blk->w_inv, dy, dlogdet, x_len, dx, blk->dlogs,

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "glowtts_actnorm_invconv_bwd": [_P] * 13 + [_I] * 4,
     "glowtts_invconv_prepare_multi": [_P, _P, _L, _I, _I],
     "glowtts_flow_boundary_fwd": [_P] * 17 + [_I] * 6,
+    "glowtts_flow_boundary_bwd": [_P] * 15 + [_I] * 7,
+    "glowtts_flow_boundary_bwd_reduce": [_P] * 7 + [_I] * 4,
     "glowtts_coupling_actnorm_invconv_fwd": [_P] * 11 + [_I] * 5,
     "glowtts_coupling_actnorm_invconv_bwd": [_P] * 15 + [_I] * 5,
     "glowtts_coupling_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I],

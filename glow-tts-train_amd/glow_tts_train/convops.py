@@ -1304,6 +1304,7 @@ class FlowStackFn(Function):
         ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]),
                               *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale, ctx.fuse = cfg, bplans, counts, params, taps, scale, fuse
+        ctx.boundary = boundary
         return zs[nb - 1], logdets.sum(0)
 
     @staticmethod
@@ -1356,6 +1357,16 @@ class FlowStackFn(Function):
             for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, zs):
                 if t is not None:
                     t.record_stream(wgrad.side)
+        # between blocks (fp32 tensors): start conv backward-data(k) + ActNorm / InvConv backward(k) + coupling backward(k - 1) + end conv
+        # backward-data(k - 1) as ONE launch on the chain (csrc/flow_boundary.hip); the ActNorm / InvConv parameter gradients come out
+        # as per-workgroup partials, added up by a small launch behind the block's weight gradients
+        boundary = ctx.fuse and ctx.boundary and _FLOW_BOUNDARY_BWD
+        if boundary:
+            n_part = B * ((T + 31) // 32) * (C // n_split) * (2 * n_split + n_split * n_split)
+            part = torch.empty(nb - 1, n_part, device=dev, dtype=torch.float32)
+            ppart = ptr(part)
+            if wgrad.enabled:
+                part.record_stream(wgrad.side)
         for k in range(nb - 1, -1, -1):
             pk = params[offs[k]: offs[k + 1]]
             bplan = bplans[k]
@@ -1365,6 +1376,8 @@ class FlowStackFn(Function):
             tab.logdet_w = tab.w_inv + 4 * n_split * n_split
             fuse = ctx.fuse
             flags = int(io) | (256 if fuse and k > 0 else 0) | (512 if fuse and k < nb - 1 else 0)
+            if boundary:
+                flags |= (4096 if k > 0 else 0) | (2048 if k < nb - 1 else 0)
             bound = bplan.bind(io)
             try:
                 call("glowtts_flow_block_bwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl,
@@ -1386,7 +1399,23 @@ class FlowStackFn(Function):
                     _notify(conv_live)
             else:
                 _notify(conv_live)
-            if ai_late:
+            if ai_late and boundary:
+                tab_prev = bplans[k - 1].table(params[offs[k - 1]: offs[k]], n_layers)
+                pp = ppart + (k - 1) * n_part * 4
+                call("glowtts_flow_boundary_bwd", pdxw + k * n_layers * nH * 4, tab.wb_start, pdy + k * nC * 4, py + (k - 1) * nC * 4,
+                     po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]), ptr(pk[2]), pdl, tab_prev.wb_end, pdy + (k - 1) * nC * 4,
+                     pdo + (k - 1) * nC * 4, pds + (k - 1) * nH * 4, pp, B, C, H, T, n_split, int(sigmoid_scale), int(two_src))
+                if on_side:
+                    wgrad.side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(wgrad.side):
+                        call("glowtts_flow_boundary_bwd_reduce", pp, tab.w_inv, pdl, pl, ptr(pk[0].grad), ptr(pk[1].grad),
+                             ptr(pk[2].grad), B, C, T, n_split)
+                        _notify(live[:3])
+                else:
+                    call("glowtts_flow_boundary_bwd_reduce", pp, tab.w_inv, pdl, pl, ptr(pk[0].grad), ptr(pk[1].grad), ptr(pk[2].grad),
+                         B, C, T, n_split)
+                    _notify(live[:3])
+            elif ai_late:
                 # block k's ActNorm + InvConv backward fused with block k - 1's coupling backward: dy_k -> dy_{k-1}, dout_{k-1}
                 call("glowtts_coupling_actnorm_invconv_bwd", py + (k - 1) * nC * 4, po + (k - 1) * nC * 4, pm, ptr(pk[0]), ptr(pk[1]),
                      ptr(pk[2]), tab.w_inv, pdy + k * nC * 4, pdl, pl, pdy + (k - 1) * nC * 4, pdo + (k - 1) * nC * 4, ptr(pk[0].grad),
@@ -1399,6 +1428,7 @@ class FlowStackFn(Function):
 _ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
 _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn: coupling(k) fused with ActNorm + InvConv (k + 1)
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
+_FLOW_BOUNDARY_BWD = os.environ.get("GLOWTTS_FLOW_BOUNDARY_BWD", "1") != "0"   # ... and the same in the backward
 
 
 def _enc_layer_table(group, attn, ffn, norm1, norm2):

@@ -164,6 +164,22 @@ int glowtts_flow_boundary_fwd(const float *skip, const float *wp_end, const floa
                               const float *wp_start, const float *b_start, float *out, float *y, float *h0, float *logdet_prev,
                               float *logdet, int B, int C, int H, int T, int n_split, int sigmoid_scale, glowtts_stream_t stream);
 
+/* The same boundary backwards, ONE launch on the chain (csrc/flow_boundary.hip; fp32 tensors):
+ *   dyf = dy_next + [W_start^T (dx_wn mask) ; 0]  (the start conv's backward-data of block k + 1, mask_in form) ; the ActNorm +
+ *   InvConvNear backward of block k + 1 on z recomputed from (y_prev, out_prev) and block k's coupling backward — the arithmetic of
+ *   glowtts_coupling_actnorm_invconv_bwd — writing dy_prev, dout_prev (B, C, T) ; dskip = W_end^T dout_prev, times the mask if
+ *   mask_dskip (the end conv's backward-data of block k).  wb_start / wb_end: the convolutions' packed backward weights.
+ * The ActNorm / InvConv parameter gradients leave as per-workgroup partials in `partial`
+ * (B * ceil(T / 32) * (C / n_split) * (2 n_split + n_split^2) floats); glowtts_flow_boundary_bwd_reduce ADDS their sums (and the log-determinant
+ * terms, as glowtts_actnorm_invconv_bwd does) into dlogs (C), dbias (C), dw (n, n) — any stream that waits for the first launch.
+ * Limits as glowtts_flow_boundary_fwd. */
+int glowtts_flow_boundary_bwd(const float *dx_wn, const float *wb_start, const float *dy_next, const float *y_prev, const float *out_prev,
+                              const float *mask, const float *logs, const float *bias, const float *w, const float *dlogdet,
+                              const float *wb_end, float *dy_prev, float *dout_prev, float *dskip, float *partial, int B, int C, int H,
+                              int T, int n_split, int sigmoid_scale, int mask_dskip, glowtts_stream_t stream);
+int glowtts_flow_boundary_bwd_reduce(const float *partial, const float *w_inv, const float *dlogdet, const float *x_len, float *dlogs,
+                                     float *dbias, float *dw, int B, int C, int T, int n_split, glowtts_stream_t stream);
+
 /* ---- the affine apply of block k fused with ActNorm + InvConvNear of block k + 1 (round 4; attentions.py:128-142 followed by
  * layers.py:182-199, 238-272): adjacent element-wise passes over the same flow tensor.  fp32 tensors, n_split in {2, 4}.
  * fwd: z = [y0 ; (m + e^logs' y1) mask] with (m, logs') = out_prev is formed in registers and never written;
@@ -523,7 +539,7 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       (needs bit 0) = the flow tensor too (x, y, z, dz, dy, dx).  io = 1 keeps the invertible chain in fp32, as the
  *       reference's autocast does, and needs y0h, the bf16 copy of y's first half that the start conv reads.
  *       fp32 tensors only (io & 3 == 0), for a caller that fuses a block's affine apply with the next block's ActNorm + InvConv
- *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bits 11 / 12 = forward: the end conv (with bit 9) / the start conv (with bit 8) are the caller's too (glowtts_flow_boundary_fwd); bit 10 = forward: W^-1 / log det W are in place (glowtts_invconv_prepare_multi); bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
+ *       (glowtts_coupling_actnorm_invconv_fwd / _bwd): bits 11 / 12 = the end conv (with bit 9) / the start conv (with bit 8) — in the backward their backward-data launches — are the caller's too (glowtts_flow_boundary_fwd / _bwd); bit 10 = forward: W^-1 / log det W are in place (glowtts_invconv_prepare_multi); bit 8 = forward: y has been written by the caller (no W^-1 factorisation, no
  *       ActNorm + InvConv launch) / backward: no ActNorm + InvConv backward at the end (dx is not written); bit 9 = forward: no
  *       affine apply at the end (z is not written) / backward: dy and dout have been written by the caller (no coupling backward) */
 int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);

@@ -1916,3 +1916,55 @@ def test_flow_boundary_kernel_equals_its_three_launches(G, b, c, h, t, ns, sig):
         assert torch.equal(a, e), (name, float((a - e).abs().max()))
     assert_close(got[3], want[3], what="logdet_prev", rtol=1e-5, atol=1e-4 * max(1.0, float(want[3].abs().max())))
     assert_close(got[4], want[4], what="logdet", rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,c,h,t,ns,sig,mask_dskip", [(3, 160, 192, 400, 4, 0, 1), (2, 160, 192, 52, 4, 1, 0), (2, 64, 96, 36, 2, 0, 1),
+                                                        (1, 192, 192, 128, 4, 0, 1)])
+def test_flow_boundary_backward_kernel_equals_its_three_launches(G, b, c, h, t, ns, sig, mask_dskip):
+    """csrc/flow_boundary.hip backwards: start conv backward-data(k + 1) + ActNorm / InvConv backward(k + 1) + coupling backward(k) +
+    end conv backward-data(k) in one launch (+ the small reduction of the parameter-gradient partials) against the three launches it
+    replaces: dy, dout, dskip bit for bit (same MFMA products in the same order, same element-wise arithmetic); dlogs / dbias / dW
+    to fp32 summation order."""
+    from glow_tts_train._hip import call
+
+    P = lambda x: x.data_ptr()                                             # noqa: E731
+    torch.manual_seed(c + 3 * t)
+    f = lambda *s: torch.randn(*s, device="cuda")                          # noqa: E731
+    lens = torch.tensor([t, max(1, t - 7), max(1, t // 2)][:b], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float().contiguous()
+    x_len = lens.float()
+    dx_wn, dy_next = f(b, h, t), f(b, c, t)
+    y_prev, out_prev = f(b, c, t) * mask[:, None], f(b, c, t) * 0.3
+    logs, bias, w = f(c) * 0.1, f(c) * 0.1, torch.linalg.qr(f(ns, ns))[0].contiguous()
+    if float(torch.det(w)) < 0:
+        w[:, 0] = -w[:, 0]
+    w_inv = torch.empty(ns * ns + 1, device="cuda")
+    call("glowtts_invconv_prepare", P(w), P(w_inv), P(w_inv) + 4 * ns * ns, ns)
+    dlogdet = f(b)
+    gh, gc = (h + 15) // 16, (c + 15) // 16
+    wb_start = (f(gh, c // 2, 16) * 0.05) * (torch.arange(gh * 16, device="cuda").view(gh, 1, 16) < h)      # [G(H)][C/2][16]
+    wb_end = (f(gc, h, 16) * 0.05) * (torch.arange(gc * 16, device="cuda").view(gc, 1, 16) < c)             # [G(C)][H][16]
+    wb_start, wb_end = wb_start.contiguous(), wb_end.contiguous()
+    nan = float("nan")
+    got = [torch.full((b, c, t), nan, device="cuda"), torch.full((b, c, t), nan, device="cuda"), torch.full((b, h, t), nan, device="cuda")]
+    ggrad = [torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(ns, ns, device="cuda")]
+    want = [x.clone() for x in got]
+    wgrad = [x.clone() for x in ggrad]
+    n_part = b * ((t + 31) // 32) * (c // ns) * (2 * ns + ns * ns)
+    part = torch.full((n_part,), nan, device="cuda")
+    call("glowtts_flow_boundary_bwd", P(dx_wn), P(wb_start), P(dy_next), P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w),
+         P(dlogdet), P(wb_end), P(got[0]), P(got[1]), P(got[2]), P(part), b, c, h, t, ns, sig, mask_dskip)
+    call("glowtts_flow_boundary_bwd_reduce", P(part), P(w_inv), P(dlogdet), P(x_len), P(ggrad[0]), P(ggrad[1]), P(ggrad[2]), b, c, t, ns)
+    # the three launches: dy_next[:, :C/2] += W_start^T (dx_wn mask) ; the fused flow backward ; dskip = W_end^T dout [mask]
+    dyf = dy_next.clone()
+    call("glowtts_conv_fwd", P(dx_wn), h * t, P(wb_start), None, P(mask), P(dyf), c * t, P(dyf), c * t, b, h, c // 2, t, 1, 1, 0, 1, 0, 0)
+    call("glowtts_coupling_actnorm_invconv_bwd", P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w), P(w_inv), P(dyf), P(dlogdet),
+         P(x_len), P(want[0]), P(want[1]), P(wgrad[0]), P(wgrad[1]), P(wgrad[2]), b, c, t, ns, sig)
+    call("glowtts_conv_fwd", P(want[1]), c * t, P(wb_end), None, P(mask) if mask_dskip else None, None, 0, P(want[2]), h * t, b, c, h, t,
+         1, 1, 0, 0, mask_dskip, 0)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(part).any()), "a partial was left unwritten"
+    for name, a, e in zip(("dy", "dout", "dskip"), got, want):
+        assert torch.equal(a, e), (name, float((a - e).abs().max()))
+    for name, a, e in zip(("dlogs", "dbias", "dw"), ggrad, wgrad):
+        assert_close(a, e, what=name, rtol=2e-4, atol=2e-4 * max(1.0, float(e.abs().max())))
