@@ -1428,7 +1428,10 @@ class FlowStackFn(Function):
 _ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
 _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn: coupling(k) fused with ActNorm + InvConv (k + 1)
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
-_FLOW_BOUNDARY_BWD = os.environ.get("GLOWTTS_FLOW_BOUNDARY_BWD", "1") != "0"   # ... and the same in the backward
+# ... and the same in the backward: OPT-IN.  The kernel is 32 us against 45 for the three launches alone, but in the step the chain
+# waits for the weight gradients' compute units at every block boundary of the backward whatever it launches (13.73 -> 13.72 ms per
+# step), and the extra stream hand-over for its parameter-gradient reduction costs 1.4 ms of host enqueue (DESIGN.md lesson 36)
+_FLOW_BOUNDARY_BWD = os.environ.get("GLOWTTS_FLOW_BOUNDARY_BWD", "0") == "1"
 
 
 def _enc_layer_table(group, attn, ffn, norm1, norm2):

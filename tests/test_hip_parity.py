@@ -1396,9 +1396,12 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
     orig, orig_stack = convops.FlowBlockFn.forward, convops.FlowStackFn.forward
     # "stack": every block in ONE autograd node (convops.FlowStackFn; not with conditioning rows); "both": one node per block;
     # "fwd": the block executor declines, the per-operator path runs
-    for mode in ("stack", "both", "fwd"):
-        convops._WN_NATIVE = "both" if mode == "stack" else mode
-        G.models._FLOW_STACK = mode == "stack"
+    # "stack+bwd": the stack node with the opt-in one-launch block boundary of the BACKWARD as well (GLOWTTS_FLOW_BOUNDARY_BWD=1)
+    for mode in ("stack", "stack+bwd", "both", "fwd"):
+        convops._WN_NATIVE = "both" if mode.startswith("stack") else mode
+        G.models._FLOW_STACK = mode.startswith("stack")
+        bnd_bwd = convops._FLOW_BOUNDARY_BWD
+        convops._FLOW_BOUNDARY_BWD = mode == "stack+bwd"
         calls, stack_calls = [], []
         convops.FlowBlockFn.forward = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
         convops.FlowStackFn.forward = staticmethod(lambda *a, _o=orig_stack, _c=stack_calls: (_c.append(1), _o(*a))[1])
@@ -1415,6 +1418,7 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
         finally:
             convops._WN_NATIVE = "both"
             G.models._FLOW_STACK = True
+            convops._FLOW_BOUNDARY_BWD = bnd_bwd
             convops.FlowBlockFn.forward = orig
             convops.FlowStackFn.forward = orig_stack
         used[mode] = (len(calls), len(stack_calls))
@@ -1423,9 +1427,9 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
             grads["<speaker rows g>"] = gg.grad.clone()
         res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), grads)
     assert used["both"] == (blocks, 0) and used["fwd"] == (0, 0), used
-    assert used["stack"] == ((0, 1) if gin == 0 else (blocks, 0)), used          # conditioning rows: one node per block
+    assert used["stack"] == used["stack+bwd"] == ((0, 1) if gin == 0 else (blocks, 0)), used   # conditioning rows: one node per block
     z0, l0, dx0, g0 = res["fwd"]
-    for mode in ("both", "stack"):
+    for mode in ("both", "stack", "stack+bwd"):
         z1, l1, dx1, g1 = res[mode]
         assert_close(z1, z0, what=f"{mode}: z", rtol=1e-6, atol=1e-6)
         assert_close(l1, l0, what=f"{mode}: logdet", rtol=1e-6, atol=1e-4)
