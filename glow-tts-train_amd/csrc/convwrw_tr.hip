@@ -48,8 +48,8 @@ struct WrwTrGeom {
     static constexpr int XPL = XR * XP, DPL = CF * DP;  // one plane image
     static_assert(TAPS - 1 + OFF < 8 && (XP / 4) % 8 == 4 && (DP / 4) % 8 == 4, "window and bank layout");
     static constexpr size_t group_bytes(int ns) { return (size_t)ns * (XPL + DPL); }
-    static constexpr size_t lds_bytes(int ns, bool w32 = false) {
-        const size_t img = 2 * group_bytes(ns), red = (size_t)TAPS * (w32 ? 16 : MT * 4) * 256 * 4;
+    static constexpr size_t lds_bytes(int ns, bool w32 = false, int ng = 2) {
+        const size_t img = ng * group_bytes(ns), red = ng == 2 ? (size_t)TAPS * (w32 ? 16 : MT * 4) * 256 * 4 : 0;
         return (img > red ? img : red) + MR * sizeof(float);
     }
 };
@@ -61,9 +61,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Same matrix work; but a 32x32x16 MFMA holds the SIMD's vector issue port 8 of its 32 cycles where the 16x16x32 one holds it 8 of
 // 16, so the SIMD's OTHER wave — splitting and storing the next chunk, ~2 vector instructions per 16 MFMA cycles, the pace-setter of
 // the W32 = false form — gets three quarters of the issue slots instead of half.  Four partial sums per output meet in LDS.
-template <int NS, int TAPS, int MT, bool W32 = false>
-__global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
+// NG = 1 (round 4, opt-in: GLOWTTS_WRW_TR_NG=1): ONE group per workgroup — 256 threads, one LDS image (59 KB for the 5-tap 64 x 64
+// form instead of 118): the multiply and the store phase of a workgroup then alternate instead of overlapping, and what fills the matrix
+// pipe meanwhile is whatever else the CU holds — in the backward a workgroup of the chain's convolution kernels, which the two-group
+// form's LDS keeps off the CU (DESIGN.md lesson 36).
+template <int NS, int TAPS, int MT, bool W32 = false, int NG = 2>
+__global__ __launch_bounds__(256 * NG, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     static_assert(!W32 || MT == 2, "the 32x32 form is the 64 x 32 tile");
+    static_assert(NG == 2 || !W32, "one group: the 16x16x32 forms only");
     using G = WrwTrGeom<TAPS, MT>;
     constexpr int MR = G::MR, CF = G::CF, PAD = G::PAD, OFF = G::OFF, XR = G::XR, XP = G::XP, DP = G::DP;
     constexpr int XPL = G::XPL, DPL = G::DPL;
@@ -71,10 +76,10 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     constexpr int NDI = (MR / 2) * (CF / 4), NDR = (NDI + 255) / 256;      // d items
     constexpr int CPH = MR / 32;                                           // 16-pair halves of a d row
     extern __shared__ __align__(16) char smem_tr[];
-    const int tid = threadIdx.x, grp = tid >> 8, gt = tid & 255, wave = (tid >> 6) & 3, lane = tid & 63;
+    const int tid = threadIdx.x, grp = NG == 2 ? tid >> 8 : 0, gt = tid & 255, wave = (tid >> 6) & 3, lane = tid & 63;
     char *Xg = smem_tr + grp * G::group_bytes(NS);
     char *Dg = Xg + NS * XPL;
-    float *rowacc = reinterpret_cast<float *>(smem_tr + G::lds_bytes(NS, W32) - MR * sizeof(float));
+    float *rowacc = reinterpret_cast<float *>(smem_tr + G::lds_bytes(NS, W32, NG) - MR * sizeof(float));
 
     // ---- which tile, which frames (workgroups numbered XCD-major: the splits of one tile share frames with the other tiles
     // of the same split, which then sit on one or two XCDs' L2s)
@@ -96,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
     const int nct = (p.T + CF - 1) / CF;
     const int c0 = split * p.nb;
     const int n_split = max(0, min(p.B * nct, c0 + p.nb) - c0);           // (utterance, chunk) items of this workgroup
-    const int n_my = (n_split - grp + 1) / 2;                              // this group: items c0 + grp, c0 + grp + 2, ...
-    const int n_max = (n_split + 1) / 2;
+    const int n_my = NG == 2 ? (n_split - grp + 1) / 2 : n_split;          // this group: items c0 + grp, c0 + grp + 2, ... (NG = 1: all)
+    const int n_max = NG == 2 ? (n_split + 1) / 2 : n_split;
 
     f32x4 acc[W32 ? 1 : TAPS][W32 ? 1 : MT];
     f32x16 acc32[W32 ? TAPS : 1];
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
         const int b = nb_, tc = nci * CF;
         const int ts = tc - PAD - OFF;
         steps_loaded = (min(CF, p.T - tc) + 31) >> 5;
-        nci += 2;
+        nci += NG;
         while (nci >= nct) { nci -= nct; ++nb_; }
         const int xbo = (b * (int)p.x_bs + ts) * 4, dbo = (b * (int)d_bs + tc) * 4;     // (ts may be -4: only added to valid quads)
         const int xlo = -ts, xhi = p.T - ts, dhi = p.T - tc;                             // valid quads: xlo <= 4 fq < xhi (T % 4 == 0)
@@ -439,12 +444,14 @@ __global__ __launch_bounds__(512, 2) void convwrw_tr_kernel(ConvWrwParams p) {
         GLOWTTS_TRACE_POINT_Z(3);
         if (grp == 0) {
             const int lrow = lane & 15, lk = lane >> 4;
+            if constexpr (NG == 2) {
 #pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp)
+                for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[tp][i][reg] += red[((tp * MT + i) * 4 + reg) * 256 + gt];
+                        for (int reg = 0; reg < 4; ++reg) acc[tp][i][reg] += red[((tp * MT + i) * 4 + reg) * 256 + gt];
+            }
             if (k0 + 64 <= p.Cin && m0 + MR <= p.M) {
                 const int lane_off = (wave * 16 + lk * 4) * p.M + lrow;      // per lane, once; the rest of an address is uniform
 #pragma unroll
@@ -490,13 +497,13 @@ static int compute_units() {
     return n[dev];
 }
 
-template <int NS, int TAPS, int MT, bool W32 = false>
+template <int NS, int TAPS, int MT, bool W32 = false, int NG = 2>
 static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     using G = WrwTrGeom<TAPS, MT>;
-    constexpr size_t lds = G::lds_bytes(NS, W32);
+    constexpr size_t lds = G::lds_bytes(NS, W32, NG);
     static_assert(lds <= 160 * 1024, "one workgroup per CU");
     static LdsLimit attr_max_e;
-    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_tr_kernel<NS, TAPS, MT, W32>), lds, "glowtts_conv_wrw (tr)")) return rc_;
+    if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convwrw_tr_kernel<NS, TAPS, MT, W32, NG>), lds, "glowtts_conv_wrw (tr)")) return rc_;
     const int tiles = ((p.Cin + 63) / 64) * ((p.M + G::MR - 1) / G::MR);
     const int total = p.B * ((p.T + G::CF - 1) / G::CF);
     int splits = compute_units() / tiles;               // ONE workgroup (8 waves) per CU, one round
@@ -507,13 +514,14 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     // envs=GLOWTTS_WRW5_BSPLIT:0,GLOWTTS_WRW5_BSPLIT:1; two launches of two problems x 7 splits: 15.01).  Read at every launch.
     if (p.nbatch > 1 && env_knob("GLOWTTS_WRW5_BSPLIT", 1) == 1 && compute_units() >= tiles * p.nbatch)
         splits = compute_units() / (tiles * p.nbatch);
+    if (NG == 1) splits *= env_knob("GLOWTTS_WRW_TR_NG_SPLITS", 1);      // (one group: workgroups per CU's worth of items; 1 = same grid)
     if (splits > (total + 1) / 2) splits = (total + 1) / 2;      // a workgroup wants an item for each of its two groups
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
     static const int prio_mode = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_PRIO"); return e ? std::atoi(e) : 2; }();
     p.xs_pitch = prio_mode;          // (tuning switch: 0 = the multiplying waves run at raised priority, 1 = nobody, 2 = the storing waves)
     dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
-    hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT, W32>), grid, dim3(512), lds, s, p);
+    hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT, W32, NG>), grid, dim3(256 * NG), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (tr)");
 }
 
@@ -537,7 +545,8 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     // 66.3; either form with the MULTIPLYING waves raised 67-69), GLOWTTS_WRW_TR=1 their 16x16x32 form
     static const bool mt2 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '2'; }();
     static const bool w16 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '1'; }();
-    if (ns == 3 && !mt2 && !w16 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0)) return launch_wrw_tr<3, 5, 4>(p, s);
+    if (ns == 3 && !mt2 && !w16 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0))
+        return env_knob("GLOWTTS_WRW_TR_NG", 2) == 1 ? launch_wrw_tr<3, 5, 4, false, 1>(p, s) : launch_wrw_tr<3, 5, 4>(p, s);
     if (ns == 3 && !w16) return launch_wrw_tr<3, 5, 2, true>(p, s);
     if (ns == 3) return launch_wrw_tr<3, 5, 2>(p, s);
     if (ns == 2) return launch_wrw_tr<2, 5, 2>(p, s);

@@ -27,6 +27,8 @@
  *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
  *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip; read at
  *                                                     every launch)
+ *                                 GLOWTTS_WRW_TR_NG   [2]     1 = the 5-tap 64 x 64 weight gradient with ONE 4-wave group per workgroup (half the
+ *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36; read at every launch)
  *                                 GLOWTTS_CONV_ROW_ADJ [1]    0 = the bf16-plane convolution kernels take their workgroups in grid order
  *                                                     (all frame tiles of row tile 0, then row tile 1, ..) instead of numbering the
  *                                                     row tiles of one frame tile into consecutive slots of one XCD
