@@ -77,15 +77,17 @@ static int wrw_any(const void *x, long x_bs, const void *d, long d_bs, const flo
                                    B, Cin, M, T, taps, 1, stream);
 }
 
-extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
-                                 const float *cond, const unsigned char *drop, float drop_scale, void *xs, void *acts,
-                                 void *ts, void *skip, int B, int H, int T, int taps, int dil_rate, int io,
-                                 glowtts_stream_t stream) {
+// slab_B: utterances per LAYER slab of xs / acts / ts / drop (>= B).  The stack node's forward runs two half-batch chains on two
+// streams into the same (n_layers, slab_B, ..) slabs: each call then covers B = slab_B / 2 utterances of every layer's slab.
+static int wn_fwd_impl(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask, const float *cond,
+                       const unsigned char *drop, float drop_scale, void *xs, void *acts, void *ts, void *skip, int B, int slab_B, int H,
+                       int T, int taps, int dil_rate, int io, glowtts_stream_t stream) {
     GLOWTTS_CHECK_ARG(layers && x && mask && acts && ts && skip, "glowtts_wn_fwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_fwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_fwd: bad shape");
-    const long BHT = (long)B * H * T;
-    if (!io && !cond) {        // the layer-resident kernel (csrc/wn_fused.hip): fp32 tensors, bf16x6 arithmetic, H = 192, 5 taps
+    GLOWTTS_CHECK_ARG(slab_B >= B && (slab_B == B || !cond), "glowtts_wn_fwd: bad slab batch");
+    const long BHT = (long)slab_B * H * T;
+    if (!io && !cond && slab_B == B) {        // the layer-resident kernel (csrc/wn_fused.hip): fp32 tensors, bf16x6 arithmetic, H = 192, 5 taps
         const int rc = wn_fused_dispatch(layers, n_layers, static_cast<const float *>(x), mask, drop, drop_scale, static_cast<float *>(xs),
                                          static_cast<float *>(acts), static_cast<float *>(ts), static_cast<float *>(skip), B, H, T, taps,
                                          dil_rate, (hipStream_t)stream);
@@ -107,6 +109,13 @@ extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, c
                                             last ? 1 : 0, io, stream));
     }
     return 0;
+}
+
+extern "C" int glowtts_wn_fwd_io(const glowtts_wn_layer *layers, int n_layers, const void *x, const float *mask,
+                                 const float *cond, const unsigned char *drop, float drop_scale, void *xs, void *acts,
+                                 void *ts, void *skip, int B, int H, int T, int taps, int dil_rate, int io,
+                                 glowtts_stream_t stream) {
+    return wn_fwd_impl(layers, n_layers, x, mask, cond, drop, drop_scale, xs, acts, ts, skip, B, B, H, T, taps, dil_rate, io, stream);
 }
 
 extern "C" int glowtts_wn_fwd(const glowtts_wn_layer *layers, int n_layers, const float *x, const float *mask,
@@ -348,8 +357,10 @@ extern "C" int glowtts_flow_block_fwd_io(const glowtts_flow_block *blk, const vo
     if (!skip_start)
         WN_TRY(glowtts_conv_fwd_io(start_in, start_bs, blk->wf_start, blk->b_start, mask, nullptr, 0, h0, HT, B, C / 2, H, T, 1, 1, 0, 0,
                                    1, 0, io_h, io_h, stream));
-    WN_TRY(glowtts_wn_fwd_io(blk->layers, blk->n_layers, h0, mask, cond, drop, drop_scale, xs, acts, ts, skip, B, H, T, taps, dil_rate,
-                             io_h, stream));
+    // (blk->reserved > 0: the layer slabs hold that many utterances and this call covers B of them — the stack node's two
+    // half-batch forward chains)
+    WN_TRY(wn_fwd_impl(blk->layers, blk->n_layers, h0, mask, cond, drop, drop_scale, xs, acts, ts, skip, B,
+                       blk->reserved > B ? blk->reserved : B, H, T, taps, dil_rate, io_h, stream));
     if (!skip_end)
         WN_TRY(glowtts_conv_fwd_io(skip, HT, blk->wf_end, blk->b_end, nullptr, nullptr, 0, out, CT, B, H, C, T, 1, 1, 0, 0, 0, 0, io_h, 0,
                                    stream));

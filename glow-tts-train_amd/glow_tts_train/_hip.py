@@ -394,6 +394,17 @@ def call(name: str, *args, tag=None) -> None:
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")
 
 
+def call_on(stream_ptr: int, name: str, *args) -> None:
+    """`call` on an explicit raw HIP stream (no stream context switch on the host: the stack node's two forward chains)."""
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*args, stream_ptr)
+    if rc != 0:
+        msg = load().glowtts_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
 # ----------------------------------------------------------------------------------------------------------------
 class _ZeroArena:
     """Zero-initialised scratch for ONE training step: accumulators the kernels add into with atomics (packed weight

@@ -1262,6 +1262,19 @@ class FlowStackFn(Function):
             if wtab is None or wtab[0] != wkey:
                 wtab = bplans[0]._w_table = (wkey, torch.tensor(wkey, dtype=torch.int64).to(dev))
             call("glowtts_invconv_prepare_multi", ptr(wtab[1]), pw, n_split * n_split + 1, nb, n_split)
+        # Two half-batch chains on two streams (forward only; fp32 tensors with the boundary launch): every utterance is independent in
+        # the forward, and two DIFFERENT kernels sharing the CUs fill each other's prologues and epilogues where two workgroups of
+        # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a
+        # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
+        halves = 2 if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % 2 == 0) else 1
+        if halves == 2:
+            main_s = torch.cuda.current_stream(dev)
+            s2 = _hip.side_stream(dev, "fwd2")
+            s2.wait_stream(main_s)
+            for t_ in (x, m2, x_len, zs, y, out, h0, skip, acts, ts, xs, logdets, winv, drops):
+                if t_ is not None:
+                    t_.record_stream(s2)
+            chains, Bh = (main_s.cuda_stream, s2.cuda_stream), B // 2
         off = 0
         for k in range(nb):
             pk = params[off: off + counts[k]]
@@ -1276,7 +1289,29 @@ class FlowStackFn(Function):
                 tab = bplan.table(pk, n_layers)
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
+                tab.reserved = B if halves == 2 else 0   # utterances per layer slab when a call covers only half of them
                 flags = int(io) | (1024 if stack_prep else 0)
+                if halves == 2:
+                    flags |= (256 | 4096 if k > 0 else 0) | (512 | 2048 if k < nb - 1 else 0)
+                    sig_i = int(sigmoid_scale)
+                    for hh in (0, 1):
+                        st, hb = chains[hh], hh * Bh
+                        oC, oH, oB, oM = hb * C * T * 4, hb * H * T * 4, hb * 4, hb * T * 4
+                        if k > 0:
+                            _hip.call_on(st, "glowtts_flow_boundary_fwd", psk + (k - 1) * nH * 4 + oH, prev_tab.wf_end, prev_tab.b_end,
+                                         py + (k - 1) * nC * 4 + oC, pm + oM, ptr(pk[0]), ptr(pk[1]), ptr(pk[2]), tab.logdet_w, pl + oB,
+                                         tab.wf_start, tab.b_start, po + (k - 1) * nC * 4 + oC, py + k * nC * 4 + oC, ph + k * nH * 4 + oH,
+                                         pld + (k - 1) * B * 4 + oB, pld + k * B * 4 + oB, Bh, C, H, T, n_split, sig_i)
+                        _hip.call_on(st, "glowtts_flow_block_fwd_io", ctypes.addressof(tab),
+                                     (px if k == 0 else pz + (k - 1) * nC * 4) + oC, pm + oM, pl + oB, None,
+                                     None if pdr is None else pdr + k * n_layers * 2 * nH + hb * 2 * H * T, scale, py + k * nC * 4 + oC, None,
+                                     ph + k * nH * 4 + oH, pxs + k * nx * nH * 4 + oH if n_layers > 1 else None,
+                                     pa + k * n_layers * nH * 4 + oH, pts + k * n_layers * 2 * nH * 4 + 2 * oH, psk + k * nH * 4 + oH,
+                                     po + k * nC * 4 + oC, pz + k * nC * 4 + oC, pld + k * B * 4 + oB, Bh, C, H, T, taps, dil_rate, n_split,
+                                     sig_i, flags)
+                    tab.reserved = 0                 # (read by the calls above while they queued their launches; the table is cached)
+                    prev_tab = tab
+                    continue
                 if fuse and k > 0 and not stack_prep:
                     call("glowtts_invconv_prepare", ptr(pk[2]), tab.w_inv, tab.logdet_w, n_split)
                 if boundary and k > 0:
@@ -1301,6 +1336,8 @@ class FlowStackFn(Function):
                      taps, dil_rate, n_split, int(sigmoid_scale), flags)
             finally:
                 bplan.unbind(bound)
+        if halves == 2:
+            main_s.wait_stream(s2)
         ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]),
                               *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale, ctx.fuse = cfg, bplans, counts, params, taps, scale, fuse
@@ -1428,6 +1465,9 @@ class FlowStackFn(Function):
 _ENC_WGRAD = os.environ.get("GLOWTTS_ENC_WGRAD", "0") == "1"      # tuning knob: encoder weight gradients on the "wgrad" stream
 _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn: coupling(k) fused with ActNorm + InvConv (k + 1)
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
+# FlowStackFn forward as two half-batch chains on two streams (even batches, fp32 tensors): 13.71 -> 13.45 ms per step for ~1 ms more
+# host enqueue (twice the decoder's forward launches); GLOWTTS_HALF_BATCH_FWD=0 keeps one chain (a rank whose host is the bottleneck)
+_HALF_BATCH_FWD = os.environ.get("GLOWTTS_HALF_BATCH_FWD", "1") != "0"
 # ... and the same in the backward: OPT-IN.  The kernel is 32 us against 45 for the three launches alone, but in the step the chain
 # waits for the weight gradients' compute units at every block boundary of the backward whatever it launches (13.73 -> 13.72 ms per
 # step), and the extra stream hand-over for its parameter-gradient reduction costs 1.4 ms of host enqueue (DESIGN.md lesson 36)

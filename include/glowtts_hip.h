@@ -418,7 +418,9 @@ typedef struct glowtts_flow_block {
     const int *pack_prefix;                       /* device, n_conv + 1 entries */
     float *dwp_all;                               /* all packed weight-gradient accumulators of the block, contiguous */
     long long dwp_floats;
-    int n_layers, n_conv, total_rows, reserved;
+    int n_layers, n_conv, total_rows;
+    int reserved;                                 /* forward only: > B = utterances per LAYER slab of xs / acts / ts / drop when a call covers
+                                                     only B of them (two half-batch forward chains writing into one set of slabs); else 0 */
 } glowtts_flow_block;
 int glowtts_flow_block_fwd(const glowtts_flow_block *blk, const float *x, const float *mask, const float *x_len,
                            const unsigned char *drop, float drop_scale, float *y, float *h0, float *xs, float *acts,

@@ -1397,11 +1397,13 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
     # "stack": every block in ONE autograd node (convops.FlowStackFn; not with conditioning rows); "both": one node per block;
     # "fwd": the block executor declines, the per-operator path runs
     # "stack+bwd": the stack node with the opt-in one-launch block boundary of the BACKWARD as well (GLOWTTS_FLOW_BOUNDARY_BWD=1)
-    for mode in ("stack", "stack+bwd", "both", "fwd"):
+    # "stack+half": the stack node's forward as two half-batch chains on two streams (GLOWTTS_HALF_BATCH_FWD=1; even batches)
+    for mode in ("stack", "stack+bwd", "stack+half", "both", "fwd"):
         convops._WN_NATIVE = "both" if mode.startswith("stack") else mode
         G.models._FLOW_STACK = mode.startswith("stack")
-        bnd_bwd = convops._FLOW_BOUNDARY_BWD
+        bnd_bwd, half_fwd = convops._FLOW_BOUNDARY_BWD, convops._HALF_BATCH_FWD
         convops._FLOW_BOUNDARY_BWD = mode == "stack+bwd"
+        convops._HALF_BATCH_FWD = mode == "stack+half"
         calls, stack_calls = [], []
         convops.FlowBlockFn.forward = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
         convops.FlowStackFn.forward = staticmethod(lambda *a, _o=orig_stack, _c=stack_calls: (_c.append(1), _o(*a))[1])
@@ -1418,7 +1420,7 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
         finally:
             convops._WN_NATIVE = "both"
             G.models._FLOW_STACK = True
-            convops._FLOW_BOUNDARY_BWD = bnd_bwd
+            convops._FLOW_BOUNDARY_BWD, convops._HALF_BATCH_FWD = bnd_bwd, half_fwd
             convops.FlowBlockFn.forward = orig
             convops.FlowStackFn.forward = orig_stack
         used[mode] = (len(calls), len(stack_calls))
@@ -1427,9 +1429,12 @@ def test_flow_block_executor_matches_per_op_path(G, b, h, t, blocks, p_drop, sig
             grads["<speaker rows g>"] = gg.grad.clone()
         res[mode] = (z.detach().clone(), ld.detach().clone(), y.grad.clone(), grads)
     assert used["both"] == (blocks, 0) and used["fwd"] == (0, 0), used
-    assert used["stack"] == used["stack+bwd"] == ((0, 1) if gin == 0 else (blocks, 0)), used   # conditioning rows: one node per block
+    assert used["stack"] == used["stack+bwd"] == used["stack+half"] == ((0, 1) if gin == 0 else (blocks, 0)), used   # conditioning rows: one node per block
+    if gin == 0:                                         # the two half-batch chains run the same kernels on the same utterances
+        assert torch.equal(res["stack+half"][0], res["stack"][0])            # (the log-determinants are sums of float atomics)
+        assert_close(res["stack+half"][1], res["stack"][1], what="stack+half: logdet", rtol=1e-6, atol=1e-4)
     z0, l0, dx0, g0 = res["fwd"]
-    for mode in ("both", "stack", "stack+bwd"):
+    for mode in ("both", "stack", "stack+bwd", "stack+half"):
         z1, l1, dx1, g1 = res[mode]
         assert_close(z1, z0, what=f"{mode}: z", rtol=1e-6, atol=1e-6)
         assert_close(l1, l0, what=f"{mode}: logdet", rtol=1e-6, atol=1e-4)

@@ -37,6 +37,8 @@ def apply(v):
         _hip.wn_fused(v == "1")
     elif name == "fuseflows":                               # FlowStackFn: coupling(k) fused with ActNorm + InvConv(k + 1) on / off
         convops._FUSE_FLOWS = v == "1"
+    elif name == "halfbatch":                               # FlowStackFn forward as two half-batch chains on two streams on / off
+        convops._HALF_BATCH_FWD = v == "1"
     elif name == "boundarybwd":                             # the same boundary launch in the backward on / off
         convops._FLOW_BOUNDARY_BWD = v == "1"
     elif name == "boundary":                                # FlowStackFn: end conv(k) + flows + start conv(k + 1) in one launch on / off
