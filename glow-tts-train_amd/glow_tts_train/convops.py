@@ -537,6 +537,11 @@ class WNPackPlan:
         call("glowtts_unpack_weight_grad_multi", ptr(self.gdesc), ptr(self.prefix), len(self.convs), self.total_rows)
 
 
+def _process_group_active() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 class StackArena:
     """ONE packed-weight buffer and ONE set of bf16 planes for all blocks of a flow stack (round 4): weight norm + packing + plane
     split of the whole decoder is one launch per step where every block launched its own (17 us each, twelve of them on the
@@ -1266,15 +1271,17 @@ class FlowStackFn(Function):
         # the forward, and two DIFFERENT kernels sharing the CUs fill each other's prologues and epilogues where two workgroups of
         # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a
         # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
-        halves = 2 if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % 2 == 0) else 1
-        if halves == 2:
+        halves = _FWD_CHAINS if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % _FWD_CHAINS == 0
+                                 and (_HALF_BATCH_ENV == "1" or not _process_group_active())) else 1
+        if halves > 1:
             main_s = torch.cuda.current_stream(dev)
-            s2 = _hip.side_stream(dev, "fwd2")
-            s2.wait_stream(main_s)
-            for t_ in (x, m2, x_len, zs, y, out, h0, skip, acts, ts, xs, logdets, winv, drops):
-                if t_ is not None:
-                    t_.record_stream(s2)
-            chains, Bh = (main_s.cuda_stream, s2.cuda_stream), B // 2
+            extra = [_hip.side_stream(dev, "fwd%d" % (j + 2)) for j in range(halves - 1)]
+            for s2 in extra:
+                s2.wait_stream(main_s)
+                for t_ in (x, m2, x_len, zs, y, out, h0, skip, acts, ts, xs, logdets, winv, drops):
+                    if t_ is not None:
+                        t_.record_stream(s2)
+            chains, Bh = [main_s.cuda_stream] + [s2.cuda_stream for s2 in extra], B // halves
         off = 0
         for k in range(nb):
             pk = params[off: off + counts[k]]
@@ -1289,12 +1296,12 @@ class FlowStackFn(Function):
                 tab = bplan.table(pk, n_layers)
                 tab.w_inv = pw + k * (n_split * n_split + 1) * 4
                 tab.logdet_w = tab.w_inv + 4 * n_split * n_split
-                tab.reserved = B if halves == 2 else 0   # utterances per layer slab when a call covers only half of them
+                tab.reserved = B if halves > 1 else 0    # utterances per layer slab when a call covers only a part of them
                 flags = int(io) | (1024 if stack_prep else 0)
-                if halves == 2:
+                if halves > 1:
                     flags |= (256 | 4096 if k > 0 else 0) | (512 | 2048 if k < nb - 1 else 0)
                     sig_i = int(sigmoid_scale)
-                    for hh in (0, 1):
+                    for hh in range(halves):
                         st, hb = chains[hh], hh * Bh
                         oC, oH, oB, oM = hb * C * T * 4, hb * H * T * 4, hb * 4, hb * T * 4
                         if k > 0:
@@ -1336,8 +1343,9 @@ class FlowStackFn(Function):
                      taps, dil_rate, n_split, int(sigmoid_scale), flags)
             finally:
                 bplan.unbind(bound)
-        if halves == 2:
-            main_s.wait_stream(s2)
+        if halves > 1:
+            for s2 in extra:
+                main_s.wait_stream(s2)
         ctx.save_for_backward(x, m2, x_len, zs, y, h0, acts, ts, skip, out, winv, xs, *([] if drops is None else [drops]),
                               *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale, ctx.fuse = cfg, bplans, counts, params, taps, scale, fuse
@@ -1467,7 +1475,11 @@ _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn:
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
 # FlowStackFn forward as two half-batch chains on two streams (even batches, fp32 tensors): 13.71 -> 13.45 ms per step for ~1 ms more
 # host enqueue (twice the decoder's forward launches); GLOWTTS_HALF_BATCH_FWD=0 keeps one chain (a rank whose host is the bottleneck)
-_HALF_BATCH_FWD = os.environ.get("GLOWTTS_HALF_BATCH_FWD", "1") != "0"
+# With a process group (data parallel: the reducer's callbacks already make the host the longer side, bench.py --rccl-self 14.9-15.3 ms)
+# the extra launches cost 1.8 ms per step: unset = two chains only without a process group, 1 = always, 0 = never
+_HALF_BATCH_ENV = os.environ.get("GLOWTTS_HALF_BATCH_FWD", "")
+_HALF_BATCH_FWD = _HALF_BATCH_ENV != "0"
+_FWD_CHAINS = int(os.environ.get("GLOWTTS_FWD_CHAINS", "2"))          # (chains of B / n utterances; 2 measured best)
 # ... and the same in the backward: OPT-IN.  The kernel is 32 us against 45 for the three launches alone, but in the step the chain
 # waits for the weight gradients' compute units at every block boundary of the backward whatever it launches (13.73 -> 13.72 ms per
 # step), and the extra stream hand-over for its parameter-gradient reduction costs 1.4 ms of host enqueue (DESIGN.md lesson 36)

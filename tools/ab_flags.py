@@ -37,6 +37,8 @@ def apply(v):
         _hip.wn_fused(v == "1")
     elif name == "fuseflows":                               # FlowStackFn: coupling(k) fused with ActNorm + InvConv(k + 1) on / off
         convops._FUSE_FLOWS = v == "1"
+    elif name == "fwdchains":                               # number of part-batch forward chains of FlowStackFn (1, 2, 4)
+        convops._HALF_BATCH_FWD, convops._FWD_CHAINS = int(v) > 1, max(int(v), 1)
     elif name == "halfbatch":                               # FlowStackFn forward as two half-batch chains on two streams on / off
         convops._HALF_BATCH_FWD = v == "1"
     elif name == "boundarybwd":                             # the same boundary launch in the backward on / off
