@@ -1475,8 +1475,9 @@ _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn:
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
 # FlowStackFn forward as two half-batch chains on two streams (even batches, fp32 tensors): 13.71 -> 13.45 ms per step for ~1 ms more
 # host enqueue (twice the decoder's forward launches); GLOWTTS_HALF_BATCH_FWD=0 keeps one chain (a rank whose host is the bottleneck)
-# With a process group (data parallel: the reducer's callbacks already make the host the longer side, bench.py --rccl-self 14.9-15.3 ms)
-# the extra launches cost 1.8 ms per step: unset = two chains only without a process group, 1 = always, 0 = never
+# With a process group (data parallel) the two chains COST 1.8 ms per step (bench.py --rccl-self: 14.9 -> 16.8 ms; cause not isolated —
+# host enqueue is 10.4 ms of the step there, a fifth stream beside RCCL's is the other suspect): unset = two chains only without a
+# process group, 1 = always, 0 = never
 _HALF_BATCH_ENV = os.environ.get("GLOWTTS_HALF_BATCH_FWD", "")
 _HALF_BATCH_FWD = _HALF_BATCH_ENV != "0"
 _FWD_CHAINS = int(os.environ.get("GLOWTTS_FWD_CHAINS", "2"))          # (chains of B / n utterances; 2 measured best)
