@@ -1272,6 +1272,7 @@ class FlowStackFn(Function):
         # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a
         # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
         halves = _FWD_CHAINS if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % _FWD_CHAINS == 0
+                                 and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"       # (one-stream profiling passes)
                                  and (_HALF_BATCH_ENV == "1" or not _process_group_active())) else 1
         if halves > 1:
             main_s = torch.cuda.current_stream(dev)
