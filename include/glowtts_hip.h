@@ -29,6 +29,9 @@
  *                                                     every launch)
  *                                 GLOWTTS_WRW_TR_NG   [2]     1 = the 5-tap 64 x 64 weight gradient with ONE 4-wave group per workgroup (half the
  *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36; read at every launch)
+ *                                 GLOWTTS_BND_EXP     [0]     timing experiments of csrc/flow_boundary.hip (WRONG results): bit 0 / 1 = without
+ *                                                     the first / second contraction's MFMAs, 2 = without the element-wise phase, 3 =
+ *                                                     backward without the group reduction (tools/boundary_bench.py; read at every launch)
  *                                 GLOWTTS_CONV_ROW_ADJ [1]    0 = the bf16-plane convolution kernels take their workgroups in grid order
  *                                                     (all frame tiles of row tile 0, then row tile 1, ..) instead of numbering the
  *                                                     row tiles of one frame tile into consecutive slots of one XCD
