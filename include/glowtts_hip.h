@@ -28,7 +28,8 @@
  *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip; read at
  *                                                     every launch)
  *                                 GLOWTTS_WRW_TR_NG   [2]     1 = the 5-tap 64 x 64 weight gradient with ONE 4-wave group per workgroup (half the
- *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36; read at every launch)
+ *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36; read at every launch;
+ *                                                     GLOWTTS_WRW_TR_NG_SPLITS [1] multiplies its split-K workgroup count)
  *                                 GLOWTTS_BND_EXP     [0]     timing experiments of csrc/flow_boundary.hip (WRONG results): bit 0 / 1 = without
  *                                                     the first / second contraction's MFMAs, 2 = without the element-wise phase, 3 =
  *                                                     backward without the group reduction (tools/boundary_bench.py; read at every launch)
