@@ -352,8 +352,9 @@ def timing_off() -> bool:
 
 def join_side_streams() -> None:
     """Make the current stream wait for everything queued on the side streams (after backward, before the optimizer)."""
-    for s in _side_streams.values():
-        torch.cuda.current_stream(s.device).wait_stream(s)
+    for (_, role), s in _side_streams.items():
+        if not role.startswith("fwd"):
+            torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda.Stream":
@@ -366,8 +367,9 @@ def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda
 
 
 def all_side_streams(device):
+    """The side streams gradients may come from (the forward-only chains "fwd2.." are joined inside the forward: not among them)."""
     idx = torch.device(device).index
-    return [s for (d, _), s in _side_streams.items() if d == idx]
+    return [s for (d, role), s in _side_streams.items() if d == idx and not role.startswith("fwd")]
 
 
 def call(name: str, *args, tag=None) -> None:
