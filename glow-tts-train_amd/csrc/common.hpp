@@ -167,8 +167,25 @@ struct LdsLimit {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// A tuning knob read from the environment on EVERY call (tools/ab_flags.py flips such knobs between blocks of steps inside one
-// process): only for launch-geometry experiments; a knob that ships is latched once (include/glowtts_hip.h lists them).
-int env_knob(const char *name, int dflt);
+// Tuning switches (include/glowtts_hip.h lists every one with its default).  ALL of them are read from the environment ONCE,
+// at the library's first use of any of them, into a table of atomics; afterwards a launch costs one relaxed load per switch it
+// consults (no getenv / atoi on the launch path, nothing for autograd's backward threads to race on), and the A/B tools flip a
+// switch between blocks of steps with glowtts_set_knob(name, value).  They select between kernels / launch geometries with
+// identical results.  The two timing-experiment switches that make kernels SKIP work (wrong results) exist in the tuning
+// build only (-DGLOWTTS_TRACE: `make trace`), as does every `exp` test inside the kernels (GLOWTTS_EXP_BITS).
+enum Knob {
+    K_CONV_ROW_ADJ, K_CONV32_1X1, K_WRW1_PIPE, K_WRW1_MULTI, K_WRW1_CUS, K_WRW1_XCD, K_WN_FUSED, K_WRW_BATCH, K_WRW5_BSPLIT,
+    K_WRW_TR, K_WRW_TR_MT, K_WRW_TR_NG, K_WRW_TR_NG_SPLITS, K_WRW_TR_PRIO, K_WRW_TR3, K_WRW_TR3_MT,
+#ifdef GLOWTTS_TRACE
+    K_BND_EXP, K_WRW1_EXP,
+#endif
+    K_COUNT
+};
+int knob(Knob k);
+#ifdef GLOWTTS_TRACE
+#define GLOWTTS_EXP_BITS(v) (v)
+#else
+#define GLOWTTS_EXP_BITS(v) 0
+#endif
 
 }  // namespace glowtts

@@ -902,7 +902,7 @@ static int dispatch_convgemm(ConvGemmParams &p, hipStream_t s) {
         use32 = wg5 < 380 && t32 * 10 <= p.T * 11;
         // plain 1x1 convolutions (the coupling's start / end convs and the end conv's backward-data: 12 800 columns, 480 tiles of
         // 80 frames) take 32-frame tiles as well: four consecutive A/B pairs 15.04 -> 15.00 ms per step (GLOWTTS_CONV32_1X1=0 / 1)
-        if (p.taps == 1 && t32 * 10 <= p.T * 11 && env_knob("GLOWTTS_CONV32_1X1", 1) == 1) use32 = true;
+        if (p.taps == 1 && t32 * 10 <= p.T * 11 && knob(K_CONV32_1X1) == 1) use32 = true;
     }
     if (int rc = conv_split_dispatch(p, EPI, big, use32 ? 2 : (n5 ? 5 : 4), pipe_ok, s); rc >= 0) return rc;   // bf16-plane arithmetic
     if (use32) {

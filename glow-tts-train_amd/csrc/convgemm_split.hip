@@ -752,6 +752,12 @@ __global__ __launch_bounds__(256, 2) void convwrw_split_kernel(ConvWrwParams p) 
                     if (more && q >= 1 && q - 1 < NU) unit(q - 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // the groups above gave slots to units 0 .. NSTEP * MT - 2: the 64-frame form <., 1, 4, 4> has NU = NSTEP * MT = 8,
+                // so its last unit (d item 3: rows 48..63 of the d tile, bsum[3]) runs here, behind the last group
+                if (more) {
+#pragma unroll
+                    for (int u = NSTEP * MT - 1; u < NU; ++u) unit(u);
+                }
                 if (c + 2 < nchunks) load_chunk(c + 2);      // the units have consumed chunk c + 1's registers
                 if (c == 0) GLOWTTS_TRACE_POINT_Z(2);
                 __syncthreads();                             // every wave is through with this chunk's d image
@@ -872,7 +878,7 @@ static int launch_split(ConvGemmParams &p, const unsigned short *planes, long st
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;
     dim3 grid(ntile_t * p.B, (rows + per - 1) / per);
-    p.wg_order = (grid.y > 1 && grid.x % 8 == 0 && env_knob("GLOWTTS_CONV_ROW_ADJ", 1) == 1) ? 1 : 0;
+    p.wg_order = (grid.y > 1 && grid.x % 8 == 0 && knob(K_CONV_ROW_ADJ) == 1) ? 1 : 0;
     hipLaunchKernelGGL((convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS, IOB, NSA>), grid, dim3(256), lds, s, p, planes, stride);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv (split)");
 }
@@ -948,8 +954,7 @@ static int launch_wrw_split(ConvWrwParams &p, hipStream_t s) {
     if (splits > total) splits = total;
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
-    const char *e_pipe = std::getenv("GLOWTTS_WRW1_PIPE");        // (read per launch: tools/ab_flags.py flips it between blocks of steps)
-    p.ds_pitch = (e_pipe && e_pipe[0] == '0') ? 1 : 0;             // 1x1 kernel: 1 = the unpipelined loop (tuning / A-B switch)
+    p.ds_pitch = knob(K_WRW1_PIPE) == 0 ? 1 : 0;                   // 1x1 kernel: 1 = the unpipelined loop (tuning / A-B switch)
     dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_split_kernel<NS, TAPS, NGRP, MT>), grid, dim3(256), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (split)");

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
     auto load_next = [&]() {
         const int s = s_begin + grp + 2 * ld_i;
         ++ld_i;
-        if ((P.exp & 8) && ld_i > 1) return;          // (timing experiment: no global loads after the first step)
+        if ((GLOWTTS_EXP_BITS(P.exp) & 8) && ld_i > 1) return;          // (timing experiment: no global loads after the first step)
         const int b = s / P.steps_u, t = (s - b * P.steps_u) * 32 + q * 4;
         const bool tok = t < T;
 #pragma unroll
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
     for (int ph = 0; ph < 2 * n_max; ++ph) {
         const int rel = ph - grp;
         if (rel >= 0 && (rel & 1) == 0) {
-            if ((rel >> 1) < n_my && !(P.exp & 4)) compute();
+            if ((rel >> 1) < n_my && !(GLOWTTS_EXP_BITS(P.exp) & 4)) compute();
         } else {
             const int i = (rel + 1) >> 1;
             if (i < n_my && (i > 0 || grp == 1)) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void convwrw1_kernel(Wrw1Params P) {
     }
 
     // ---- the two groups' sums meet in LDS (the images are dead); group 0 sends the tile's split-K atomics -----------------------------
-    if (P.exp & 1) { if (acc[0][0][0] == 123.456f) pdw[0] = 1.f; return; }
+    if (GLOWTTS_EXP_BITS(P.exp) & 1) { if (acc[0][0][0] == 123.456f) pdw[0] = 1.f; return; }
     float *red = reinterpret_cast<float *>(w1_lds);
     if (grp == 1) {
 #pragma unroll
@@ -281,7 +281,7 @@ static int w1_compute_units() {
 
 // 0 = launched; -1 = not handled (arithmetic mode, shapes, alignment): the caller launches the problems one by one
 int conv_wrw1_multi_dispatch(int n, const glowtts_wrw1_problem *pr, int B, int T, hipStream_t s) {
-    if (conv_math_wrw() != 3 || env_knob("GLOWTTS_WRW1_MULTI", 1) == 0) return -1;
+    if (conv_math_wrw() != 3 || knob(K_WRW1_MULTI) == 0) return -1;
     if (n < 1 || n > kW1Max || (T & 3) != 0 || B < 1 || T < 4) return -1;
     Wrw1Params P{};
     int tiles = 0;
@@ -302,15 +302,18 @@ int conv_wrw1_multi_dispatch(int n, const glowtts_wrw1_problem *pr, int B, int T
     }
     for (int j = n; j <= kW1Max; ++j) P.tile0[j] = tiles;
     P.n = n; P.B = B; P.T = T; P.total_tiles = tiles;
-    P.exp = env_knob("GLOWTTS_WRW1_EXP", 0);
+    #ifdef GLOWTTS_TRACE
+    P.exp = knob(K_WRW1_EXP);
+#endif
     P.steps_u = (T + 31) / 32;
     P.total_steps = B * P.steps_u;
     // split-K sized for HALF the compute units: every workgroup ends with 98 KB of float atomics (a tile is the whole problem, so
     // splits x tiles x 98 KB leave the chip at ~1.3 TB/s whatever the kernel does), and the launch shares the GPU with the
     // backward's chain on the other stream — alone the launch is faster on all CUs (79 against 117 us for a flow block's six
     // problems), in the step it is not: 14.34 / 14.24 / 14.17 ms per step for 256 / 192 / 128 (tools/ab_flags.py envs=GLOWTTS_WRW1_CUS:..)
-    int splits = env_knob("GLOWTTS_WRW1_CUS", w1_compute_units() / 2) / tiles;
-    if (splits >= 16 && env_knob("GLOWTTS_WRW1_XCD", 1)) splits &= ~7;      // (see the kernel's workgroup numbering)
+    const int cus = knob(K_WRW1_CUS);                                  // -1 (default): half the compute units
+    int splits = (cus > 0 ? cus : w1_compute_units() / 2) / tiles;
+    if (splits >= 16 && knob(K_WRW1_XCD)) splits &= ~7;      // (see the kernel's workgroup numbering)
     if (splits > P.total_steps) splits = P.total_steps;
     if (splits < 1) splits = 1;
     P.nb = (P.total_steps + splits - 1) / splits;

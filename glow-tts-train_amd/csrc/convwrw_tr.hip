@@ -512,14 +512,13 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     // nbatch times fewer prologues, group reductions and split-K atomics per problem (82 KB per workgroup: 20.7 -> 4.4 MB per
     // problem) for 16 % of the compute units left to the other streams; 15.08 -> 14.98 ms per step (tools/ab_flags.py
     // envs=GLOWTTS_WRW5_BSPLIT:0,GLOWTTS_WRW5_BSPLIT:1; two launches of two problems x 7 splits: 15.01).  Read at every launch.
-    if (p.nbatch > 1 && env_knob("GLOWTTS_WRW5_BSPLIT", 1) == 1 && compute_units() >= tiles * p.nbatch)
+    if (p.nbatch > 1 && knob(K_WRW5_BSPLIT) == 1 && compute_units() >= tiles * p.nbatch)
         splits = compute_units() / (tiles * p.nbatch);
-    if (NG == 1) splits *= env_knob("GLOWTTS_WRW_TR_NG_SPLITS", 1);      // (one group: workgroups per CU's worth of items; 1 = same grid)
+    if (NG == 1) splits *= knob(K_WRW_TR_NG_SPLITS);      // (one group: workgroups per CU's worth of items; 1 = same grid)
     if (splits > (total + 1) / 2) splits = (total + 1) / 2;      // a workgroup wants an item for each of its two groups
     if (splits < 1) splits = 1;
     p.nb = (total + splits - 1) / splits;
-    static const int prio_mode = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_PRIO"); return e ? std::atoi(e) : 2; }();
-    p.xs_pitch = prio_mode;          // (tuning switch: 0 = the multiplying waves run at raised priority, 1 = nobody, 2 = the storing waves)
+    p.xs_pitch = knob(K_WRW_TR_PRIO);         // (tuning switch: 0 = the multiplying waves run at raised priority, 1 = nobody, 2 = the storing waves)
     dim3 grid(tiles, 1, ((total + p.nb - 1) / p.nb) * (p.nbatch > 0 ? p.nbatch : 1));
     hipLaunchKernelGGL((convwrw_tr_kernel<NS, TAPS, MT, W32, NG>), grid, dim3(256 * NG), lds, s, p);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_wrw (tr)");
@@ -527,12 +526,12 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
 
 // called by conv_wrw_split_dispatch for fp32 tensors: -1 = not handled here
 int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
-    static const bool off = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '0'; }();
-    if (off) return -1;
+    const int tr = knob(K_WRW_TR);                    // -1 unset, 0 = off, 1 = 64 x 32 tiles in the 16x16x32 form
+    if (tr == 0) return -1;
     if (p.M % 32 != 0 || (p.d2 && p.d_split % 32 != 0)) return -1;
     if (p.taps == 3) {        // the text encoder's FFN convolutions (768 <-> 192 channels, T_text frames)
-        static const bool no3 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR3"); return e && e[0] == '0'; }();
-        if (ns == 3 && !no3 && env_knob("GLOWTTS_WRW_TR3_MT", 2) == 4 && p.M % 64 == 0) return launch_wrw_tr<3, 3, 4>(p, s);
+        const bool no3 = knob(K_WRW_TR3) == 0;
+        if (ns == 3 && !no3 && knob(K_WRW_TR3_MT) == 4 && p.M % 64 == 0) return launch_wrw_tr<3, 3, 4>(p, s);
         return (ns == 3 && !no3) ? launch_wrw_tr<3, 3, 2, true>(p, s) : -1;
     }
     // 1x1 convolutions stay on the frame-packed kernel: this one is staging-bound there (measured at B=32 / T'=400, 384 <- 192
@@ -543,10 +542,9 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s) {
     // is (16.25 -> 16.00 ms, three alternating runs).  GLOWTTS_WRW_TR_MT=2 selects 64 x 32 tiles in the 32x32x16 form with the
     // storing waves at raised priority (A/B at B=32 / T'=400, production build: 65.7 us per back-to-back launch; 16x16x32 form
     // 66.3; either form with the MULTIPLYING waves raised 67-69), GLOWTTS_WRW_TR=1 their 16x16x32 form
-    static const bool mt2 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR_MT"); return e && e[0] == '2'; }();
-    static const bool w16 = [] { const char *e = std::getenv("GLOWTTS_WRW_TR"); return e && e[0] == '1'; }();
+    const bool mt2 = knob(K_WRW_TR_MT) == 2, w16 = tr == 1;
     if (ns == 3 && !mt2 && !w16 && p.M % 64 == 0 && (!p.d2 || p.d_split % 64 == 0))
-        return env_knob("GLOWTTS_WRW_TR_NG", 2) == 1 ? launch_wrw_tr<3, 5, 4, false, 1>(p, s) : launch_wrw_tr<3, 5, 4>(p, s);
+        return knob(K_WRW_TR_NG) == 1 ? launch_wrw_tr<3, 5, 4, false, 1>(p, s) : launch_wrw_tr<3, 5, 4>(p, s);
     if (ns == 3 && !w16) return launch_wrw_tr<3, 5, 2, true>(p, s);
     if (ns == 3) return launch_wrw_tr<3, 5, 2>(p, s);
     if (ns == 2) return launch_wrw_tr<2, 5, 2>(p, s);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, NT == 16 ? 3 : 2) void flow_boundary_fwd_kerne
 
     // ---- phase 1: out = W_end skip + b_end -> LDS [C][33] -------------------------------------------------------------
     f32x4 acc[kBndRT][NC];
-    bnd_gemm<NT>(p.wp_end, C, (p.exp & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
+    bnd_gemm<NT>(p.wp_end, C, (GLOWTTS_EXP_BITS(p.exp) & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
     bnd_wload(p.wp_start, H, GS, 0, wave, lrow, lk, aw[0]);          // (the start conv's first weights: under phase 2)
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, NT == 16 ? 3 : 2) void flow_boundary_fwd_kerne
     for (int u = 0; u < 2; ++u) {                          // (G * 8 <= 512 items: C <= 192, n_split >= 2 ... checked on the host)
         const int i = tid + 256 * u;
         const int g = i / NQ, q = i % NQ;
-        if (i >= G * NQ || t0 + q * 4 >= T || (p.exp & 4)) continue;
+        if (i >= G * NQ || t0 + q * 4 >= T || (GLOWTTS_EXP_BITS(p.exp) & 4)) continue;
         const float *mq = Ms + q * 4;
         float yv[N][4];
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, NT == 16 ? 3 : 2) void flow_boundary_fwd_kerne
     }
 
     // ---- phase 3: h0 = (W_start y'0 + b_start) mask ------------------------------------------------------------------------
-    bnd_gemm<NT>(p.wp_start, H, (p.exp & 2) ? 0 : GS, Ys, wave, lrow, lk, aw, acc);
+    bnd_gemm<NT>(p.wp_start, H, (GLOWTTS_EXP_BITS(p.exp) & 2) ? 0 : GS, Ys, wave, lrow, lk, aw, acc);
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
         const int row0 = (wave + 4 * r) * 16 + lk * 4;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_bwd_kernel(BoundaryBwdPa
 
     // ---- phase 1: the start conv's input gradient (C/2 rows) -> LDS ---------------------------------------------------------
     f32x4 acc[kBndRT][NC];
-    bnd_gemm<NT>(p.wb_start, half, (p.exp & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
+    bnd_gemm<NT>(p.wb_start, half, (GLOWTTS_EXP_BITS(p.exp) & 1) ? 0 : GH, Xs, wave, lrow, lk, aw, acc);
     bnd_wload(p.wb_end, H, GC, 0, wave, lrow, lk, aw[0]);            // (the end conv's first weights: under phase 2)
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_bwd_kernel(BoundaryBwdPa
         const int i = tid + 256 * u;
         const int g = i / NQ, q = i % NQ;
         const bool item = i < G * NQ;                    // (uniform over the 8 lanes of a group: they reduce together below)
-        const bool live = item && t0 + q * 4 < T && !(p.exp & 4);
+        const bool live = item && t0 + q * 4 < T && !(GLOWTTS_EXP_BITS(p.exp) & 4);
         float aw_[N * N], al[N], ab[N];
 #pragma unroll
         for (int v = 0; v < N * N; ++v) aw_[v] = 0.f;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_bwd_kernel(BoundaryBwdPa
             }
         }
         // the group's NQ lanes add up (NQ = 8 consecutive lanes); lane q == 0 hands the partial over
-        if (item && !(p.exp & 8)) {                      // (G * NQ is a multiple of NQ: the NQ lanes of a group are all in or all out)
+        if (item && !(GLOWTTS_EXP_BITS(p.exp) & 8)) {                      // (G * NQ is a multiple of NQ: the NQ lanes of a group are all in or all out)
 #pragma unroll
             for (int off = 1; off < NQ; off <<= 1) {
 #pragma unroll
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void flow_boundary_bwd_kernel(BoundaryBwdPa
     __syncthreads();
 
     // ---- phase 3: dskip = (W_end^T dout) [mask] ------------------------------------------------------------------------------
-    bnd_gemm<NT>(p.wb_end, H, (p.exp & 2) ? 0 : GC, Xs, wave, lrow, lk, aw, acc);
+    bnd_gemm<NT>(p.wb_end, H, (GLOWTTS_EXP_BITS(p.exp) & 2) ? 0 : GC, Xs, wave, lrow, lk, aw, acc);
 #pragma unroll
     for (int r = 0; r < kBndRT; ++r) {
         const int row0 = (wave + 4 * r) * 16 + lk * 4;
@@ -554,7 +554,7 @@ extern "C" int glowtts_flow_boundary_fwd(const float *skip, const float *wp_end,
                       "glowtts_flow_boundary_fwd: tensors must be 16-byte aligned");
     if ((long)B * T == 0) return 0;
     BoundaryParams p{skip, wp_end, b_end, y_prev, mask, logs, bias, w, logdet_w, x_len, wp_start, b_start,
-                     out, y, h0, logdet_prev, logdet, B, C, H, T, sigmoid_scale, env_knob("GLOWTTS_BND_EXP", 0)};
+                     out, y, h0, logdet_prev, logdet, B, C, H, T, sigmoid_scale, GLOWTTS_EXP_BITS(knob(K_BND_EXP))};
     // 32 frames per workgroup (400 workgroups at config 2).  16-frame tiles (800 workgroups, three per CU) were measured: 36 us against
     // 28 — every workgroup streams both weight matrices from L2, and halving the tile halves the use of each weight register
     constexpr int nt = 32;
@@ -588,7 +588,7 @@ extern "C" int glowtts_flow_boundary_bwd(const float *dx_wn, const float *wb_sta
                       "glowtts_flow_boundary_bwd: tensors must be 16-byte aligned");
     if ((long)B * T == 0) return 0;
     BoundaryBwdParams p{dx_wn, wb_start, dy_next, y_prev, out_prev, mask, logs, bias, w, dlogdet, wb_end,
-                        dy_prev, dout_prev, dskip, partial, B, C, H, T, sigmoid_scale, mask_dskip, env_knob("GLOWTTS_BND_EXP", 0)};
+                        dy_prev, dout_prev, dskip, partial, B, C, H, T, sigmoid_scale, mask_dskip, GLOWTTS_EXP_BITS(knob(K_BND_EXP))};
     constexpr int nt = 32;
     constexpr size_t lds = ((size_t)kBndMaxG * nt * kBndKP + 192 * (nt + 1) + nt) * sizeof(float);
     const dim3 grid(B * ((T + nt - 1) / nt));

@@ -409,8 +409,7 @@ static std::atomic<int> g_wn_fused_launches{0};
 static bool wn_fused_enabled() {
     int v = g_wn_fused.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char *e = getenv("GLOWTTS_WN_FUSED");
-        v = e && e[0] == '1';
+        v = knob(K_WN_FUSED) == 1;
         g_wn_fused.store(v, std::memory_order_relaxed);
     }
     return v != 0;

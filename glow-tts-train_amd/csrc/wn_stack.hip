@@ -166,7 +166,7 @@ extern "C" int glowtts_wn_bwd_io(const glowtts_wn_layer *layers, int n_layers, c
         // another): a launch per problem ends with its split-K atomics draining before the stream's next kernel may start; in one
         // launch the next problem's workgroups take the compute units as they free up — 15.54 -> 15.30 ms per step (three
         // alternating runs).  GLOWTTS_WRW_BATCH=0: a launch per layer, each as soon as its operands exist.
-        static const bool batch = [] { const char *e = getenv("GLOWTTS_WRW_BATCH"); return !(e && e[0] == '0'); }();
+        const bool batch = knob(K_WRW_BATCH) != 0;
         if (batch && n_layers <= 8) {
             const float *bx5[8], *bd5[8], *bx1[8], *bd1[8], *bd1b[8];
             float *bw5[8], *bb5[8], *bw1[8], *bb1[8];

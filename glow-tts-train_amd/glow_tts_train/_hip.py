@@ -157,7 +157,8 @@ class EncLayer(ctypes.Structure):
 
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
-                           "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused"])
+                           "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused",
+                           "glowtts_set_knob", "glowtts_get_knob"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -190,6 +191,10 @@ def load() -> ctypes.CDLL:
     lib.glowtts_conv_math.argtypes = [_I]
     lib.glowtts_wn_fused.restype = _I
     lib.glowtts_wn_fused.argtypes = [_I]
+    lib.glowtts_set_knob.restype = _I
+    lib.glowtts_set_knob.argtypes = [ctypes.c_char_p, _I]
+    lib.glowtts_get_knob.restype = _I
+    lib.glowtts_get_knob.argtypes = [ctypes.c_char_p, ctypes.POINTER(_I)]
     lib.glowtts_conv_bind_planes.restype = _I
     lib.glowtts_conv_bind_planes.argtypes = [_P, _L, _P]
     lib.glowtts_conv_bind_planes_ns.restype = _I
@@ -275,6 +280,22 @@ def wn_fused(enable: Optional[bool] = None) -> bool:
 def wn_fused_launches() -> int:
     """Launches of the layer-resident WN forward kernel so far in this process."""
     return int(load().glowtts_wn_fused(-2))
+
+
+def set_knob(name: str, value: int) -> None:
+    """Set one of the library's tuning switches (include/glowtts_hip.h, conventions block) for the launches queued from now
+    on; an unknown name raises."""
+    lib = load()
+    if lib.glowtts_set_knob(name.encode(), int(value)) != 0:
+        raise RuntimeError(lib.glowtts_last_error().decode())
+
+
+def get_knob(name: str) -> int:
+    lib = load()
+    out = _I(0)
+    if lib.glowtts_get_knob(name.encode(), ctypes.byref(out)) != 0:
+        raise RuntimeError(lib.glowtts_last_error().decode())
+    return int(out.value)
 
 
 def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] = None):

@@ -11,33 +11,48 @@
  *       process-wide, mutable : the arithmetic mode of glowtts_conv_math and the glowtts_wn_fused switch (explicit setters;
  *                               atomic — a launch uses the setting in force when it is queued, so flip them between steps,
  *                               not while a backward runs);
- *       process-wide, latched : the tuning switches below, read from the environment ONCE at the first launch that
- *                               consults them (they select between kernels with identical results; defaults in brackets):
- *                                 GLOWTTS_WRW_TR      [unset] 0 = 5-tap weight gradient on the frame-packed kernel, 1 = 64x32
+ *       process-wide, latched : the tuning switches below — ALL of them are read from the environment ONCE, at the library's
+ *                               first use of any of them, into a table of atomics (csrc/error.hip; no getenv on the launch
+ *                               path); glowtts_set_knob(name, value) changes one afterwards (the A/B tools flip them between
+ *                               blocks of steps; like the two setters above: not while a backward runs).  They select between
+ *                               kernels / launch geometries with IDENTICAL results; defaults in brackets (-1 = unset):
+ *                                 GLOWTTS_WRW_TR      [-1]    0 = 5-tap weight gradient on the frame-packed kernel, 1 = 64x32
  *                                                     tiles in the 16x16x32 form            (csrc/convwrw_tr.hip)
  *                                 GLOWTTS_WRW_TR_MT   [4]     2 = 64x32 tiles (32x32x16 form) instead of 64x64
  *                                 GLOWTTS_WRW_TR3     [1]     0 = 3-tap weight gradients on the frame-packed kernel
+ *                                 GLOWTTS_WRW_TR3_MT  [2]     4 = 3-tap weight gradients on 64x64 tiles instead of 64x32
  *                                 GLOWTTS_WRW_TR_PRIO [2]     which wave group of the 5-tap weight gradient runs at raised priority
+ *                                                     (0 = the multiplying waves, 1 = nobody, 2 = the storing waves)
  *                                 GLOWTTS_WRW_BATCH   [1]     0 = one weight-gradient launch per WN layer (csrc/wn_stack.hip)
  *                                 GLOWTTS_WRW1_PIPE   [1]     0 = 1x1 weight gradient without the software-pipelined plane split
- *                                                     (csrc/convgemm_split.hip; this one is read at every launch)
+ *                                                     (csrc/convgemm_split.hip)
  *                                 GLOWTTS_WRW5_BSPLIT [1]     0 = a batched 5-tap weight-gradient launch sizes its split-K per problem
  *                                                     (one round of workgroups per problem) instead of sharing the compute units
- *                                                     between the problems of the batch (csrc/convwrw_tr.hip; read at every launch)
+ *                                                     between the problems of the batch (csrc/convwrw_tr.hip)
  *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
- *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip; read at
- *                                                     every launch)
+ *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip)
+ *                                 GLOWTTS_WRW1_CUS    [-1]    compute units the multi-problem 1x1 weight gradient sizes its split-K for
+ *                                                     (-1 = half of the device's: DESIGN.md 4j)
+ *                                 GLOWTTS_WRW1_XCD    [1]     0 = its split count is not rounded down to a multiple of 8 (one split's
+ *                                                     tiles then no longer share an XCD)
  *                                 GLOWTTS_WRW_TR_NG   [2]     1 = the 5-tap 64 x 64 weight gradient with ONE 4-wave group per workgroup (half the
- *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36; read at every launch;
+ *                                                     LDS; measured 0.5 ms per step slower: DESIGN.md lesson 36;
  *                                                     GLOWTTS_WRW_TR_NG_SPLITS [1] multiplies its split-K workgroup count)
- *                                 GLOWTTS_BND_EXP     [0]     timing experiments of csrc/flow_boundary.hip (WRONG results): bit 0 / 1 = without
- *                                                     the first / second contraction's MFMAs, 2 = without the element-wise phase, 3 =
- *                                                     backward without the group reduction (tools/boundary_bench.py; read at every launch)
  *                                 GLOWTTS_CONV_ROW_ADJ [1]    0 = the bf16-plane convolution kernels take their workgroups in grid order
  *                                                     (all frame tiles of row tile 0, then row tile 1, ..) instead of numbering the
  *                                                     row tiles of one frame tile into consecutive slots of one XCD
- *                                                     (csrc/convgemm_split.hip; read at every launch)
+ *                                                     (csrc/convgemm_split.hip)
+ *                                 GLOWTTS_CONV32_1X1  [1]     0 = plain 1x1 convolutions (native fp32 kernels) on 80- / 64-frame tiles
+ *                                                     instead of 32-frame tiles (csrc/convgemm.hip)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
+ *                               Only in the tuning build (`make -C csrc trace`, -DGLOWTTS_TRACE, tools/libglowtts_trace.bin; the
+ *                               shipped library contains neither the names nor the code paths), timing experiments that make
+ *                               kernels SKIP work and so give WRONG results:
+ *                                 GLOWTTS_BND_EXP     [0]     csrc/flow_boundary.hip: bit 0 / 1 = without the first / second contraction's
+ *                                                     MFMAs, 2 = without the element-wise phase, 3 = backward without the group
+ *                                                     reduction (tools/boundary_bench.py)
+ *                                 GLOWTTS_WRW1_EXP    [0]     csrc/convwrw1.hip: bit 0 = no atomics, 2 = no MFMAs, 3 = no loads after the first
+ *                                                     step (tools/wrw1_bench.py)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
  *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)
@@ -62,6 +77,13 @@ typedef void *glowtts_stream_t; /* hipStream_t */
 
 const char *glowtts_last_error(void);
 int glowtts_abi_version(void);
+
+/* ---- tuning switches (conventions block above; no reference counterpart: the reference has no native tuning state) ----------
+ * set_knob : set the switch `name` ("GLOWTTS_WRW_TR_MT" or "WRW_TR_MT") for every launch queued from now on; non-zero (and
+ *            glowtts_last_error) for a name the library does not know — a misspelt switch is an error, not a silent no-op.
+ * get_knob : the value in force (environment value, default, or the last set_knob). */
+int glowtts_set_knob(const char *name, int value);
+int glowtts_get_knob(const char *name, int *value);
 
 /* ---- monotonic alignment search ----------------------------------------------------------------------------
  * replaces maximum_path_c / maximum_path_each (monotonic_align/core.pyx:9-45) and the D2H/H2D round trip of its

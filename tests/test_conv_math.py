@@ -138,6 +138,33 @@ def test_every_mode_against_fp64(M, b, h, t):
     _check(_errors(wrw1, torch.einsum("bot,bct->co", d2.double(), acts_in.double()).reshape(-1), M, (), MODES), "weight grad 1x1")
 
 
+@pytest.mark.parametrize("b,h,m,t", [(32, 192, 192, 128), (32, 192, 384, 192), (40, 192, 192, 96), (32, 192, 384, 160)])
+def test_unmasked_1x1_weight_gradient_with_several_chunks_per_workgroup(M, b, h, m, t):
+    """The software-pipelined 1x1 weight gradient (convwrw_split_kernel<., 1, 4 | 5, 4>, AG form) when a workgroup holds
+    MORE THAN ONE chunk: the split units of chunk c + 1 ride behind the MFMA groups of chunk c, and the 64-frame form has as
+    many units as groups — its last unit (rows 48..63 of the d tile, the last bias partial) once ran in the prologue only, so
+    every later chunk multiplied chunk 0's d planes.  T = 128 / 192 / 96 take the 64-frame form
+    (nb = ceil(B * ceil(T / 64) / (512 / tiles)) >= 2 here), T = 160 the 80-frame one; dW and dbias against fp64."""
+    call, ptr = M.hip.call, M.hip.ptr
+    dev = "cuda"
+    torch.manual_seed(b + h + m + t)
+    x = torch.randn(b, h, t, device=dev) * 0.5
+    d = torch.randn(b, m, t, device=dev)
+    tiles = -(-h // 64) * -(-m // 64)
+    ct = 80 if (t % 80 == 0 or -(-t // 80) * 80 <= -(-t // 64) * 64) else 64
+    assert -(-(b * -(-t // ct)) // (512 // tiles)) >= 2, "the case must give a workgroup several chunks"
+
+    def wrw1():
+        dwp = torch.zeros(1, h, m, device=dev)
+        db = torch.zeros(m, device=dev)
+        call("glowtts_conv_wrw", ptr(x), x.stride(0), ptr(d), d.stride(0), None, None, ptr(dwp), ptr(db), b, h, m, t, 1, 1, 0)
+        return torch.cat([dwp.reshape(-1), db])
+
+    ref = torch.cat([torch.einsum("bot,bct->co", d.double(), x.double()).reshape(-1), d.double().sum((0, 2))])
+    err = _errors(wrw1, ref, M, (), ("fp32", "bf16x6+wrw"))
+    assert err["fp32"] < 2e-5 and err["bf16x6+wrw"] <= 1.5 * err["fp32"] + 1e-7, err
+
+
 def test_planes_are_a_snapshot_and_only_bound_weights_switch(M):
     """The planes are a snapshot of the packed buffer they were made from (WNPackPlan re-splits after every pack), and only
     the buffer bound to the calling thread runs in the selected mode: everything else stays native, bit for bit."""

@@ -461,6 +461,59 @@ def test_conv_math_mode_names():
         _hip.conv_math(before)
 
 
+def test_tuning_switches_are_latched_listed_and_settable():
+    """the library's tuning switches.  (1) No kernel-launch path calls getenv: the ONLY getenv of csrc/ is the
+    one-time table fill in error.hip.  (2) Every switch name of that table is documented in include/glowtts_hip.h, and the header
+    names no switch the table lacks.  (3) The two skip-work experiment switches exist under GLOWTTS_TRACE only: the shipped
+    library does not contain their names.  (4) glowtts_set_knob / glowtts_get_knob work without a GPU and reject unknown names."""
+    from glow_tts_train import _hip
+
+    csrc = os.path.join(ROOT, "glow-tts-train_amd", "csrc")
+    sites = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".hpp")):
+            for i, line in enumerate(open(os.path.join(csrc, fn)), 1):
+                code = line.split("//")[0]
+                if re.search(r"\bgetenv\s*\(|\benv_knob\s*\(", code):
+                    sites.append((fn, i))
+    assert [f for f, _ in sites] == ["error.hip"], f"getenv outside the one-time table fill: {sites}"
+
+    err = open(os.path.join(csrc, "error.hip")).read()
+    table = err[err.index("kKnobs[K_COUNT] = {"):err.index("};", err.index("kKnobs[K_COUNT] = {"))]
+    shipped_part, _, trace_part = table.partition("#ifdef GLOWTTS_TRACE")
+    shipped = re.findall(r'\{"([A-Z0-9_]+)",', shipped_part)
+    trace_only = re.findall(r'\{"([A-Z0-9_]+)",', trace_part)
+    assert len(shipped) >= 10 and sorted(trace_only) == ["BND_EXP", "WRW1_EXP"]
+    common = open(os.path.join(csrc, "common.hpp")).read()
+    enum = common[common.index("enum Knob {"):common.index("K_COUNT", common.index("enum Knob {"))]
+    assert re.findall(r"\bK_([A-Z0-9_]+)", enum) == shipped + trace_only, "enum Knob and the name table must have one order"
+
+    header = open(os.path.join(ROOT, "include", "glowtts_hip.h")).read()
+    conventions = header[:header.index("#ifndef GLOWTTS_HIP_H")]
+    documented = set(re.findall(r"GLOWTTS_([A-Z0-9_]+)\s+\[-?\d+\]", conventions))
+    assert documented == set(shipped) | set(trace_only), (documented ^ (set(shipped) | set(trace_only)))
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in shipped:
+        assert "GLOWTTS_" + name in conventions
+
+    blob = open(_hip.library_path(), "rb").read()
+    for name in trace_only:
+        assert ("GLOWTTS_" + name).encode() not in blob and (name + "\0").encode() not in blob, f"{name} in the shipped library"
+    assert b"WRW_TR_PRIO\0" in blob
+
+    before = _hip.get_knob("GLOWTTS_WRW_TR_MT")
+    try:
+        _hip.set_knob("WRW_TR_MT", 2)
+        assert _hip.get_knob("GLOWTTS_WRW_TR_MT") == 2
+    finally:
+        _hip.set_knob("GLOWTTS_WRW_TR_MT", before)
+    with pytest.raises(RuntimeError, match="no tuning switch"):
+        _hip.set_knob("GLOWTTS_BND_EXP", 1)
+    with pytest.raises(RuntimeError, match="no tuning switch"):
+        _hip.get_knob("GLOWTTS_NOT_A_SWITCH")
+    assert "glowtts_set_knob" in integration
+
+
 def test_fastcall_binding_matches_the_ctypes_table():
     """`_glowtts_fastcall` (generated by csrc/gen_fastcall.py, built by `make`) wraps exactly the entry points of
     `_hip._SIGNATURES`, is bound to the addresses of the library ctypes opened, validates its arguments, and `call()` uses

@@ -3,7 +3,7 @@
 Usage: python tools/ab_flags.py NAME=VALUE_A,VALUE_B [steps_per_block] [blocks]
   NAME in: boundary (0|1: one launch between the WN stacks of consecutive blocks), stackpack (0|1: one weight-pack and one W^-1 launch for the flow stack), fuseflows (0|1: coupling(k) fused with ActNorm + InvConv(k + 1) in FlowStackFn), enc_wgrad (0|1: encoder weight gradients on the decoder's weight-gradient stream), native (both|fwd: whole-block /
   whole-layer executors vs the per-operator path), io (fp32|all|hidden), fused (0|1: layer-resident WN forward kernel),
-  envs (library knobs that are read on every launch: envs=GLOWTTS_A:0+GLOWTTS_B:4,GLOWTTS_A:1+GLOWTTS_B:2)"""
+  envs (the library's tuning switches, flipped with glowtts_set_knob: envs=GLOWTTS_A:0+GLOWTTS_B:4,GLOWTTS_A:1+GLOWTTS_B:2)"""
 import os
 import sys
 import time
@@ -52,11 +52,13 @@ def apply(v):
             convops.WNPackPlan._pack_real = convops.WNPackPlan.pack
         convops.WNPackPlan.pack = (lambda self: None) if v == "1" else convops.WNPackPlan._pack_real
     elif name == "wrw1pipe":                                # software-pipelined 1x1 weight gradient (csrc/convgemm_split.hip) on / off
-        os.environ["GLOWTTS_WRW1_PIPE"] = v
-    elif name == "envs":                                    # library knobs read per launch: envs=K1:a+K2:b,K1:c+K2:d
+        from glow_tts_train import _hip
+        _hip.set_knob("GLOWTTS_WRW1_PIPE", int(v))
+    elif name == "envs":                                    # library tuning switches: envs=K1:a+K2:b,K1:c+K2:d
         for kv in v.split("+"):
             k, _, val = kv.partition(":")
-            os.environ[k] = val
+            from glow_tts_train import _hip
+            _hip.set_knob(k, int(val))                     # (the library latches its environment once: glowtts_set_knob flips a switch)
     elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
         global CHAIN
         CHAIN = v == "1"

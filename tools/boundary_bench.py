@@ -1,6 +1,6 @@
 """csrc/flow_boundary.hip alone: the one-launch block boundary against the three launches it replaces, forward and backward, at the
 benchmark's shape (B = 32, C = 160, H = 192, T' = 400), HIP events around 200 back-to-back launches; then with one ingredient
-dropped at a time (GLOWTTS_BND_EXP bits: 1 = first contraction's MFMAs, 2 = second contraction's, 4 = the element-wise phase,
+dropped at a time (only with GLOWTTS_HIP_LIB=tools/libglowtts_trace.bin, the tuning build; GLOWTTS_BND_EXP bits: 1 = first contraction's MFMAs, 2 = second contraction's, 4 = the element-wise phase,
 8 = backward: the group reduction of the parameter-gradient partials).  DESIGN.md lesson 36.
 
   python tools/boundary_bench.py"""
@@ -64,10 +64,12 @@ print("forward: max |difference| out / y / h0 against the three launches:", floa
       float((h0 - h02).abs().max()))
 timeit("forward boundary, one launch", fwd)
 timeit("forward boundary, three launches", fwd3)
-for e in (1, 2, 4, 7):
-    os.environ["GLOWTTS_BND_EXP"] = str(e)
+EXP = "libglowtts_trace" in _hip.library_path()            # the skip-work experiments exist in the tuning build only (make trace)
+for e in (1, 2, 4, 7) if EXP else ():
+    _hip.set_knob("GLOWTTS_BND_EXP", e)
     timeit(f"  forward, GLOWTTS_BND_EXP={e}", fwd)
-os.environ["GLOWTTS_BND_EXP"] = "0"
+if EXP:
+    _hip.set_knob("GLOWTTS_BND_EXP", 0)
 
 # ---- backward ----------------------------------------------------------------------------------------------------------------
 dx_wn, dy_next, out_prev, dlogdet = f(b, h, t), f(b, c, t), f(b, c, t) * 0.3, f(b)
@@ -101,6 +103,6 @@ print("backward: max |difference| dy / dout / dskip against the three launches:"
 timeit("backward boundary, one launch", bwd)
 timeit("backward: reduction of the partials", red)
 timeit("backward boundary, three launches (+ one copy)", bwd3)
-for e in (1, 2, 4, 8, 15):
-    os.environ["GLOWTTS_BND_EXP"] = str(e)
+for e in (1, 2, 4, 8, 15) if EXP else ():
+    _hip.set_knob("GLOWTTS_BND_EXP", e)
     timeit(f"  backward, GLOWTTS_BND_EXP={e}", bwd)

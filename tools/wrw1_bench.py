@@ -1,7 +1,8 @@
 """Time of glowtts_conv_wrw1_multi on a flow block's six 1x1 weight gradients (B=32, H=192, C=160, T'=400) and on a transformer
 layer's four (B=32, 192 channels, T=160): HIP events around back-to-back launches.  python tools/wrw1_bench.py [reps]
-GLOWTTS_WRW1_CUS=<n> sizes the split-K for n compute units; GLOWTTS_WRW1_EXP bit 0 drops the atomics, bit 1 the plane split of the
-loop (timing experiments: the results are then wrong)."""
+GLOWTTS_WRW1_CUS=<n> sizes the split-K for n compute units; GLOWTTS_WRW1_EXP (tuning build only:
+GLOWTTS_HIP_LIB=tools/libglowtts_trace.bin) bit 0 drops the atomics, bit 2 the MFMAs, bit 3 the loads after the first step (timing
+experiments: the results are then wrong)."""
 import ctypes
 import os
 import sys
