@@ -12,26 +12,28 @@ T_text=160, T_mel=800, 80 mels, 12 flow blocks, n_split=4, fp32, ModelConfig def
 random-init weights, data-dependent ActNorm init done before timing.  Weak scaling: every rank gets its own B=32.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  "roofline"     : the dominant hand-written HIP kernel of the step (largest total time): the weight gradient of the WN stack's
-                   5-tap convolutions, bound = "mfma".  Its mean launch duration is measured with HIP events on the launch
-                   stream in an instrumented pass after the timed region.  In the default arithmetic ("bf16x6+wrw": each fp32
-                   operand as three bf16 planes, six products per fp32 product on v_mfma_f32_16x16x32_bf16) the line carries
-                   THREE fractions and says which is which:
+  "roofline"     : the dominant hand-written HIP launch of the step, chosen MECHANICALLY: arg-max of launches per step x mean
+                   duration over the table of launches the step makes (`as_launched_top5`).  Mean durations come from an
+                   instrumented pass after the timed region (HIP events on the launch stream around every launch); the two
+                   families the step batches (a WN stack's four 5-tap weight gradients = one glowtts_conv_wrw_batch launch, a
+                   block's 1x1 weight gradients = one glowtts_conv_wrw1_multi launch) are re-priced with that batched launch
+                   timed back to back.  In the default arithmetic ("bf16x6+wrw": each fp32 operand as three bf16 planes, six
+                   products per fp32 product on v_mfma_f32_16x16x32_bf16) the object carries THREE fractions:
                      frac_algorithmic = algorithmic FLOPs (2*M*K*taps*columns) / t / 2.5 PFLOP/s dense bf16 peak,
                      frac_pipe        = 6 x that (the MFMA work the pipe really does) = `frac`,
-                     mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the committed PMC
-                                        pass (profiles/r04_pmc.json), null when no pass exists for the kernel;
-                   with GLOWTTS_CONV_MATH=fp32 the peak is the 157.3 TFLOP/s dense fp32 MFMA figure and all three coincide.
-                   Round 4: `frac`, `achieved`, `mean_us` are those of the launch the step really makes — the four layers'
-                   problems of a WN stack in ONE glowtts_conv_wrw_batch launch (HIP events on its stream around back-to-back
-                   launches after the timed region; "as_launched_in_the_step" has the per-problem figures); the single-problem
-                   launch of the instrumented pass stays beside them as "single_launch".
-                   "wrw1_multi_as_launched_in_the_step": a flow block's six 1x1 weight gradients as the one
-                   glowtts_conv_wrw1_multi launch the step makes for them (csrc/convwrw1.hip).
-                   "traffic" = HBM-side bytes per launch from the PMC passes.  Every MFMA kernel is listed with its
-                   algorithmic bytes and FLOPs, its time at each roof and `bound: hbm|mfma` (the 1x1 convolutions are
-                   byte-bound: they are reported against 8 TB/s, not as TFLOP/s alone); every streaming kernel with GB/s against
-                   8 TB/s; plus the SURVEY.md 8d(i) invertible-subset fraction and the decoder alone (8d(ii));
+                     mfma_busy_measured = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs) from the NEWEST committed
+                                        counter pass (profiles/rNN_pmc.json); `traffic` = HBM-side bytes per launch from the same
+                                        record (`pmc_source`, `pmc_key` say which).  Both are null when that file has no record
+                                        under exactly this kernel's name and grid — never another kernel's, never an older round's.
+                   "wrw5_batch_as_launched_in_the_step": the batched 5-tap weight gradient (the dominant launch until round 4)
+                   whichever launch leads; "wrw1_multi_as_launched_in_the_step": a flow block's six 1x1 weight gradients.
+                   Every MFMA kernel is listed with its algorithmic bytes and FLOPs, its time at each roof and `bound: hbm|mfma`
+                   (the 1x1 convolutions are byte-bound: reported against 8 TB/s); every streaming kernel with GB/s against 8 TB/s;
+                   plus SURVEY.md 8d(i)'s invertible subset (un-fused kernels of the instrumented pass, and
+                   `as_launched_in_the_step`: the block-boundary launch forward / the fused kernel backward) and the decoder
+                   alone (8d(ii));
+  "other_configs": BASELINE configs[2] (bf16 tensors, B=64, T_mel=1000) and configs[4] (speaker-conditioned, B=48, T_mel=1200,
+                   20 blocks) timed after everything else, 3 warm-up + 5 steps each (N=1 only; never `value`);
   "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) on this host's cores as BASELINE.md section 3 prescribes:
                    3 warm-up + 10 timed full steps, median, all usable cores, plus a 1-thread run on a shorter sample; the
                    CPU model is stated.
@@ -70,6 +72,8 @@ def parse():
     ap.add_argument("--gin", type=int, default=64, help="speaker embedding width when --speakers > 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the leg that times BASELINE configs[2] and configs[4] for a few steps after the main workload")
     ap.add_argument("--no-split-math", action="store_true",
                     help="skip the extra leg that times the same step with the WN convolutions in bf16x6 split arithmetic")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU-oracle steps on all cores (BASELINE.md section 3: 10)")
@@ -123,62 +127,86 @@ INVERTIBLE_SUBSET = ("glowtts_actnorm_fwd", "glowtts_actnorm_bwd", "glowtts_invc
                      "glowtts_coupling_bwd")
 
 
-# bench tag -> (HIP kernel, grid size) of the committed counter passes, per arithmetic of the WN convolutions
+# bench tag -> (HIP kernel, grid size[#duration class]) in the NEWEST committed counter passes (profiles/rNN_pmc.json), per
+# arithmetic of the WN convolutions.  tests/test_host_cpu.py::test_bench_pmc_keys_exist_in_the_newest_profiles holds every value to a
+# key of that file, its kernel name to a row of the newest rNN_kernel_stats.csv, and its traffic to >= 0.9 x the algorithmic bytes:
+# a kernel that is renamed (a new template argument) without a new counter pass fails the CPU suite instead of silently
+# reporting another kernel's bytes.
 _PMC_KERNEL = {
-    # round 4: the launch the step makes — a WN stack's four problems sharing one round of 216 workgroups (the pre-net's single
+    # the launch the step makes for a WN stack's four 5-tap weight gradients: one round of 216 workgroups (the pre-net's single
     # 5-tap problems have the same grid size: tools/rocpd_summary.py separates the two duration classes)
-    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false> grid=110592#long",
-    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32"): "convwrw_fp_kernel<5,5,2> grid=196608",
+    ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false,2> grid=110592#long",
     ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
     ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
+    ("glowtts_conv_gate_bwd[M192 K384x1 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,5,1,0,3> grid=122880",
+    ("glowtts_conv_res_skip_fwd[M384 K192x1 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,2,1,0,3> grid=122880",
+    ("glowtts_flow_boundary_fwd", "bf16x6+wrw"): "flow_boundary_fwd_kernel<4,32> grid=106496",
+    ("glowtts_coupling_actnorm_invconv_bwd", "bf16x6+wrw"): "coupling_ai_bwd_kernel<4,4> grid=51200",
 }
+# kernels whose launch the step makes with SEVERAL problems: the record is per launch, the algorithmic bytes per problem
+_PMC_PROBLEMS_PER_LAUNCH = {"glowtts_conv_wrw[M384 K192x5 N32x400]": 4}
+
+
+def newest_profile(suffix):
+    """Path of profiles/rNN<suffix> with the largest NN (None when there is none): the bench line reads committed counter /
+    kernel-trace records of the NEWEST round only — an older round's file describes older kernels."""
+    import re as _re
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    best = None
+    try:
+        for fn in os.listdir(here):
+            m = _re.fullmatch(r"r(\d+)" + _re.escape(suffix), fn)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), os.path.join(here, fn))
+    except OSError:
+        return None
+    return best[1] if best else None
 
 
 def pmc_entry(kernel_tag, math="bf16x6+wrw"):
     """The committed rocprofv3 PMC record of `kernel_tag` (FETCH_SIZE / WRITE_SIZE / MFMA-busy cannot be collected from inside
-    this process): profiles/r04_pmc.json, else r03 / r02 — tools/pmc_passes.sh over this same bench command, one counter group per
-    run, combined per kernel (matched by name; the grid size is part of the key) by tools/pmc_combine.py as
-    MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled on gfx950).  {} when no measurement exists."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    key = _PMC_KERNEL.get((kernel_tag, math if math.startswith("bf16x6") else "fp32"))
-    if key is None:
+    this process): the newest profiles/rNN_pmc.json — tools/pmc_passes.sh over this same bench command, one counter group per
+    run, combined per kernel (exact name AND grid size) by tools/pmc_combine.py as MI355X_MICROARCH.md prescribes (FETCH_SIZE
+    doubled on gfx950).  {} when that file has no record under exactly this key: never another kernel's, never an older round's."""
+    key = _PMC_KERNEL.get((kernel_tag, math))
+    path = newest_profile("_pmc.json")
+    if key is None or path is None:
         return {}
-    name = key.split(" grid=")[0]
-    for fn in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
-        try:
-            table = json.load(open(os.path.join(here, "profiles", fn)))
-        except Exception:
-            continue
-        if key in table:
-            return dict(table[key], source="profiles/" + fn)
-        if "#long" in key:                         # the batched launch was never profiled before round 4: no older record applies
-            continue
-        same = [k for k in table if k.split(" grid=")[0] == name]
-        if same:                                   # same kernel, another grid size: the largest (the config-2 shape)
-            k = max(same, key=lambda k_: int(k_.split("grid=")[1].split("#")[0]))
-            return dict(table[k], source="profiles/" + fn)
-    return {}
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return {}
+    if key not in table:
+        log(f"no PMC record for {kernel_tag!r} (key {key!r}) in {os.path.basename(path)}: traffic / mfma_busy reported as null")
+        return {}
+    return dict(table[key], source="profiles/" + os.path.basename(path), pmc_key=key)
 
 
-def subset_from_kernel_trace(sub_bytes, survey_gb, blocks):
-    """The invertible subset's kernels in the committed rocprofv3 kernel trace (profiles/r04_kernel_stats.csv: total dispatch time of
-    the subset's kernels over the traced steps): ms per step and the fractions of 8 TB/s that gives — beside the HIP-event figures of
-    this run, which include each launch's latency.  Since round 4 the step launches coupling(k) fused with ActNorm + InvConv(k + 1)
-    (coupling_ai_{fwd,bwd}_kernel: 3 X and 5 X per launch where the pair moved 5 X and 7 X): `alg_GB_as_launched` counts the bytes
-    of the launches the trace holds, `frac` is on those, `frac_unfused_bytes` on the per-kernel count the un-fused step moved."""
+def subset_from_kernel_trace(x_bytes, survey_gb, blocks):
+    """The kernels that carry the invertible subset (ActNorm, InvConvNear, affine apply) in the newest committed rocprofv3 kernel
+    trace (profiles/rNN_kernel_stats.csv, one stream: the launches the step makes), beside the HIP-event figures of this run
+    (which include each launch's latency).  What the step launches since round 4: forward — ONE flow_boundary_fwd_kernel per
+    block boundary (end conv + affine apply + ActNorm + InvConv + start conv: the subset's forward half cannot be timed apart from
+    the two contractions it shares the launch with, so that launch is counted WHOLE, with the 4.4 X it moves); backward —
+    coupling_ai_bwd_kernel (5 X); the first block's ActNorm + InvConv and the last block's coupling on the un-fused kernels.
+    `frac` = bytes of the launches found / their time / 8 TB/s; `survey_frac` = SURVEY 8d(i)'s un-fused 19.5 X per block over that
+    time — an UNDER-estimate of the subset's own fraction, since the forward launch's time includes two convolutions.  A fraction
+    above 1 would mean launches were missed: None is reported instead."""
     import csv
 
-    here = os.path.dirname(os.path.abspath(__file__))
-    names = {"actnorm_invconv_fwd_kernel": 2, "actnorm_invconv_bwd_kernel": 3, "coupling_fwd_kernel": 3, "coupling_bwd_kernel": 4,
-             "coupling_ai_fwd_kernel": 3, "coupling_ai_bwd_kernel": 5}          # X per launch
+    path = newest_profile("_kernel_stats.csv")
+    names = {"actnorm_invconv_fwd_kernel": 2.0, "actnorm_invconv_bwd_kernel": 3.0, "coupling_fwd_kernel": 3.0, "coupling_bwd_kernel": 4.0,
+             "coupling_ai_fwd_kernel": 3.0, "coupling_ai_bwd_kernel": 5.0,
+             # skip (H) + y in; out, y, h0 (H) out = (2 H + 3 C) / C = 5.4 X at H = 192, C = 160
+             "flow_boundary_fwd_kernel": 5.4, "flow_boundary_bwd_kernel": 8.6}          # X per launch
     try:
-        rows = list(csv.DictReader(open(os.path.join(here, "profiles", "r04_kernel_stats.csv"))))
+        rows = list(csv.DictReader(open(path)))
     except Exception:
         return None
     steps = next((int(r["Calls"]) for r in rows if "glowtts::adam_kernel<" in r["Name"]), 0)
     if not steps:
         return None
-    x_bytes = sub_bytes / (12.0 * blocks)               # the un-fused subset moves 12 X per block (2 + 3 + 3 + 4)
     ns, xs, us, calls = 0.0, 0.0, {}, {}
     for r in rows:
         for n, nx in names.items():
@@ -191,37 +219,49 @@ def subset_from_kernel_trace(sub_bytes, survey_gb, blocks):
         return None
     ms = ns / steps / 1e6
     launched = xs / steps * x_bytes
-    return {"source": "profiles/r04_kernel_stats.csv", "mean_us": us, "launches_per_step": calls, "ms_per_step": round(ms, 3),
+    frac, sfrac = launched / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, survey_gb / (ms * 1e-3) / HBM_PEAK_GBS
+    complete = calls.get("flow_boundary_fwd_kernel", 0) + calls.get("coupling_ai_fwd_kernel", 0) + calls.get("actnorm_invconv_fwd_kernel", 0) >= blocks - 0.5
+    return {"source": "profiles/" + os.path.basename(path), "mean_us": us, "launches_per_step": calls, "ms_per_step": round(ms, 3),
             "alg_GB_as_launched": round(launched / 1e9, 3),
-            "frac": round(launched / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "frac_unfused_bytes": round(sub_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "survey_frac": round(survey_gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+            "frac": round(frac, 4) if frac <= 1 and complete else None,
+            "survey_frac": round(sfrac, 4) if sfrac <= 1 and complete else None,
+            "note": "forward: the whole flow_boundary_fwd launch (two 1x1 contractions inside) is counted, so survey_frac under-states "
+                    "the subset's own fraction"}
 
 
 def fused_flows_time(args, dev, iters=30):
-    """The two fused kernels of the flow stack as the step launches them (convops.FlowStackFn): coupling(k) + ActNorm + InvConv(k + 1)
-    forward (3 X) and ActNorm + InvConv(k + 1) + coupling(k) backward (5 X) at the benchmark's shape, HIP events on the launch
-    stream around back-to-back launches (so each figure includes a launch's latency)."""
+    """What the step's flow stack launches BETWEEN the WN stacks of blocks k and k + 1 (convops.FlowStackFn, fp32 tensors), HIP
+    events on the launch stream around back-to-back launches at the benchmark's shape (each figure includes a launch's latency):
+    fwd — `glowtts_flow_boundary_fwd` (csrc/flow_boundary.hip: end conv(k) + affine apply(k) + ActNorm + InvConv(k + 1) + start
+          conv(k + 1) in ONE launch; algorithmic bytes skip + y in, out + y + h0 out = (2 H + 3 C) N e);
+    bwd — `glowtts_coupling_actnorm_invconv_bwd` (ActNorm + InvConv(k + 1) backward + coupling(k) backward: 5 X), between the
+          separately launched backward-data convolutions (the one-launch backward boundary is opt-in: no gain in the step)."""
     from glow_tts_train import _hip
 
-    b, t, c, ns = args.batch, args.t_mel // 2, 160, 4
+    b, t, c, h, ns = args.batch, args.t_mel // 2, 160, 192, 4
     f = lambda *sh: torch.randn(*sh, device=dev)                                                       # noqa: E731
     y_prev, out_prev, dz = f(b, c, t), f(b, c, t) * 0.1, f(b, c, t)
     mask, x_len = torch.ones(b, t, device=dev), torch.full((b,), float(t), device=dev)
     logs, bias, w = f(c) * 0.1, f(c) * 0.1, torch.linalg.qr(f(ns, ns))[0].contiguous()
     w_inv, logdet_w = torch.inverse(w).contiguous(), torch.zeros(1, device=dev)
-    y, ld_prev, ld, dld = torch.empty(b, c, t, device=dev), torch.zeros(b, device=dev), torch.zeros(b, device=dev), f(b)
+    ld_prev, ld, dld = torch.zeros(b, device=dev), torch.zeros(b, device=dev), f(b)
     dy_prev, dout_prev = torch.empty(b, c, t, device=dev), torch.empty(b, c, t, device=dev)
     dlogs, dbias, dw = torch.zeros(c, device=dev), torch.zeros(c, device=dev), torch.zeros(ns, ns, device=dev)
+    skip = f(b, h, t)
+    wp_end, b_end = f(h // 16, c, 16) * 0.05, f(c) * 0.1
+    wp_start, b_start = f((c // 2 + 15) // 16, h, 16) * 0.05, f(h) * 0.1
+    out, y, h0 = torch.empty(b, c, t, device=dev), torch.empty(b, c, t, device=dev), torch.empty(b, h, t, device=dev)
     P = lambda x: x.data_ptr()                                                                         # noqa: E731
-    fwd = lambda: _hip.call("glowtts_coupling_actnorm_invconv_fwd", P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w),   # noqa: E731
-                            P(logdet_w), P(x_len), P(y), P(ld_prev), P(ld), b, c, t, ns, 0)
+    fwd = lambda: _hip.call("glowtts_flow_boundary_fwd", P(skip), P(wp_end), P(b_end), P(y_prev), P(mask), P(logs), P(bias), P(w),   # noqa: E731
+                            P(logdet_w), P(x_len), P(wp_start), P(b_start), P(out), P(y), P(h0), P(ld_prev), P(ld), b, c, h, t, ns, 0)
     bwd = lambda: _hip.call("glowtts_coupling_actnorm_invconv_bwd", P(y_prev), P(out_prev), P(mask), P(logs), P(bias), P(w),   # noqa: E731
                             P(w_inv), P(dz), P(dld), P(x_len), P(dy_prev), P(dout_prev), P(dlogs), P(dbias), P(dw), b, c, t, ns, 0)
     cur = torch.cuda.current_stream(dev)
     res = {}
     x_bytes = 4.0 * b * c * t
-    for name, fn, nx in (("fwd", fwd, 3), ("bwd", bwd, 5)):
+    fwd_bytes = 4.0 * b * t * (2 * h + 3 * c)
+    for name, fn, nbytes, tag in (("fwd", fwd, fwd_bytes, "glowtts_flow_boundary_fwd"),
+                                  ("bwd", bwd, 5 * x_bytes, "glowtts_coupling_actnorm_invconv_bwd")):
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -231,24 +271,23 @@ def fused_flows_time(args, dev, iters=30):
         e1.record(cur)
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / iters
-        res[name] = {"mean_us": round(us, 2), "alg_MB": round(nx * x_bytes / 1e6, 2),
-                     "hbm_frac": round(nx * x_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        pe = pmc_entry(tag)
+        res[name] = {"entry": tag, "mean_us": round(us, 2), "alg_MB": round(nbytes / 1e6, 2),
+                     "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": pe.get("traffic_bytes"), "pmc_source": pe.get("source")}
+    res["fwd"]["what"] = ("end conv + affine apply + ActNorm + InvConv + start conv of a block boundary in one launch: the subset's "
+                          "forward half is not a launch of its own any more")
     nb = args.blocks
     res["ms_per_step_fused_part"] = round((nb - 1) * (res["fwd"]["mean_us"] + res["bwd"]["mean_us"]) / 1e3, 3)
+    res["alg_GB_fused_part"] = round((nb - 1) * (fwd_bytes + 5 * x_bytes) / 1e9, 3)
     res["note"] = ("per step: blocks - 1 launches of each, plus the first block's ActNorm + InvConv and the last block's coupling "
-                   "on the un-fused kernels (timed above)")
+                   "on the un-fused kernels (timed in the instrumented pass)")
     return res
 
 
 def pmc_traffic(kernel_tag, math="bf16x6+wrw"):
-    e = pmc_entry(kernel_tag, math)
-    if "traffic_bytes" in e:
-        return e["traffic_bytes"]
-    try:                                           # round 1's table (native kernels)
-        here = os.path.dirname(os.path.abspath(__file__))
-        return json.load(open(os.path.join(here, "profiles", "r01_pmc_traffic.json")))[kernel_tag]["traffic_bytes"]
-    except Exception:
-        return None
+    """HBM-side bytes per launch from the newest counter pass, or None (never a value measured on another kernel)."""
+    return pmc_entry(kernel_tag, math).get("traffic_bytes")
 
 
 def conv_algorithmic_bytes(name, M, K, taps, cols, H):
@@ -477,6 +516,56 @@ def build_workload(args, dev, rank):
     torch.cuda.synchronize()
     log("data-dependent init forward done")
     return model, opt, batch, cfg
+
+
+def other_configs_leg(args, dev, warm=3, steps=5):
+    """BASELINE.json configs[2] (bf16 tensors in HBM, B=64, T_mel=1000) and configs[4] (speaker-conditioned couplings, B=48,
+    T_mel=1200, 20 flow blocks, 4 speakers, gin 64): the same full training step, `warm` + `steps` steps each on fresh models,
+    so that the driver's run times them too.  Never `value`."""
+    import copy
+    import gc
+
+    from glow_tts_train.attentions import MultiHeadAttention
+    from glow_tts_train.train import train_batch
+
+    res = {}
+    for key, over, bf16 in (("configs[2]", dict(batch=64, t_mel=1000, blocks=12, speakers=0), True),
+                            ("configs[4]", dict(batch=48, t_mel=1200, blocks=20, speakers=4), False)):
+        a2 = copy.copy(args)
+        for k, v in over.items():
+            setattr(a2, k, v)
+        a2.t_text = 0
+        try:
+            model, opt, batch, cfg = build_workload(a2, dev, 0)
+            if bf16:
+                model.decoder.io_bf16 = "all"
+                for m in model.modules():
+                    if isinstance(m, MultiHeadAttention):
+                        m.bf16_mma = True
+            loss = None
+            for _ in range(warm):
+                loss = train_batch(model, opt, batch, cfg.grad_clip, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = train_batch(model, opt, batch, cfg.grad_clip, None)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[key] = {"workload": f"B={a2.batch}, T_text={a2.t_mel // 5}, T_mel={a2.t_mel}, {a2.blocks} flow blocks"
+                                    + (f", {a2.speakers} speakers (gin {a2.gin})" if a2.speakers else "")
+                                    + (", bf16 tensors in HBM for the flow decoder + bf16-MFMA attention, fp32 accumulate" if bf16 else ", fp32"),
+                        "dtype": "bf16 tensors / fp32 accumulate" if bf16 else "f32",
+                        "ms_per_step": round(1e3 * dt / steps, 3), "value": round(a2.batch * a2.t_mel * steps / dt),
+                        "unit": "mel-frames/s", "steps": steps, "warmup": warm, "final_loss": float(loss)}
+            log(f"other_configs {key}: {res[key]['ms_per_step']:.2f} ms/step")
+        except Exception as exc:                    # an orientation leg must never cost the run its result
+            log(f"other_configs {key} failed ({type(exc).__name__}: {exc}); reported as null")
+            res[key] = None
+        finally:
+            model = opt = batch = None
+            gc.collect()
+            torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -735,7 +824,6 @@ def main():
         sub_ms = sum(hbm[k]["total_ms_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
         sub_bytes = sum(alg[k] * hbm[k]["launches_per_step"] for k in INVERTIBLE_SUBSET if k in hbm)
         survey_gb = 3 * 6.5 * C * 4 * B * Ts * cfg.model.n_blocks_dec / 1e9
-        dom = max(mfma, key=lambda k: mfma[k]["total_ms_per_step"]) if mfma else None
         conv_ms = sum(v["total_ms_per_step"] for v in mfma.values())
         conv_flop = sum(v["alg_GFLOP"] * v["launches_per_step"] for v in mfma.values())
 
@@ -776,75 +864,110 @@ def main():
                        mfma_frac_pipe=round((6.0 if split else 1.0) * row["TFLOPs"] / peak, 4),
                        bound="hbm" if t_hbm > t_mfma else "mfma",
                        frac_of_bound=round(max(t_hbm, t_mfma) * 1e3 / row["mean_us"], 4))
-        if dom is not None:
-            if on_bf16_pipe(dom):
-                # six bf16 products per fp32 product: the pipe's work is 6 x the algorithmic FLOPs, its roof the dense bf16 peak
-                pipe = 6.0 * mfma[dom]["TFLOPs"]
-                pe = pmc_entry(dom, default_math)
-                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(pipe, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": pipe / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(dom, default_math),
-                                   "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)",
-                                   "what_frac_is": "frac = frac_pipe: the six bf16 MFMAs the kernel issues per fp32 product, "
-                                                   "counted as work, over the dense bf16 peak; frac_algorithmic counts the fp32 "
-                                                   "product once",
-                                   "frac_algorithmic": round(mfma[dom]["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS, 4),
-                                   "frac_pipe": round(pipe / BF16_MFMA_PEAK_TFLOPS, 4),
-                                   "roof_TFLOPs_fp32_equivalent": round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1),
-                                   "mfma_busy_measured": pe.get("mfma_util"), "pmc_source": pe.get("source"),
-                                   "mean_us": mfma[dom]["mean_us"], "alg_GFLOP": mfma[dom]["alg_GFLOP"],
-                                   "alg_MB": mfma[dom]["alg_MB"],
-                                   "fp32_equivalent_TFLOPs": mfma[dom]["TFLOPs"],
-                                   "fp32_equivalent_vs_fp32_mfma_peak": round(mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS, 4)}
-                try:        # the form the timed step launches: the four layers' problems of a WN stack in ONE launch (lesson 20)
-                    bt = batched_wrw_time(dom, dev)
-                    rf = out["roofline"]
-                    rf["as_launched_in_the_step"] = bt
-                    # Round 4: the step no longer makes the single launch the instrumented pass times — every WN
-                    # stack's four 5-tap weight gradients are ONE launch whose problems share a round of workgroups.  `frac`,
-                    # `achieved` and `mean_us` are that launch's (four problems' FLOPs over its duration, HIP events on its stream);
-                    # the single-problem launch stays beside them.
-                    rf["single_launch"] = {"mean_us": rf["mean_us"], "frac_pipe": rf["frac_pipe"], "frac_algorithmic": rf["frac_algorithmic"],
-                                           "fp32_equivalent_TFLOPs": rf["fp32_equivalent_TFLOPs"]}
-                    n_p, us_l = bt["problems_per_launch"], bt["us_per_problem"] * bt["problems_per_launch"]
-                    tf = (n_p * mfma[dom]["alg_GFLOP"] * 1e9) / (us_l * 1e-6) / 1e12      # fp32-equivalent TFLOP/s of the launch
-                    rf.update(kernel=dom + f" x{n_p} (one glowtts_conv_wrw_batch launch, as the step makes it)",
-                              achieved=round(6.0 * tf, 2), frac=6.0 * tf / BF16_MFMA_PEAK_TFLOPS,
-                              frac_pipe=round(6.0 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
-                              frac_algorithmic=round(tf / BF16_MFMA_PEAK_TFLOPS, 4), mean_us=round(us_l, 2),
-                              alg_GFLOP=round(n_p * mfma[dom]["alg_GFLOP"], 3), alg_MB=round(n_p * mfma[dom]["alg_MB"], 2),
-                              fp32_equivalent_TFLOPs=round(tf, 2),
-                              fp32_equivalent_vs_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4))
-                except Exception as exc:
-                    log(f"batched weight-gradient timing failed ({type(exc).__name__}: {exc})")
-                try:        # the flow block's six 1x1 weight gradients: one multi-problem launch (csrc/convwrw1.hip)
-                    out["roofline"]["wrw1_multi_as_launched_in_the_step"] = wrw1_multi_time(args, dev)
-                except Exception as exc:
-                    log(f"multi-problem 1x1 weight-gradient timing failed ({type(exc).__name__}: {exc})")
+        # ---- which launch is the dominant one: arg-max of (launches per step x mean duration) over the table of launches THE STEP
+        # MAKES.  The instrumented pass above times every convolution as a launch of its own; the step batches two families
+        # (csrc/wn_stack.hip): a WN stack's four 5-tap weight gradients are ONE glowtts_conv_wrw_batch launch, a block's 1x1 weight
+        # gradients ONE glowtts_conv_wrw1_multi launch.  Their rows are re-priced with the batched launch timed here (HIP events on
+        # its stream, back to back), then the largest total wins — no kernel is named by hand.
+        kd, nl = cfg.model.kernel_size_dec, cfg.model.n_blocks_dec * cfg.model.n_block_layers
+        wrw5_tag = next((t for t in mfma if re.match(rf"glowtts_conv_wrw\[M{2 * H} K{H}x{kd} ", t)
+                         and mfma[t]["launches_per_step"] == nl and on_bf16_pipe(t)), None)
+        bt = None
+        if wrw5_tag is not None:
+            try:
+                bt = batched_wrw_time(wrw5_tag, dev, n=cfg.model.n_block_layers)
+            except Exception as exc:
+                log(f"batched weight-gradient timing failed ({type(exc).__name__}: {exc})")
+        as_launched = {}
+        for tag, row in mfma.items():
+            us = row["mean_us"]
+            if tag == wrw5_tag and bt is not None:
+                us = bt["us_per_problem"]
+            as_launched[tag] = {"launches_per_step": row["launches_per_step"], "us_per_launch_or_problem": round(us, 2),
+                                "total_ms_per_step": round(row["launches_per_step"] * us / 1e3, 3)}
+        for tag, row in hbm.items():
+            as_launched[tag] = {"launches_per_step": row["launches_per_step"], "us_per_launch_or_problem": row["mean_us"],
+                                "total_ms_per_step": row["total_ms_per_step"]}
+        dom = max(as_launched, key=lambda k: as_launched[k]["total_ms_per_step"]) if as_launched else None
+        top5 = dict(sorted(as_launched.items(), key=lambda kv: -kv[1]["total_ms_per_step"])[:5])
+
+        def mfma_roofline(tag, mean_us, problems=1):
+            """Roofline object of one MFMA launch: `problems` problems of `tag`'s shape in `mean_us` microseconds."""
+            row = mfma[tag]
+            split = on_bf16_pipe(tag)
+            peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            mult = 6.0 if split else 1.0
+            tf = problems * row["alg_GFLOP"] * 1e9 / (mean_us * 1e-6) / 1e12          # fp32-equivalent TFLOP/s
+            alg_mb = problems * row["alg_MB"]
+            hbm_frac = alg_mb * 1e6 / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+            pe = pmc_entry(tag, default_math)
+            r = {"bound": "mfma", "kernel": tag + (f" x{problems} (one launch, as the step makes it)" if problems > 1 else ""),
+                 "achieved": round(mult * tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": mult * tf / peak,
+                 "traffic": pe.get("traffic_bytes"), "pmc_source": pe.get("source"), "pmc_key": pe.get("pmc_key"),
+                 "mfma_busy_measured": pe.get("mfma_util"),
+                 "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)" if split else "fp32 MFMA",
+                 "frac_algorithmic": round(tf / peak, 4), "frac_pipe": round(mult * tf / peak, 4),
+                 "mean_us": round(mean_us, 2), "alg_GFLOP": round(problems * row["alg_GFLOP"], 3), "alg_MB": round(alg_mb, 2),
+                 "hbm_frac_on_algorithmic_bytes": round(hbm_frac, 4),
+                 "traffic_over_algorithmic": (round(pe["traffic_bytes"] / (alg_mb * 1e6), 3) if pe.get("traffic_bytes") else None),
+                 "fp32_equivalent_TFLOPs": round(tf, 2),
+                 "fp32_equivalent_vs_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            if split:
+                r["roof_TFLOPs_fp32_equivalent"] = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
+                r["what_frac_is"] = ("frac = frac_pipe: the six bf16 MFMAs the kernel issues per fp32 product, counted as work, over "
+                                     "the dense bf16 peak; frac_algorithmic counts the fp32 product once")
+            if row.get("bound") == "hbm":               # a byte-bound contraction (1x1): report it against the HBM roof
+                r.update(bound="hbm", achieved=round(alg_mb * 1e6 / (mean_us * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=hbm_frac)
+            return r
+
+        if dom is not None and dom in mfma:
+            if dom == wrw5_tag and bt is not None:
+                n_p = bt["problems_per_launch"]
+                out["roofline"] = mfma_roofline(dom, bt["us_per_problem"] * n_p, n_p)
+                out["roofline"]["single_launch"] = {k: v for k, v in mfma_roofline(dom, mfma[dom]["mean_us"]).items()
+                                                    if k in ("mean_us", "frac_pipe", "frac_algorithmic", "fp32_equivalent_TFLOPs")}
             else:
-                fr = mfma[dom]["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS
-                out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["TFLOPs"], "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": fr, "frac_algorithmic": round(fr, 4), "frac_pipe": round(fr, 4),
-                                   "mfma_busy_measured": pmc_entry(dom, "fp32").get("mfma_util"),
-                                   "traffic": pmc_traffic(dom, "fp32"), "pipe": "fp32 MFMA"}
-        else:
-            dom = max(hbm, key=lambda k: hbm[k]["total_ms_per_step"])
+                out["roofline"] = mfma_roofline(dom, mfma[dom]["mean_us"])
+                if re.match(r"glowtts_conv_(gate_fwd|res_skip_fwd)", dom):
+                    out["roofline"]["as_launched_note"] = (
+                        "the timed step launches the decoder's forward as two half-batch chains on two streams (B/2 per launch, "
+                        "DESIGN.md lesson 37); this is the whole-batch launch, the quantity the instrumented pass and the "
+                        "one-stream rocprofv3 passes (profiles/) both time")
+        elif dom is not None:
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": hbm[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": hbm[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None}
+                               "unit": "GB/s", "frac": hbm[dom]["GBps"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, default_math)}
+        else:
+            out["roofline"] = {"bound": None, "kernel": None, "frac": None, "traffic": None}
+        out["roofline"]["dominant_by"] = ("arg-max of launches_per_step x mean duration over the launches the step makes "
+                                          "(`as_launched_top5`; batched families re-priced with the batched launch)")
+        out["roofline"]["as_launched_top5"] = top5
+        if wrw5_tag is not None and bt is not None:       # the batched 5-tap weight gradient stays on the line whichever kernel leads
+            n_p = bt["problems_per_launch"]
+            out["roofline"]["wrw5_batch_as_launched_in_the_step"] = dict(
+                mfma_roofline(wrw5_tag, bt["us_per_problem"] * n_p, n_p), us_per_problem=bt["us_per_problem"], note=bt["note"])
+        if default_math.endswith("+wrw"):
+            try:        # the flow block's six 1x1 weight gradients: one multi-problem launch (csrc/convwrw1.hip)
+                out["roofline"]["wrw1_multi_as_launched_in_the_step"] = wrw1_multi_time(args, dev)
+            except Exception as exc:
+                log(f"multi-problem 1x1 weight-gradient timing failed ({type(exc).__name__}: {exc})")
         try:        # coupling(k) + ActNorm + InvConv(k + 1): the two kernels the step's flow stack launches between blocks
             fused = fused_flows_time(args, dev)
         except Exception as exc:
             fused = None
             log(f"fused flow timing failed ({type(exc).__name__}: {exc})")
         if fused:
-            # the subset as the step launches it, all by HIP events: the fused pair between blocks (timed just above) plus the first
-            # block's ActNorm + InvConv and the last block's coupling on the un-fused kernels (instrumented pass of this run)
-            ends = sum(hbm[k]["mean_us"] for k in ("glowtts_actnorm_invconv_fwd", "glowtts_actnorm_invconv_bwd", "glowtts_coupling_fwd",
-                                                   "glowtts_coupling_bwd") if k in hbm)
+            # the subset as the step launches it, all by HIP events: the boundary launch (forward) and the fused backward kernel
+            # between blocks (timed just above) plus the first block's ActNorm + InvConv and the last block's coupling on the
+            # un-fused kernels (instrumented pass of this run).  The forward launch also carries two 1x1 contractions, so
+            # `survey_frac_lower_bound` under-states the subset's own fraction.
+            ends_k = ("glowtts_actnorm_invconv_fwd", "glowtts_actnorm_invconv_bwd", "glowtts_coupling_fwd", "glowtts_coupling_bwd")
+            ends = sum(hbm[k]["mean_us"] for k in ends_k if k in hbm)
             ms_l = fused["ms_per_step_fused_part"] + ends / 1e3
-            gb_l = sub_bytes / 1e9 * (8.0 * (args.blocks - 1) + 12.0) / (12.0 * args.blocks)     # 3X + 5X per pair, 12X for the two ends
+            gb_l = fused["alg_GB_fused_part"] + sum(alg[k] for k in ends_k if k in hbm) / 1e9
             fused.update({"ms_per_step": round(ms_l, 3), "alg_GB_as_launched": round(gb_l, 3),
                           "frac": round(gb_l / (ms_l * 1e-3) / HBM_PEAK_GBS, 4),
-                          "survey_frac": round(survey_gb / (ms_l * 1e-3) / HBM_PEAK_GBS, 4)})
+                          "survey_frac_lower_bound": round(survey_gb / (ms_l * 1e-3) / HBM_PEAK_GBS, 4)})
         out["roofline"].update({
             "conv_math": default_math,
             "mfma_contractions": {"ms_per_step": round(conv_ms, 3), "alg_TFLOP_per_step": round(conv_flop / 1e3, 3),
@@ -860,14 +983,20 @@ def main():
                                   "survey_frac": round(survey_gb / (sub_ms * 1e-3) / HBM_PEAK_GBS, 4) if sub_ms else None,
                                   # HIP events around a 6-15 us launch include its launch latency (~4 us); the committed
                                   # rocprofv3 kernel trace of this same command times the kernels themselves
-                                  "rocprofv3": subset_from_kernel_trace(sub_bytes, survey_gb, args.blocks),
-                                  "fused_as_launched_in_the_step": fused},
+                                  "rocprofv3": subset_from_kernel_trace(4.0 * C * B * Ts, survey_gb, args.blocks),
+                                  "what_these_are": "ms_per_step / frac / survey_frac: the UN-FUSED kernels of the instrumented pass "
+                                                    "(one launch per flow); `as_launched_in_the_step`: what the timed step launches",
+                                  "as_launched_in_the_step": fused},
             "step_ms": round(ms_per_step, 3),
             "decoder": dec,
             "mfma_kernels": dict(sorted(mfma.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "hbm_kernels": dict(sorted(hbm.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
             "other_kernels": dict(sorted(other.items(), key=lambda kv: -kv[1]["total_ms_per_step"])),
         })
+
+    # ---- the other single-GPU BASELINE configurations, a few steps each (orientation beside `value`, timed by the same driver run)
+    if rank == 0 and world == 1 and mode == "eager" and not args.no_other_configs and reducer is None and which == "BASELINE configs[1]":
+        out["other_configs"] = other_configs_leg(args, dev)
 
     # ---- CPU baseline leg: the oracle (a port of the reference path) on this host's cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

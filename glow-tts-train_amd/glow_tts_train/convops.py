@@ -67,9 +67,10 @@ def remove_grad_ready_listener(fn) -> None:
 
 
 def _notify(params) -> None:
+    """The gradients of `params` are complete on the current stream.  A listener is called ONCE per group with the list (a flow
+    block announces 56 tensors at a time: one call, not 56, on the backward thread)."""
     for fn in _grad_ready_listeners:
-        for p in params:
-            fn(p)
+        fn(params)
 
 
 def _rows_ok(x: torch.Tensor) -> bool:
@@ -561,6 +562,11 @@ class StackArena:
         keys = tuple(WNPackPlan.make_key(cp) for cp in conv_params)
         if keys != self.keys or any(p.shared is not self for p in plans):
             sizes = [WNPackPlan.arena_floats(cp, n_convs) for cp in conv_params]
+            if getattr(self, "arena", None) is not None and self.arena.is_cuda and not torch.cuda.is_current_stream_capturing():
+                # a REBUILD (a parameter moved: rare) drops the old packed buffer and planes, which kernels queued on the forward
+                # chains' and the weight-gradient streams may still read and whose addresses the cached tables hold: wait for the
+                # device once before the allocator may hand that memory out again
+                torch.cuda.synchronize(self.arena.device)
             self.arena = torch.zeros(sum(sizes), device=conv_params[0][0].device, dtype=torch.float32)
             self.planes = None
             off, rows = 0, [0]

@@ -32,24 +32,32 @@ class LayerNorm(nn.Module):
 
     def __init__(self, channels, eps=1e-4):
         super().__init__()
-        if channels > self.MAX_CHANNELS:
-            raise ValueError(f"LayerNorm: {channels} channels exceed the {self.MAX_CHANNELS} the register-resident kernels of this "
-                             "build take (hidden_channels / filter_channels_dp)")
-        self.channels, self.eps = channels, eps
+        self.channels, self.eps = channels, eps      # any width builds and loads (checkpoints of wider models, CPU construction)
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
 
     def forward(self, x, res=None, relu_in=False, relu_out=False, p_drop=0.0, site="ln"):
         """LayerNorm over channels of x (+ res: the residual add that precedes every norm in the encoder is fused in).
         relu_in / relu_out / p_drop: the ReLU before and the ReLU / dropout after the norm, inside its kernels (3-D input);
-        `site` names the dropout's keep-mask (ops.keep_mask).  relu_in with a residual input is not supported (raises)."""
-        if x.dim() == 3:                               # (a CPU tensor raises in the operator: no fallback)
+        `site` names the dropout's keep-mask (ops.keep_mask).  relu_in with a residual input is not supported (raises).
+        (B, C, T) tensors of up to MAX_CHANNELS channels run on the register-resident kernels; wider norms and other ranks —
+        neither occurs in the reference's model — take a composition of framework operators on the same device (never the CPU)."""
+        if x.dim() == 3 and self.channels <= self.MAX_CHANNELS:      # (a CPU tensor raises in the operator: no fallback)
             return _chan_ln_apply(x, res, self.gamma, self.beta, self.eps, relu_in, relu_out, p_drop, site)
-        if relu_in or relu_out or p_drop:
-            raise RuntimeError("LayerNorm: the fused ReLU / dropout forms need a (B, C, T) tensor")
-        # other ranks: F.layer_norm normalises trailing dims: move channels last, normalise, move back
+        if relu_in and res is not None:
+            raise RuntimeError("LayerNorm: relu_in together with a residual input is not supported")
+        # F.layer_norm normalises trailing dims: move channels last, normalise, move back
         v = x if res is None else x + res
-        return F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
+        if relu_in:
+            v = F.relu(v)
+        y = F.layer_norm(v.transpose(1, -1), (self.channels,), self.gamma, self.beta, self.eps).transpose(1, -1)
+        if relu_out:
+            y = F.relu(y)
+        if p_drop:
+            from . import ops
+            keep = ops.keep_mask(tuple(y.shape), p_drop, y.device, site)
+            y = y * keep.to(y.dtype) * (1.0 / (1.0 - p_drop))
+        return y
 
 
 class ConvReluNorm(nn.Module):

@@ -21,7 +21,10 @@ data-dependent ActNorm initialisation win).
 from __future__ import annotations
 
 import contextlib
+import os
+import queue
 import re
+import threading
 import typing
 
 import torch
@@ -67,7 +70,7 @@ class FlowBlockReducer:
 
     def __init__(self, model: torch.nn.Module, optimizer, process_group=None,
                  bucket_key: typing.Callable[[str], str] = default_bucket_key, force: bool = False,
-                 measure: bool = False):
+                 measure: bool = False, comm_thread: typing.Optional[bool] = None):
         """`force`: hook the gradients and issue every bucket's collective even in a group of ONE rank (the collective is
         then the identity; it exercises the RCCL launch path, its streams and `finish()` on a single GPU).
         `measure`: record HIP events around the wait in `finish()` — `exposed_comm_ms()` is the time the compute stream
@@ -76,7 +79,13 @@ class FlowBlockReducer:
         has been waited for, `end` on the launch stream after the collective (RCCL only: the launch stream is made to wait for
         the work, which does not block the host).  ready -> start is what the collective waits for OTHER streams' queued work
         (every bucket waits on all side streams, the encoder's included), start -> end its queueing behind earlier
-        collectives plus its time on the wire."""
+        collectives plus its time on the wire.
+        `comm_thread` (default: GLOWTTS_DP_COMM_THREAD, on): the collectives are issued by a launcher thread of this reducer, not by
+        the thread whose gradient announcement completed the bucket.  That thread — autograd's backward thread, which queues the
+        whole backward — only records one event per producer stream and hands (bucket, events) over; the launcher makes the
+        collective's launch stream wait for those events and calls `all_reduce` (~50-80 us of host time per collective inside
+        the process-group machinery, which releases the interpreter lock).  Buckets are handed over and launched in the same
+        order on every rank (a FIFO; the backward's node order is the same everywhere), as the communicator requires."""
         flat = getattr(optimizer, "_optim", optimizer)
         if not hasattr(flat, "flat_g"):
             raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
@@ -92,6 +101,12 @@ class FlowBlockReducer:
         self._bucket_events: typing.List[typing.Tuple[int, bool, typing.Any, typing.Any, typing.Any]] = []
         self._in_finish = False
         self.launched_in_backward = 0          # buckets whose collective was issued before finish() in the last step
+        if comm_thread is None:
+            comm_thread = os.environ.get("GLOWTTS_DP_COMM_THREAD", "1") != "0"
+        self._thread_mode = bool(comm_thread) and self._active and flat.flat_g.is_cuda
+        self._q: typing.Optional[queue.SimpleQueue] = None
+        self._thr: typing.Optional[threading.Thread] = None
+        self._thr_error: typing.Optional[BaseException] = None
         named = list(model.named_parameters())
         by_id = {id(p): (o, p.numel()) for p, o in zip(flat._params, flat.offsets)}
         self.buckets: typing.List[Bucket] = []
@@ -130,6 +145,10 @@ class FlowBlockReducer:
                     self._hook_of[id(p)] = h
             # gradients the conv operators write straight into .grad are announced by the operators themselves
             convops.add_grad_ready_listener(self._on_announce)
+            if self._thread_mode:
+                self._q = queue.SimpleQueue()
+                self._thr = threading.Thread(target=self._comm_loop, args=(flat.flat_g.device,), name="glowtts-dp-comm", daemon=True)
+                self._thr.start()
 
     # -- collectives ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -137,9 +156,62 @@ class FlowBlockReducer:
         if self._active:
             dist.broadcast(self.flat.flat_p, src=src, group=self.group)
 
+    def _comm_loop(self, device):
+        """The launcher thread: for every (bucket, producer events, ...) handed over, in order, make the launch stream wait for the
+        events and issue the collective.  A `threading.Event` in the queue is a rendezvous (finish() waits for it); None ends the
+        thread."""
+        torch.cuda.set_device(device)
+        comm = _hip.side_stream(device, "comm")
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            if isinstance(item, threading.Event):
+                item.set()
+                continue
+            i, waits, ev, early = item
+            try:
+                b = self.buckets[i]
+                view = self.flat.flat_g[b.lo:b.hi]
+                with torch.cuda.stream(comm):
+                    for e in waits:
+                        comm.wait_event(e)
+                    if ev is not None:
+                        ev[1].record(comm)
+                    if self._use_avg:
+                        work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                    else:
+                        view.div_(self.world)
+                        work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    if self.backend == "nccl":
+                        work.wait()                  # the LAUNCH stream waits for the collective (no host block): `end` is its end
+                    if ev is not None:
+                        ev[2].record(comm)
+                        self._bucket_events.append((i, early, *ev))
+                        self._trim_events()
+                self._works.append(work)
+            except BaseException as exc:               # surfaced by finish() on the training thread
+                self._thr_error = exc
+
     def _launch(self, i: int):
         b = self.buckets[i]
         view = self.flat.flat_g[b.lo:b.hi]
+        if self._thread_mode:
+            dev = view.device
+            comm = _hip.side_stream(dev, "comm")
+            cur = torch.cuda.current_stream(dev)
+            ev = None
+            if self._measure:
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                ev[0].record(cur)
+            waits = []
+            for s in [cur] + [s for s in _hip.all_side_streams(dev) if s is not comm and s is not cur]:
+                e = torch.cuda.Event()
+                e.record(s)
+                waits.append(e)
+            self._q.put((i, waits, ev, not self._in_finish))
+            self._launched[i] = True
+            return
         if view.is_cuda:
             # A bucket's gradients come from several streams (dx chain, weight-gradient stream, encoder stream) and the
             # announcement that completes it arrives in the context of only ONE of them.  The collective is therefore issued
@@ -165,13 +237,24 @@ class FlowBlockReducer:
             else:
                 view.div_(self.world)
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.backend == "nccl" and view.is_cuda:
+                work.wait()                          # the LAUNCH stream waits for the collective (no host block; the same with and
+                                                     # without `measure`): `end` is its end
             if ev is not None:
-                if self.backend == "nccl":
-                    work.wait()                      # the LAUNCH stream waits for the collective (no host block): `end` is its end
                 ev[2].record(comm)
                 self._bucket_events.append((i, not self._in_finish, *ev))
+                self._trim_events()
         self._works.append(work)
         self._launched[i] = True
+
+    def _trim_events(self, keep_steps: int = 64):
+        """`measure=True` keeps the timing events of the last `keep_steps` steps only: a long run that never reads
+        `bucket_timings()` must not grow without bound."""
+        cap = keep_steps * len(self.buckets)
+        if len(self._bucket_events) > 2 * cap:
+            del self._bucket_events[:-cap]
+        if len(self._exposed) > 2 * keep_steps:
+            del self._exposed[:-keep_steps]
 
     def _on_hook(self, p: torch.Tensor):
         # AccumulateGrad hooks also fire for parameters whose gradient an operator writes in place (it hands autograd None),
@@ -181,9 +264,22 @@ class FlowBlockReducer:
             return
         self._on_grad(p)
 
-    def _on_announce(self, p: torch.Tensor):
-        self._announced.add(id(p))
-        self._on_grad(p)
+    def _on_announce(self, params):
+        """convops._notify: the gradients of `params` (a list) are complete on the current stream."""
+        bucket_of, seen, pending = self._bucket_of, self._seen, self._pending
+        ready = []
+        for p in params:
+            pid = id(p)
+            self._announced.add(pid)
+            i = bucket_of.get(pid)
+            if i is None or pid in seen:
+                continue
+            seen.add(pid)
+            pending[i] -= 1
+            if pending[i] == 0 and not self._launched[i]:
+                ready.append(i)
+        for i in ready:
+            self._launch(i)
 
     def _on_grad(self, p: torch.Tensor):
         if id(p) not in self._bucket_of or id(p) in self._seen:
@@ -204,6 +300,13 @@ class FlowBlockReducer:
                 if not self._launched[i]:
                     self._launch(i)
             self._in_finish = False
+            if self._thread_mode:                        # every bucket handed over so far has been launched once this returns
+                done = threading.Event()
+                self._q.put(done)
+                done.wait()
+                if self._thr_error is not None:
+                    exc, self._thr_error = self._thr_error, None
+                    raise RuntimeError("FlowBlockReducer: the collective launcher thread failed") from exc
             cuda = self.flat.flat_g.is_cuda
             if cuda and self._measure:
                 cur = torch.cuda.current_stream(self.flat.flat_g.device)
@@ -266,3 +369,7 @@ class FlowBlockReducer:
             h.remove()
         self._hooks.clear()
         convops.remove_grad_ready_listener(self._on_announce)
+        if self._thr is not None:
+            self._q.put(None)
+            self._thr.join(timeout=10)
+            self._thr, self._thread_mode = None, False

@@ -8,6 +8,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def source_digest():
+    """sha1 of the kernel sources (glow-tts-train_amd/csrc/*.hip, *.hpp) with comments and white space removed: what a
+    measurement file (parity margins) was taken on.  Comment-only edits do not change it; any code edit does."""
+    import hashlib
+    import re
+
+    csrc = os.path.join(ROOT, "glow-tts-train_amd", "csrc")
+    h = hashlib.sha1()
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".hpp")):
+            text = open(os.path.join(csrc, fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            h.update(fn.encode())
+            h.update(re.sub(r"\s+", "", text).encode())
+    return h.hexdigest()[:16]
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: d[k] for k in d.files}

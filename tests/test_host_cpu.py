@@ -514,6 +514,68 @@ def test_tuning_switches_are_latched_listed_and_settable():
     assert "glowtts_set_knob" in integration
 
 
+def test_bench_pmc_keys_exist_in_the_newest_profiles():
+    """the bench line's counter fields must be re-derivable from profiles/.  Every kernel key bench.py looks
+    up (`_PMC_KERNEL`) is a key of the NEWEST profiles/rNN_pmc.json, its kernel name a row of the kernel trace of the SAME round,
+    and the recorded HBM-side traffic at least 0.9 x the launch's algorithmic bytes (a record far below them belongs to another
+    kernel — round 4's driver line carried round 1's).  A kernel renamed without a fresh counter pass fails here."""
+    import csv
+    import json
+
+    import bench
+
+    pmc_path, stats_path = bench.newest_profile("_pmc.json"), bench.newest_profile("_kernel_stats.csv")
+    assert pmc_path and stats_path
+    assert os.path.basename(pmc_path)[:3] == os.path.basename(stats_path)[:3], "counter passes and kernel trace of one round"
+    table = json.load(open(pmc_path))
+    stat_names = [r["Name"].replace(" ", "") for r in csv.DictReader(open(stats_path))]
+    B, T, H, C = 32, 400, 192, 160
+    other_bytes = {"glowtts_flow_boundary_fwd": 4.0 * B * T * (2 * H + 3 * C), "glowtts_coupling_actnorm_invconv_bwd": 5 * 4.0 * B * C * T}
+    assert len(bench._PMC_KERNEL) >= 4
+    for (tag, math), key in bench._PMC_KERNEL.items():
+        assert key in table, f"{tag}: {key!r} is not a key of {os.path.basename(pmc_path)}"
+        name = key.split(" grid=")[0]
+        assert any("glowtts::" + name + "(" in n or "glowtts::" + name + "<" in n for n in stat_names), f"{name} not in {os.path.basename(stats_path)}"
+        m = re.match(r"(glowtts_conv\w*)\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", tag)
+        if m:
+            alg = bench.conv_algorithmic_bytes(m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)),
+                                               int(m.group(5)) * int(m.group(6)), H)
+            alg *= bench._PMC_PROBLEMS_PER_LAUNCH.get(tag, 1)
+        else:
+            alg = other_bytes[tag]
+        traffic = table[key]["traffic_bytes"]
+        assert traffic >= 0.9 * alg, f"{tag}: {traffic / 1e6:.1f} MB of counter traffic for {alg / 1e6:.1f} MB algorithmic"
+        assert bench.pmc_entry(tag, math)["pmc_key"] == key and bench.pmc_traffic(tag, math) == traffic
+    # a tag without a record gives null, not another kernel's bytes
+    assert bench.pmc_traffic("glowtts_conv_wrw[M384 K192x5 N32x400]", "fp32") is None
+    assert bench.pmc_entry("glowtts_no_such_kernel") == {}
+
+
+def test_committed_parity_margins_belong_to_this_code():
+    """the committed parity margins (profiles/rNN_parity_margins.json, written on the MI355X by
+    tests/test_full_size_parity.py) carry the digest of the kernel sources they were measured on; it must be the digest of the
+    sources in this tree, every whole-step case of both arithmetics must be there, and none may sit above the margin the GPU test
+    enforces."""
+    import json
+
+    import bench
+    from helpers import source_digest
+
+    path = bench.newest_profile("_parity_margins.json")
+    assert path, "no profiles/rNN_parity_margins.json"
+    data = json.load(open(path))
+    if "source_digest" not in data:
+        pytest.skip(f"{os.path.basename(path)} predates the digest (round 4's file): re-run the full-size tests on the GPU box")
+    assert data["source_digest"] == source_digest(), (
+        f"{os.path.basename(path)} was measured on other kernel sources ({data['source_digest']} != {source_digest()}): run "
+        "tests/test_full_size_parity.py on the GPU box and commit gpurun_out/parity_margins.json as the new profiles/ copy")
+    for case in ("train_step_config2", "train_step_config2_dropout", "train_step_config2_dropout_onechain", "train_step_config5",
+                 "train_step_config5_dropout"):
+        for arith in ("fp32", "bf16x6+wrw"):
+            f = data[case][arith]
+            assert f["worst_grad_err_over_tol"] <= 0.5 and f["loss_err_over_tol"] <= 1.0, (case, arith, f)
+
+
 def test_fastcall_binding_matches_the_ctypes_table():
     """`_glowtts_fastcall` (generated by csrc/gen_fastcall.py, built by `make`) wraps exactly the entry points of
     `_hip._SIGNATURES`, is bound to the addresses of the library ctypes opened, validates its arguments, and `call()` uses

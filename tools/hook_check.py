@@ -9,7 +9,7 @@ for n, p in blk.named_parameters():
     p.grad = torch.zeros_like(p)
     p.register_post_accumulate_grad_hook(lambda p_, n=n: fired.append(n))
 notified = []
-convops.add_grad_ready_listener(lambda p: notified.append(id(p)))
+convops.add_grad_ready_listener(lambda ps: notified.extend(id(p) for p in ps))
 x = torch.randn(2, 32, 40, device="cuda", requires_grad=True)
 z, ld = blk(x, torch.ones(2, 1, 40, device="cuda"))
 (z.sum() + ld.sum()).backward()

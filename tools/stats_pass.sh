@@ -9,6 +9,6 @@ export TMPDIR=/tmp GLOWTTS_SIDE_STREAM=0
 cd /tmp
 D=/tmp/stats_${TAG}
 rm -rf "$D"
-rocprofv3 --kernel-trace --stats -d "$D" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --steps $STEPS --warmup 3 > "$ROOT/gpurun_out/${TAG}_trace.bench.json" 2> "$ROOT/gpurun_out/${TAG}_trace.err"
+rocprofv3 --kernel-trace --stats -d "$D" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --no-other-configs --steps $STEPS --warmup 3 > "$ROOT/gpurun_out/${TAG}_trace.bench.json" 2> "$ROOT/gpurun_out/${TAG}_trace.err"
 DB=$(find "$D" -name '*.db' | head -1)
 python3 "$ROOT/tools/rocpd_summary.py" kernels "$DB" "$ROOT/gpurun_out/${TAG}_kernel_stats.csv"

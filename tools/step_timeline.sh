@@ -7,7 +7,7 @@ set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --steps 4 --warmup 3 ${BENCH_EXTRA:-} > "$ROOT/gpurun_out/step_timeline.bench.json" 2> "$ROOT/gpurun_out/step_timeline.err"
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-split-math --no-roofline --no-other-configs --steps 4 --warmup 3 ${BENCH_EXTRA:-} > "$ROOT/gpurun_out/step_timeline.bench.json" 2> "$ROOT/gpurun_out/step_timeline.err"
 F=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
 python3 - "$F" > "$ROOT/gpurun_out/step_timeline.txt" <<'PY'
 import csv, re, sys
