@@ -334,6 +334,279 @@ __global__ __launch_bounds__(256) void mas_kernel(const float *__restrict__ valu
     MAS_TRACE(4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the dynamic programme on UP TO FOUR waves.  The single DP wave above spends ~200 cycles per lattice
+// column whatever it does (a lone wave issues a vector instruction every ~10 cycles; 5 instructions per row and column, three
+// rows per lane at 160 tokens) and three waves only feed it.  Here
+//   * the ROWS are split over the waves: global lane L = 64 w + lane owns rows L R .. L R + R - 1 (R = 1 up to 256 tokens), so a
+//     column costs a wave 2 + 5 R vector instructions instead of 1 + 5 ceil(Tx / 64);
+//   * the recurrence needs v[x - 1][y - 1] across the wave boundary: wave w runs ONE 16-column slab behind wave w - 1 (a skewed
+//     pipeline over slabs, one workgroup barrier per step: ceil(ty / 16) + waves - 1 steps), and after every column each wave
+//     leaves its lanes' running values in an LDS ring (64 columns deep) from which its successor takes lane 63's — all 16 of a
+//     slab with one burst of broadcast reads;
+//   * nothing is staged: a lane reads the 16 cells of its own row straight from `value` (four 16-byte loads per slab and row,
+//     the next slab's in flight while this one is worked on) — the transposing LDS image and the staging waves are gone;
+//   * only in-band cells are ever read back (see the kernel above), so rows above the diagonal and ring slots never written
+//     may hold anything;
+//   * the 0/1 path is NOT written here when the caller wants the spans: mas_path_from_spans_kernel expands them on the whole
+//     chip (one utterance's 512 KB took its single workgroup ~20 us), on a stream of the caller's choice.
+// Same arithmetic per cell (select, compare, max, add: bit-exact with the reference), same 1-bit back-pointers, same backtrack.
+template <int R>
+__global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__ value, float *__restrict__ path,
+                                                       const int *__restrict__ t_xs, const int *__restrict__ t_ys,
+                                                       int Tx, int Ty, int nblk32, int nw,
+                                                       int *__restrict__ first_out, int *__restrict__ tok_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int D = 16, LW = 256;
+    uint32_t *dirs = reinterpret_cast<uint32_t *>(smem);                         // [R][nblk32][LW]
+    float *ring = reinterpret_cast<float *>(dirs + R * nblk32 * LW);             // [4 waves][64 columns][64 lanes]
+    int *first = reinterpret_cast<int *>(ring + 4 * 64 * 64);                    // [Tx + 1]
+
+    const int b = blockIdx.x;
+    int tx = t_xs[b], ty = t_ys[b];
+    tx = tx < 0 ? 0 : (tx > Tx ? Tx : tx);
+    ty = ty < 0 ? 0 : (ty > Ty ? Ty : ty);
+    const float *val = value + (size_t)b * Tx * Ty;
+    const int L = threadIdx.x, lane = L & 63;
+    // the wave index as a SCALAR: everything derived from it (the wave's slab, the `whole slab inside the utterance` test) then
+    // branches on the scalar unit instead of becoming per-column exec-mask sequences (DESIGN.md lesson 32b)
+    const int w = __builtin_amdgcn_readfirstlane(L >> 6);
+    const int nslab = (tx > 0 && ty > 0) ? (ty + D - 1) / D : 0;
+
+    float v[R];
+    uint32_t dw[R];
+    const float *rowp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        v[r] = 0.0f;
+        dw[r] = 0u;
+        int x = L * R + r;
+        x = x < Tx ? x : Tx - 1;                   // rows past the lattice read the last row: out of band, never read back
+        rowp[r] = val + (size_t)x * Ty;
+    }
+    float4 ca[R][4], cb[R][4];
+    auto load = [&](float4 (&c)[R][4], int s) {
+        const int y0 = s * D;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                c[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (y0 + 4 * q < Ty) c[r][q] = *reinterpret_cast<const float4 *>(rowp[r] + y0 + 4 * q);      // (Ty % 4 == 0)
+            }
+    };
+    auto flush = [&](int y) {                      // after column y: store the rows' words of its 32-column block
+        const int sh = 31 - (y & 31), blk = y >> 5;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t wd = __brev(dw[r] << sh);     // column 32 blk + j of the word in bit j
+            const int x = L * R + r;
+            if ((x >> 5) == blk) wd |= 1u << (x & 31);      // x == y: the path must step (bits past y are never read)
+            dirs[(r * nblk32 + blk) * LW + L] = wd;
+            dw[r] = 0u;
+        }
+    };
+    auto column = [&](const float (&cells)[R], const unsigned long long (&dg)[R], float edge) {
+        float vp[R], vc[R], best[R];
+        vp[0] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v[R - 1]), 0x138, 0xf, 0xf, false));
+#pragma unroll
+        for (int r = 1; r < R; ++r) vp[r] = v[r - 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vc[r]) : "v"(v[r]), "v"(kMasNeg), "s"(dg[r]));
+        unsigned long long take[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) take[r] = __builtin_amdgcn_fcmpf(vp[r], vc[r], 2);      // vprev > vcur
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("v_max_f32 %0, %1, %2" : "=v"(best[r]) : "v"(vp[r]), "v"(vc[r]));
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = best[r] + cells[r];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            unsigned long long carry_out;
+            asm volatile("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(dw[r]), "=s"(carry_out) : "v"(dw[r]), "s"(take[r]));
+        }
+    };
+    float *my_ring = ring + w * 64 * 64 + lane;      // (the last wave's ring is never read: an unconditional store beats a branch per column)
+    const float *prev_ring = ring + (w > 0 ? w - 1 : 0) * 64 * 64 + 63;
+    auto slab = [&](const float4 (&c)[R][4], int s) {
+        const int y0 = s * D;
+        float bnd[D];                              // v[64 w R - 1][y - 1] for the slab's columns (wave 0: the sentinels of core.pyx:24-27)
+        if (w > 0) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) bnd[u] = prev_ring[((y0 + u) & 63) * 64];
+        } else {
+#pragma unroll
+            for (int u = 0; u < D; ++u) bnd[u] = kMasNeg;
+            if (s == 0) bnd[0] = 0.0f;
+        }
+        float *rb = my_ring + (y0 & 63) * 64;      // columns y0 + 1 .. y0 + 15 of the ring: immediate offsets; y0 + 16 may wrap
+        if (y0 + D <= ty) {                        // the whole slab lies inside the utterance: no per-column test
+#pragma unroll
+            for (int g = 0; g < D / 4; ++g) {
+                unsigned long long dg[4][R];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        dg[u][r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)(y0 + 4 * g + u), 32);    // x == y
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float cells[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
+                    column(cells, dg[u], bnd[4 * g + u]);
+                    if (4 * g + u < D - 1) rb[(4 * g + u + 1) * 64] = v[R - 1];
+                    else my_ring[((y0 + D) & 63) * 64] = v[R - 1];
+                }
+            }
+            const int y = y0 + D - 1;              // (y0 is a multiple of 16: only the slab's last column can end a block)
+            if ((y & 31) == 31 || y == ty - 1) flush(y);
+        } else {                                   // the utterance's last, partial slab
+#pragma unroll
+            for (int g = 0; g < D / 4; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int y = y0 + 4 * g + u;
+                    if (y < ty) {
+                        unsigned long long dg[R];
+                        float cells[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            dg[r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)y, 32);
+                            cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
+                        }
+                        column(cells, dg, bnd[4 * g + u]);
+                        my_ring[((y + 1) & 63) * 64] = v[R - 1];
+                        if ((y & 31) == 31 || y == ty - 1) flush(y);
+                    }
+                }
+        }
+    };
+
+    if (w < nw && nslab > 0) load(ca, 0);
+    for (int t = 0; t < nslab + nw - 1; ++t) {
+        const int s = t - w;
+        if (w < nw && s >= 0 && s < nslab) {
+            if (s & 1) {
+                if (s + 1 < nslab) load(ca, s + 1);
+                slab(cb, s);
+            } else {
+                if (s + 1 < nslab) load(cb, s + 1);
+                slab(ca, s);
+            }
+        }
+        __syncthreads();                           // ring slots and direction words of this step are visible to the next
+    }
+
+    // ---- backtrack: as in mas_kernel (one lane's walk, state in scalar registers) over the [R][nblk32][256] word image
+    for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = x >= tx ? ty : 0;
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && tx > 0 && ty > 0) {
+        auto word_of = [&](int row, int blk) -> uint32_t {
+            if (row <= 0) return 0u;
+            const uint32_t wd = dirs[((row % R) * nblk32 + blk) * LW + row / R];
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)wd);
+        };
+        int index = tx - 1, y = ty - 1, blk = y >> 5;
+        uint32_t word = word_of(index, blk), below = word_of(index - 1, blk);
+        while (index > 0 && y > 0) {
+            uint32_t m = word & (0xffffffffu >> (31 - (y & 31)));
+            if (blk == 0) m &= ~1u;
+            if (m == 0) {
+                if (blk == 0) break;
+                y = (blk << 5) - 1;
+                --blk;
+                word = word_of(index, blk);
+                below = word_of(index - 1, blk);
+                continue;
+            }
+            y = (blk << 5) + (31 - __clz(m));
+            first[index] = y;
+            --index;
+            --y;
+            word = below;
+            if ((y >> 5) != blk) {
+                blk = y >> 5;
+                word = word_of(index, blk);
+            }
+            below = word_of(index - 1, blk);
+        }
+    }
+    __syncthreads();
+
+    if (first_out != nullptr)
+        for (int x = threadIdx.x; x <= Tx; x += 256) first_out[(size_t)b * (Tx + 1) + x] = first[x];
+    if (tok_out != nullptr) {                      // frame -> token: every text row writes its span, frames past the utterance -1
+        for (int y = ty + (int)threadIdx.x; y < Ty; y += 256) tok_out[(size_t)b * Ty + y] = -1;
+        for (int x = threadIdx.x; x < tx; x += 256) {
+            const int lo = first[x], hi = first[x + 1];
+            for (int y = lo; y < hi; ++y) tok_out[(size_t)b * Ty + y] = x;
+        }
+    }
+    if (path != nullptr) {                         // (callers without a span table: the path from this workgroup, 16-byte stores)
+        float *pb = path + (size_t)b * Tx * Ty;
+        const int ty4 = Ty >> 2;
+        for (int q = threadIdx.x; q < ty4; q += 256) {
+            const int y = q << 2;
+            float4 *dst = reinterpret_cast<float4 *>(pb) + q;
+            int lo = first[0];
+#pragma unroll 4
+            for (int x = 0; x < Tx; ++x) {
+                const int hi = first[x + 1];
+                dst[(size_t)x * ty4] = make_float4((y + 0 >= lo && y + 0 < hi) ? 1.0f : 0.0f, (y + 1 >= lo && y + 1 < hi) ? 1.0f : 0.0f,
+                                                   (y + 2 >= lo && y + 2 < hi) ? 1.0f : 0.0f, (y + 3 >= lo && y + 3 < hi) ? 1.0f : 0.0f);
+                lo = hi;
+            }
+        }
+    }
+}
+
+// path[b][x][y] = 1 for first[b][x] <= y < first[b][x + 1], else 0: a workgroup writes 8 text rows of one utterance with 16-byte
+// stores (Ty % 4 == 0, 16-byte aligned path)
+__global__ __launch_bounds__(256) void mas_path_from_spans_kernel(const int *__restrict__ first, float *__restrict__ path, int Tx, int Ty) {
+    constexpr int RW = 8;
+    __shared__ int span[RW + 1];
+    const int b = blockIdx.y, x0 = blockIdx.x * RW;
+    if (threadIdx.x <= RW) span[threadIdx.x] = first[(size_t)b * (Tx + 1) + min(x0 + (int)threadIdx.x, Tx)];
+    __syncthreads();
+    const int ty4 = Ty >> 2;
+    const int rows = min(RW, Tx - x0);
+    float4 *dst = reinterpret_cast<float4 *>(path + ((size_t)b * Tx + x0) * Ty);
+    for (int i = threadIdx.x; i < rows * ty4; i += 256) {
+        const int r = i / ty4, y = (i - r * ty4) << 2;
+        const int lo = span[r], hi = span[r + 1];
+        dst[i] = make_float4((y + 0 >= lo && y + 0 < hi) ? 1.0f : 0.0f, (y + 1 >= lo && y + 1 < hi) ? 1.0f : 0.0f,
+                             (y + 2 >= lo && y + 2 < hi) ? 1.0f : 0.0f, (y + 3 >= lo && y + 3 < hi) ? 1.0f : 0.0f);
+    }
+}
+
+// LDS the multi-wave kernel needs for a (Tx, Ty) lattice with R rows per lane; 0 = not eligible (shape / size)
+static size_t mas_wave_lds(int Tx, int Ty, int R) {
+    if (Tx < 1 || Ty < 4 || (Ty & 3) != 0 || Tx > 256 * R) return 0;
+    const size_t nblk32 = (size_t)(Ty + 31) / 32;
+    const size_t bytes = (size_t)R * nblk32 * 256 * 4 + 4 * 64 * 64 * 4 + (((size_t)(Tx + 1) * 4 + 15) & ~(size_t)15);
+    return bytes <= 150 * 1024 ? bytes : 0;
+}
+static int mas_wave_rows(int Tx, int Ty) {          // rows per lane of the multi-wave kernel, 0 = use mas_kernel
+    if (knob(K_MAS_WAVES) == 0) return 0;
+    for (int R = 1; R <= 2; ++R)
+        if (mas_wave_lds(Tx, Ty, R)) return R;
+    return 0;
+}
+
+template <int R>
+static int launch_mas_wave(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B, int Tx, int Ty,
+                           int *first_out, int *tok_out, hipStream_t stream) {
+    const size_t bytes = mas_wave_lds(Tx, Ty, R);
+    const int nw = (Tx + 64 * R - 1) / (64 * R);
+    static LdsLimit limit;
+    if (int rc_ = limit.ensure(reinterpret_cast<const void *>(&mas_wave_kernel<R>), bytes, "glowtts_mas_path")) return rc_;
+    hipLaunchKernelGGL((mas_wave_kernel<R>), dim3(B), dim3(256), bytes, stream, value, path, t_x, t_y, Tx, Ty, (Ty + 31) / 32, nw,
+                       first_out, tok_out);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mas_path");
+}
+
 template <int R>
 static int launch_mas(const float *value, float *path, const int32_t *t_x, const int32_t *t_y, int B, int Tx,
                       int Ty, int *first_out, int *tok_out, hipStream_t stream) {
@@ -366,16 +639,40 @@ static int launch_mas(const float *value, float *path, const int32_t *t_x, const
 
 }  // namespace glowtts
 
+extern "C" int glowtts_mas_spans_supported(int Tx, int Ty) { return glowtts::mas_wave_rows(Tx, Ty) != 0 ? 1 : 0; }
+
+extern "C" int glowtts_mas_path_from_spans(const int32_t *first, float *path, int B, int Tx, int Ty, glowtts_stream_t stream) {
+    using namespace glowtts;
+    GLOWTTS_CHECK_ARG(first && path, "glowtts_mas_path_from_spans: null pointer");
+    GLOWTTS_CHECK_ARG(B >= 0 && Tx >= 0 && Ty >= 0 && (Ty & 3) == 0 && aligned16(path),
+                      "glowtts_mas_path_from_spans: needs Ty %% 4 == 0 and a 16-byte aligned path");
+    if (B == 0 || Tx == 0 || Ty == 0) return 0;
+    hipLaunchKernelGGL(mas_path_from_spans_kernel, dim3((Tx + 7) / 8, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), first, path,
+                       Tx, Ty);
+    GLOWTTS_LAUNCH_CHECK("glowtts_mas_path_from_spans");
+}
+
 extern "C" int glowtts_mas_path_spans(const float *value, float *path, int32_t *first, int32_t *tok, const int32_t *t_x,
                                       const int32_t *t_y, int B, int Tx, int Ty, glowtts_stream_t stream) {
     using namespace glowtts;
-    GLOWTTS_CHECK_ARG(value && path && t_x && t_y, "glowtts_mas_path: null pointer");
+    GLOWTTS_CHECK_ARG(value && t_x && t_y, "glowtts_mas_path: null pointer");
     GLOWTTS_CHECK_ARG(B >= 0 && Tx >= 0 && Ty >= 0, "glowtts_mas_path: negative size");
     if (B == 0 || Tx == 0 || Ty == 0) return 0;
     GLOWTTS_CHECK_ARG(Tx <= 2048, "glowtts_mas_path: Tx=%d exceeds the 2048-token limit of this build", Tx);
     GLOWTTS_CHECK_ARG((long)Tx * Ty < (1L << 31), "glowtts_mas_path: lattice too large");
     GLOWTTS_CHECK_ARG(!tok || (Ty & 3) != 0 || aligned16(tok), "glowtts_mas_path: tok must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // the multi-wave search (mas_wave_kernel): spans from the search, the path from the spans on the whole chip
+    const int rw = (aligned16(value) && (path == nullptr || aligned16(path))) ? mas_wave_rows(Tx, Ty) : 0;
+    GLOWTTS_CHECK_ARG(path != nullptr || (first != nullptr && rw != 0),
+                      "glowtts_mas_path_spans: path may be NULL only with a span table and a lattice glowtts_mas_spans_supported() accepts");
+    if (rw != 0) {
+        float *in_kernel = first ? nullptr : path;      // no span table to expand from: the search's workgroups write the path
+        const int rc = rw == 1 ? launch_mas_wave<1>(value, in_kernel, t_x, t_y, B, Tx, Ty, first, tok, s)
+                               : launch_mas_wave<2>(value, in_kernel, t_x, t_y, B, Tx, Ty, first, tok, s);
+        if (rc != 0 || first == nullptr || path == nullptr) return rc;
+        return glowtts_mas_path_from_spans(first, path, B, Tx, Ty, stream);
+    }
     const int r = (Tx + 63) / 64;
 #define GLOWTTS_MAS(R) return launch_mas<R>(value, path, t_x, t_y, B, Tx, Ty, first, tok, s)
     switch (r) {

@@ -26,6 +26,7 @@ _F = ctypes.c_float
 _SIGNATURES = {
     "glowtts_mas_path": [_P, _P, _P, _P, _I, _I, _I],
     "glowtts_mas_path_spans": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "glowtts_mas_path_from_spans": [_P, _P, _I, _I, _I],
     "glowtts_align_logp": [_P, _P, _P, _P, _I, _I, _I, _I],
     "glowtts_align_expand_fwd": [_P, _P, _P, _I, _I, _I, _I],
     "glowtts_align_expand_bwd": [_P, _P, _P, _I, _I, _I, _I],
@@ -158,7 +159,7 @@ class EncLayer(ctypes.Structure):
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
                            "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused",
-                           "glowtts_set_knob", "glowtts_get_knob"])
+                           "glowtts_set_knob", "glowtts_get_knob", "glowtts_mas_spans_supported"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -191,6 +192,8 @@ def load() -> ctypes.CDLL:
     lib.glowtts_conv_math.argtypes = [_I]
     lib.glowtts_wn_fused.restype = _I
     lib.glowtts_wn_fused.argtypes = [_I]
+    lib.glowtts_mas_spans_supported.restype = _I
+    lib.glowtts_mas_spans_supported.argtypes = [_I, _I]
     lib.glowtts_set_knob.restype = _I
     lib.glowtts_set_knob.argtypes = [ctypes.c_char_p, _I]
     lib.glowtts_get_knob.restype = _I

@@ -496,14 +496,28 @@ def mas_path(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -> torch
 
 
 def mas_path_spans(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor):
-    """The search plus its by-products: (path (B,Tx,Ty) 0/1 fp32, first (B,Tx+1) int32, tok (B,Ty) int32)."""
+    """The search plus its by-products: (path (B,Tx,Ty) 0/1 fp32, first (B,Tx+1) int32, tok (B,Ty) int32).
+    Where the multi-wave search takes the lattice (`glowtts_mas_spans_supported`) the kernel hands out the spans only and the
+    path is expanded from them by a second launch — inside a training step (`_hip.side_stream_enabled()`: the step joins its
+    side streams before the optimizer) on the text encoder's stream, off the serial stretch between forward and backward:
+    nothing in the step reads the path, the reference returns it (models.py:394-399)."""
     value = f32(_c(value.detach()))
     B, Tx, Ty = value.shape
+    dev = value.device
     path = torch.empty_like(value)
-    first = torch.empty(B, Tx + 1, device=value.device, dtype=torch.int32)
-    tok = torch.empty(B, Ty, device=value.device, dtype=torch.int32)
-    t_x = t_x.to(device=value.device, dtype=torch.int32).contiguous()
-    t_y = t_y.to(device=value.device, dtype=torch.int32).contiguous()
+    first = torch.empty(B, Tx + 1, device=dev, dtype=torch.int32)
+    tok = torch.empty(B, Ty, device=dev, dtype=torch.int32)
+    t_x = t_x.to(device=dev, dtype=torch.int32).contiguous()
+    t_y = t_y.to(device=dev, dtype=torch.int32).contiguous()
+    if B * Tx * Ty > 0 and _hip.side_stream_enabled() and _hip.load().glowtts_mas_spans_supported(Tx, Ty):
+        call("glowtts_mas_path_spans", ptr(value), None, ptr(first), ptr(tok), ptr(t_x), ptr(t_y), B, Tx, Ty)
+        cur = torch.cuda.current_stream(dev)
+        side = _hip.side_stream(dev, "encoder")
+        side.wait_stream(cur)
+        _hip.call_on(side.cuda_stream, "glowtts_mas_path_from_spans", ptr(first), ptr(path), B, Tx, Ty)
+        for t in (first, path):
+            t.record_stream(side)
+        return path, first, tok
     call("glowtts_mas_path_spans", ptr(value), ptr(path), ptr(first), ptr(tok), ptr(t_x), ptr(t_y), B, Tx, Ty)
     return path, first, tok
 

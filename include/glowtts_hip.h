@@ -45,6 +45,8 @@
  *                                 GLOWTTS_CONV32_1X1  [1]     0 = plain 1x1 convolutions (native fp32 kernels) on 80- / 64-frame tiles
  *                                                     instead of 32-frame tiles (csrc/convgemm.hip)
  *                                 GLOWTTS_WN_FUSED    [0]     initial value of the glowtts_wn_fused switch (csrc/wn_fused.hip)
+ *                                 GLOWTTS_MAS_WAVES   [1]     0 = the alignment search on the single-wave kernel for every lattice
+ *                                                     (csrc/mas.hip; 1: up to four DP waves where glowtts_mas_spans_supported)
  *                               Only in the tuning build (`make -C csrc trace`, -DGLOWTTS_TRACE, tools/libglowtts_trace.bin; the
  *                               shipped library contains neither the names nor the code paths), timing experiments that make
  *                               kernels SKIP work and so give WRONG results:
@@ -105,6 +107,18 @@ int glowtts_mas_path(const float *value, float *path, const int32_t *t_x, const 
  * tok (B, Ty) int32: the text row of every frame, -1 for frames >= t_y. */
 int glowtts_mas_path_spans(const float *value, float *path, int32_t *first, int32_t *tok, const int32_t *t_x,
                            const int32_t *t_y, int B, int Tx, int Ty, glowtts_stream_t stream);
+/* Round 5 — the search on up to four wavefronts (csrc/mas.hip: mas_wave_kernel; core.pyx:9-35 unchanged in arithmetic): text rows
+ * split over the waves, a skewed pipeline over 16-frame slabs, cells read straight from `value`.  Lattices with
+ * glowtts_mas_spans_supported(Tx, Ty) != 0 (Ty % 4 == 0, Tx <= 512, back-pointer bits within the LDS; 16-byte aligned value / path)
+ * take it inside glowtts_mas_path / glowtts_mas_path_spans; every other lattice the single-wave kernel.  With a span table the path
+ * is not written by the search but expanded from `first` by a second launch over the whole chip:
+ *   - glowtts_mas_path_spans(..., path = NULL, first != NULL, ...) on a supported lattice runs the search alone (spans, tok);
+ *   - glowtts_mas_path_from_spans(first, path, B, Tx, Ty, stream): path[b, x, y] = 1 for first[b, x] <= y < first[b, x + 1], else 0,
+ *     on any stream ordered behind the search (the Python host: a side stream, off the step's serial stretch; Ty % 4 == 0,
+ *     16-byte aligned path).
+ * GLOWTTS_MAS_WAVES = 0 (tuning switch) keeps every lattice on the single-wave kernel. */
+int glowtts_mas_spans_supported(int Tx, int Ty);
+int glowtts_mas_path_from_spans(const int32_t *first, float *path, int B, int Tx, int Ty, glowtts_stream_t stream);
 
 /* ---- alignment-side glue of FlowGenerator.forward (csrc/align.hip; reference models.py:361-393) -------------------------
  * align_logp : logp[b, x, y] = log N(z[b, :, y]; x_m[b, :, x], exp(x_logs[b, :, x])) summed over the C channels — the

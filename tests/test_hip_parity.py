@@ -80,7 +80,17 @@ def test_library_is_the_hip_one(G):
 
 
 # =============================================================================================== MAS
-def test_mas_golden_bit_exact(G):
+@pytest.fixture(params=[1, 0], ids=["multiwave", "singlewave"])
+def mas_kernel(request, G):
+    """Both forms of the search (csrc/mas.hip): up to four DP waves where the lattice qualifies (round 5, the default) and the
+    single-wave kernel for every lattice (GLOWTTS_MAS_WAVES=0; also what every other lattice takes)."""
+    before = G.hip.get_knob("GLOWTTS_MAS_WAVES")
+    G.hip.set_knob("GLOWTTS_MAS_WAVES", request.param)
+    yield request.param
+    G.hip.set_knob("GLOWTTS_MAS_WAVES", before)
+
+
+def test_mas_golden_bit_exact(G, mas_kernel):
     g = load_golden("mas_cases")
     for i in range(int(g["n"])):
         v, tx, ty, want = g[f"value{i}"], g[f"tx{i}"], g[f"ty{i}"], g[f"path{i}"]
@@ -107,7 +117,7 @@ def test_mas_reference_wrapper_semantics(G):
                                      # beyond the former limits: > 512 tokens; bit lattice > LDS (500 x 4000:
                                      # back-pointers go through the output buffer); odd frame count on that path
                                      (2, 700, 1500), (1, 1100, 1203), (2, 500, 4000), (1, 2048, 2100)])
-def test_mas_vs_oracle_full_size(G, b, tx, ty):
+def test_mas_vs_oracle_full_size(G, mas_kernel, b, tx, ty):
     from oracle import glow_oracle as O
 
     rng = np.random.RandomState(b * 1000 + tx)
@@ -130,7 +140,7 @@ def test_mas_vs_oracle_full_size(G, b, tx, ty):
         assert ((d == 0) | (d == 1)).all() and idx[0] == 0 and idx[-1] == txs[j] - 1
 
 
-def test_mas_ties_and_quantised(G):
+def test_mas_ties_and_quantised(G, mas_kernel):
     from oracle import glow_oracle as O
 
     rng = np.random.RandomState(5)
@@ -142,6 +152,55 @@ def test_mas_ties_and_quantised(G):
     for j in range(6):
         mask[j, : txs[j], : tys[j]] = 1
     assert (got == O.mas_numpy(v * mask, txs, tys)).all()
+
+
+@pytest.mark.parametrize("b,tx,ty", [(32, 160, 800), (6, 240, 1200), (4, 64, 64), (3, 65, 132), (5, 129, 400), (2, 256, 512),
+                                     (2, 257, 640), (3, 512, 1000), (7, 1, 8), (3, 100, 20), (2, 513, 1024), (2, 100, 402)])
+def test_mas_spans_and_split_launches_vs_oracle(G, mas_kernel, b, tx, ty):
+    """glowtts_mas_path_spans in all its forms: search + path in one call; the search alone (path = NULL) with the path expanded
+    from the span table by glowtts_mas_path_from_spans (the form the training step uses, on a side stream); first / tok against the
+    oracle's path.  Lattices at the wave boundaries (64 / 65, 128 / 129, 256 / 257 rows), at the edge of what the multi-wave
+    kernel takes (512 / 513 tokens, Ty % 4 != 0), ragged lengths, t_x = 1, utterances shorter than a 16-frame slab."""
+    from oracle import glow_oracle as O
+
+    rng = np.random.RandomState(b * 77 + tx + ty)
+    v = (rng.randn(b, tx, ty) * 2).astype(np.float32)
+    txs = rng.randint(1, tx + 1, size=b).astype(np.int32)
+    tys = np.maximum(txs, rng.randint(max(1, ty // 3), ty + 1, size=b)).astype(np.int32)
+    tys = np.minimum(tys, ty)
+    txs = np.minimum(txs, tys)
+    txs[0], tys[0] = min(tx, ty), ty
+    mask = np.zeros_like(v)
+    for j in range(b):
+        mask[j, : txs[j], : tys[j]] = 1
+    want = O.mas_numpy(v * mask, txs, tys).astype(np.float32)
+    vd, txd, tyd = dev(v), dev(txs), dev(tys)
+    path, first, tok = G.ops.mas_path_spans(vd, txd, tyd)
+    torch.cuda.synchronize()
+    assert (path.cpu().numpy() == want).all()
+    first, tok = first.cpu().numpy(), tok.cpu().numpy()
+    for j in range(b):
+        assert (np.diff(first[j]) == want[j].sum(1)).all() and first[j, 0] == 0 and (first[j, txs[j]:] == tys[j]).all()
+        assert (tok[j, : tys[j]] == want[j, :, : tys[j]].argmax(0)).all() and (tok[j, tys[j]:] == -1).all()
+    supported = bool(G.hip.load().glowtts_mas_spans_supported(tx, ty))
+    assert supported == (mas_kernel == 1 and ty % 4 == 0 and tx <= 512)
+    if supported:                                  # the search alone, then the path from the spans on another stream
+        first2 = torch.full((b, tx + 1), -7, device="cuda", dtype=torch.int32)
+        tok2 = torch.full((b, ty), -7, device="cuda", dtype=torch.int32)
+        path2 = torch.full((b, tx, ty), float("nan"), device="cuda")
+        G.hip.call("glowtts_mas_path_spans", G.hip.ptr(vd), None, G.hip.ptr(first2), G.hip.ptr(tok2), G.hip.ptr(txd.int()),
+                   G.hip.ptr(tyd.int()), b, tx, ty)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        G.hip.call_on(side.cuda_stream, "glowtts_mas_path_from_spans", G.hip.ptr(first2), G.hip.ptr(path2), b, tx, ty)
+        torch.cuda.synchronize()
+        assert (first2.cpu().numpy() == first).all() and (tok2.cpu().numpy() == tok).all()
+        assert (path2.cpu().numpy() == want).all()
+    else:
+        with pytest.raises(RuntimeError, match="path may be NULL only"):
+            G.hip.call("glowtts_mas_path_spans", G.hip.ptr(vd), None, G.hip.ptr(torch.empty(b, tx + 1, device="cuda", dtype=torch.int32)),
+                       None, G.hip.ptr(txd.int()), G.hip.ptr(tyd.int()), b, tx, ty)
+
 
 
 @pytest.mark.parametrize("b,c,tx,ty,mean_only", [(3, 80, 37, 101, False), (2, 80, 160, 800, True), (1, 6, 5, 9, False),
