@@ -499,40 +499,75 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
         __syncthreads();                           // ring slots and direction words of this step are visible to the next
     }
 
-    // ---- backtrack: as in mas_kernel (one lane's walk, state in scalar registers) over the [R][nblk32][256] word image
-    for (int x = threadIdx.x; x <= Tx; x += 256) first[x] = x >= tx ? ty : 0;
+    // ---- backtrack (core.pyx:32-35) with the direction words in REGISTERS.  mas_kernel's walk fetches a word from LDS, hands it
+    // to the scalar unit and decides — ~390 cycles per text row, 30 us at 160 tokens.  Here the words of a 32-frame block sit where
+    // the DP left them: lane L of wave w holds those of its own rows, so the wave that owns a row reads any of them with
+    // v_readlane (a scalar lane index, no memory) and the walk passes from wave to wave as it descends through the rows
+    // (nw - 1 hand-overs through LDS).  The next block's words are loaded while the current one is walked; the spans collect in a
+    // register per lane and are stored once at the end.
+    int fv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) fv[r] = (L * R + r) >= tx ? ty : 0;
+    int *hand = reinterpret_cast<int *>(ring);           // (index, y) between waves; the ring is dead after the DP's last barrier
+    if (L == 0) { hand[0] = tx - 1; hand[1] = ty - 1; }
     __syncthreads();
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0 && tx > 0 && ty > 0) {
-        auto word_of = [&](int row, int blk) -> uint32_t {
-            if (row <= 0) return 0u;
-            const uint32_t wd = dirs[((row % R) * nblk32 + blk) * LW + row / R];
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)wd);
-        };
-        int index = tx - 1, y = ty - 1, blk = y >> 5;
-        uint32_t word = word_of(index, blk), below = word_of(index - 1, blk);
-        while (index > 0 && y > 0) {
-            uint32_t m = word & (0xffffffffu >> (31 - (y & 31)));
-            if (blk == 0) m &= ~1u;
-            if (m == 0) {
-                if (blk == 0) break;
-                y = (blk << 5) - 1;
-                --blk;
-                word = word_of(index, blk);
-                below = word_of(index - 1, blk);
-                continue;
+    for (int j = nw - 1; j >= 0; --j) {
+        if (w == j && tx > 0 && ty > 0) {
+            int index = __builtin_amdgcn_readfirstlane(hand[0]), y = __builtin_amdgcn_readfirstlane(hand[1]);
+            const int base = 64 * R * j;                 // this wave's first row
+            if (index >= base && index > 0 && y > 0) {
+                int blk = y >> 5;
+                uint32_t wc[R], wn[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    wc[r] = dirs[(r * nblk32 + blk) * LW + L];
+                    wn[r] = blk > 0 ? dirs[(r * nblk32 + blk - 1) * LW + L] : 0u;
+                }
+                while (index >= base && index > 0 && y > 0) {
+                    const int li = index - base;
+                    uint32_t word;
+                    if (R == 1) word = (uint32_t)__builtin_amdgcn_readlane((int)wc[0], li);
+                    else {
+                        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wc[0], li >> 1);
+                        const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)wc[R - 1], li >> 1);
+                        word = (li & 1) ? w1 : w0;
+                    }
+                    uint32_t m = word & (0xffffffffu >> (31 - (y & 31)));
+                    if (blk == 0) m &= ~1u;              // no step at frame 0
+                    bool cross;
+                    if (m == 0) {                        // the path stays on this row for the rest of the 32-frame block
+                        if (blk == 0) { index = 0; break; }
+                        y = (blk << 5) - 1;
+                        cross = true;
+                    } else {
+                        y = (blk << 5) + (31 - __clz(m));         // frame at which the path leaves row `index` downwards
+                        // fv[row's register][row's lane] = y: a compare-and-select on the lane number (v_writelane takes its value
+                        // AND its lane from scalar registers, one more than gfx950's constant bus carries)
+                        if (R == 1) fv[0] = (lane == li) ? y : fv[0];
+                        else if (li & 1) fv[R - 1] = (lane == (li >> 1)) ? y : fv[R - 1];
+                        else fv[0] = (lane == (li >> 1)) ? y : fv[0];
+                        --index;
+                        --y;
+                        cross = (y >> 5) != blk;         // (y >= 0 here: the step was at a frame > 0)
+                    }
+                    if (cross) {                         // into the block below: its words are there, fetch the next
+                        --blk;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            wc[r] = wn[r];
+                            wn[r] = blk > 0 ? dirs[(r * nblk32 + blk - 1) * LW + L] : 0u;
+                        }
+                    }
+                }
             }
-            y = (blk << 5) + (31 - __clz(m));
-            first[index] = y;
-            --index;
-            --y;
-            word = below;
-            if ((y >> 5) != blk) {
-                blk = y >> 5;
-                word = word_of(index, blk);
-            }
-            below = word_of(index - 1, blk);
+            if (lane == 0) { hand[0] = index; hand[1] = y; }
         }
+        __syncthreads();
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (L * R + r <= Tx) first[L * R + r] = fv[r];
+    if (L == 0) first[Tx] = ty;                          // (row Tx itself when Tx = 256 R)
     __syncthreads();
 
     if (first_out != nullptr)

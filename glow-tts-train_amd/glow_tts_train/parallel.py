@@ -87,6 +87,8 @@ class FlowBlockReducer:
         the process-group machinery, which releases the interpreter lock).  Buckets are handed over and launched in the same
         order on every rank (a FIFO; the backward's node order is the same everywhere), as the communicator requires."""
         flat = getattr(optimizer, "_optim", optimizer)
+        if hasattr(flat, "flat_g") and flat.flat_g.is_cuda and os.environ.get("GLOWTTS_PRECREATE_STREAMS", "0") == "1":
+            _hip.precreate_streams(flat.flat_g.device)       # before the first collective creates the communicator's stream
         if not hasattr(flat, "flat_g"):
             raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
         self.flat = flat

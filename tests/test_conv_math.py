@@ -340,15 +340,19 @@ def test_weight_gradient_from_presplit_planes(M, b, h, t):
         call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), h * t, ptr(dp), d.numel(), 2 * h * t, ptr(dwp), None, b, h, 2 * h, t, 3, 3)
 
 
-def test_encoder_ffn_convs_take_the_group_planes(M):
-    """Round 3: the text encoder's 3-tap FFN convolutions (attentions.py:347-381; 192 -> 768 -> 192 channels at T_text frames)
+@pytest.mark.parametrize("b,t", [(8, 160), (32, 160), (48, 240), (64, 200)])
+def test_encoder_ffn_convs_take_the_group_planes(M, b, t):
+    """(b, t): the text encoder's shapes at BASELINE configs[1] (32 x 160), configs[4] (48 x 240: where the whole-step margin of one
+    FFN weight gradient sits 2.8x closer to its tolerance in bf16x6 than in fp32 — profiles/r04_parity_margins.json) and
+    configs[2] (64 x 200).
+    Round 3: the text encoder's 3-tap FFN convolutions (attentions.py:347-381; 192 -> 768 -> 192 channels at T_text frames)
     run in the selected conv arithmetic when their ConvGroup keeps bf16 planes: forward, backward-data (32-frame tiles at
     T = 160) and the 3-tap weight gradient (convwrw_tr.hip) against torch fp64 — bf16x6 no worse than the native kernels, and
     bit-different from them (the plane kernels really ran)."""
     import torch.nn as nn
 
     torch.manual_seed(11)
-    b, h, f, t = 8, 192, 768, 160
+    h, f = 192, 768
     c1, c2 = nn.Conv1d(h, f, 3, padding=1).cuda(), nn.Conv1d(f, h, 3, padding=1).cuda()
     for p_ in list(c1.parameters()) + list(c2.parameters()):
         p_.grad = torch.zeros_like(p_)
