@@ -391,8 +391,11 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                c[r][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (y0 + 4 * q < Ty) c[r][q] = *reinterpret_cast<const float4 *>(rowp[r] + y0 + 4 * q);      // (Ty % 4 == 0)
+                // UNCONDITIONAL loads (frames past the lattice re-read its last four: columns >= ty are never worked on) — behind a
+                // branch per load the compiler can no longer count them and waits for vmcnt(0), the NEXT slab's loads included
+                int yq = y0 + 4 * q;
+                yq = yq < Ty - 4 ? yq : Ty - 4;                                                                // (Ty % 4 == 0, Ty >= 4)
+                c[r][q] = *reinterpret_cast<const float4 *>(rowp[r] + yq);
             }
     };
     auto flush = [&](int y) {                      // after column y: store the rows' words of its 32-column block
@@ -484,20 +487,33 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
         }
     };
 
-    if (w < nw && nslab > 0) load(ca, 0);
-    for (int t = 0; t < nslab + nw - 1; ++t) {
-        const int s = t - w;
-        if (w < nw && s >= 0 && s < nslab) {
-            if (s & 1) {
-                if (s + 1 < nslab) load(ca, s + 1);
-                slab(cb, s);
-            } else {
-                if (s + 1 < nslab) load(cb, s + 1);
-                slab(ca, s);
-            }
+    // Step t: wave w works on slab t - w out of buffer (t & 1) while the next slab's cells load into the other one — the roles of
+    // the two buffers are tied to the parity of the STEP, so an unrolled pair of steps has them fixed (tied to the slab's parity the
+    // compiler merged the two cases with a register copy of a whole buffer and a vmcnt(0) per step).
+    const int nsteps = nslab > 0 ? nslab + nw - 1 : 0;
+    // ring slots and direction words of a step are visible to the next through an LDS-ONLY barrier: __syncthreads() would also wait for
+    // the cell loads just issued (vmcnt(0)), i.e. put a trip to memory into every one of the ~52 steps
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto step = [&](int t, float4 (&cur)[R][4], float4 (&nxt)[R][4]) {
+        const int sl = t - w;
+        if (w < nw && sl >= 0 && sl < nslab) {
+            if (sl + 1 < nslab) load(nxt, sl + 1);
+            slab(cur, sl);
         }
-        __syncthreads();                           // ring slots and direction words of this step are visible to the next
+    };
+    if (w < nw && nslab > 0) {                     // slab 0 is worked on in step w
+        if (w & 1) load(cb, 0);
+        else load(ca, 0);
     }
+    for (int t = 0; t < nsteps; t += 2) {
+        step(t, ca, cb);
+        lds_barrier();
+        if (t + 1 < nsteps) {
+            step(t + 1, cb, ca);
+            lds_barrier();
+        }
+    }
+    __syncthreads();
 
     // ---- backtrack (core.pyx:32-35) with the direction words in REGISTERS.  mas_kernel's walk fetches a word from LDS, hands it
     // to the scalar unit and decides — ~390 cycles per text row, 30 us at 160 tokens.  Here the words of a 32-frame block sit where
