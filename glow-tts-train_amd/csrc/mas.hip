@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             slab(cur, sl);
         }
     };
+    MAS_TRACE(0);
     if (w < nw && nslab > 0) {                     // slab 0 is worked on in step w
         if (w & 1) load(cb, 0);
         else load(ca, 0);
@@ -513,7 +514,9 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             lds_barrier();
         }
     }
+    MAS_TRACE(1);
     __syncthreads();
+    MAS_TRACE(2);
 
     // ---- backtrack (core.pyx:32-35) with the direction words in REGISTERS.  mas_kernel's walk fetches a word from LDS, hands it
     // to the scalar unit and decides — ~390 cycles per text row, 30 us at 160 tokens.  Here the words of a 32-frame block sit where
@@ -584,6 +587,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
     for (int r = 0; r < R; ++r)
         if (L * R + r <= Tx) first[L * R + r] = fv[r];
     if (L == 0) first[Tx] = ty;                          // (row Tx itself when Tx = 256 R)
+    MAS_TRACE(3);
     __syncthreads();
 
     if (first_out != nullptr)
@@ -611,6 +615,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             }
         }
     }
+    MAS_TRACE(4);
 }
 
 // path[b][x][y] = 1 for first[b][x] <= y < first[b][x + 1], else 0: a workgroup writes 8 text rows of one utterance with 16-byte
