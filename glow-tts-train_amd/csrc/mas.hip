@@ -405,18 +405,24 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             uint32_t wd = __brev(dw[r] << sh);     // column 32 blk + j of the word in bit j
             const int x = L * R + r;
             if ((x >> 5) == blk) wd |= 1u << (x & 31);      // x == y: the path must step (bits past y are never read)
+            if (blk == 0) wd &= ~1u;                         // no step at frame 0 (core.pyx:34 needs y > 0): the walk need not test it
             dirs[(r * nblk32 + blk) * LW + L] = wd;
             dw[r] = 0u;
         }
     };
-    auto column = [&](const float (&cells)[R], const unsigned long long (&dg)[R], float edge) {
+    // DIAG: the slab holds cells with x == y for this wave's rows (their `stay` predecessor lies above the diagonal: max_neg_val,
+    // core.pyx:21-22).  A slab whose every column lies beyond the wave's last row has none — the select and its compare go
+    auto column = [&](const float (&cells)[R], const unsigned long long (&dg)[R], float edge, const bool diag) {
         float vp[R], vc[R], best[R];
         vp[0] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v[R - 1]), 0x138, 0xf, 0xf, false));
 #pragma unroll
         for (int r = 1; r < R; ++r) vp[r] = v[r - 1];
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vc[r]) : "v"(v[r]), "v"(kMasNeg), "s"(dg[r]));
+        for (int r = 0; r < R; ++r) {
+            // (`diag` is a constant at every call site of this inlined lambda; a generic lambda cannot hold the asm operands)
+            if (diag) asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(vc[r]) : "v"(v[r]), "v"(kMasNeg), "s"(dg[r]));
+            else vc[r] = v[r];
+        }
         unsigned long long take[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) take[r] = __builtin_amdgcn_fcmpf(vp[r], vc[r], 2);      // vprev > vcur
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
     const float *prev_ring = ring + (w > 0 ? w - 1 : 0) * 64 * 64 + 63;
     auto slab = [&](const float4 (&c)[R][4], int s) {
         const int y0 = s * D;
+        if (y0 + D - 1 < 64 * R * w) return;       // every cell of the slab lies above the diagonal for this wave's rows: nothing is read back
         float bnd[D];                              // v[64 w R - 1][y - 1] for the slab's columns (wave 0: the sentinels of core.pyx:24-27)
         if (w > 0) {
 #pragma unroll
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             if (s == 0) bnd[0] = 0.0f;
         }
         float *rb = my_ring + (y0 & 63) * 64;      // columns y0 + 1 .. y0 + 15 of the ring: immediate offsets; y0 + 16 may wrap
-        if (y0 + D <= ty) {                        // the whole slab lies inside the utterance: no per-column test
+        auto whole = [&](const bool diag) {        // the whole slab lies inside the utterance: no per-column test
 #pragma unroll
             for (int g = 0; g < D / 4; ++g) {
                 unsigned long long dg[4][R];
@@ -452,19 +459,23 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        dg[u][r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)(y0 + 4 * g + u), 32);    // x == y
+                        dg[u][r] = diag ? __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)(y0 + 4 * g + u), 32) : 0ull;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float cells[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
-                    column(cells, dg[u], bnd[4 * g + u]);
+                    column(cells, dg[u], bnd[4 * g + u], diag);
                     if (4 * g + u < D - 1) rb[(4 * g + u + 1) * 64] = v[R - 1];
                     else my_ring[((y0 + D) & 63) * 64] = v[R - 1];
                 }
             }
             const int y = y0 + D - 1;              // (y0 is a multiple of 16: only the slab's last column can end a block)
             if ((y & 31) == 31 || y == ty - 1) flush(y);
+        };
+        if (y0 + D <= ty) {
+            if (y0 >= 64 * R * (w + 1)) whole(false);
+            else whole(true);
         } else {                                   // the utterance's last, partial slab
 #pragma unroll
             for (int g = 0; g < D / 4; ++g)
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                             dg[r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)y, 32);
                             cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
                         }
-                        column(cells, dg, bnd[4 * g + u]);
+                        column(cells, dg, bnd[4 * g + u], true);
                         my_ring[((y + 1) & 63) * 64] = v[R - 1];
                         if ((y & 31) == 31 || y == ty - 1) flush(y);
                     }
@@ -542,8 +553,12 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                     wc[r] = dirs[(r * nblk32 + blk) * LW + L];
                     wn[r] = blk > 0 ? dirs[(r * nblk32 + blk - 1) * LW + L] : 0u;
                 }
-                while (index >= base && index > 0 && y > 0) {
-                    const int li = index - base;
+                // per text row: the row's word from its owner lane, the highest direction bit at or below frame y (shift the
+                // frames above y out, count leading zeros), the span's first frame into the owner lane's register.  ~20 instructions,
+                // nearly all scalar, per row; frame 0's bit is cleared in the stored words, so y >= 0 needs no test of its own.
+                int li = index - base;
+                const int li_min = base == 0 ? 1 : 0;    // (row 0 is never left)
+                while (li >= li_min) {
                     uint32_t word;
                     if (R == 1) word = (uint32_t)__builtin_amdgcn_readlane((int)wc[0], li);
                     else {
@@ -551,23 +566,20 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                         const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)wc[R - 1], li >> 1);
                         word = (li & 1) ? w1 : w0;
                     }
-                    uint32_t m = word & (0xffffffffu >> (31 - (y & 31)));
-                    if (blk == 0) m &= ~1u;              // no step at frame 0
+                    const uint32_t m = word << ((~y) & 31);       // frame y in bit 31, the frames below it after it
                     bool cross;
                     if (m == 0) {                        // the path stays on this row for the rest of the 32-frame block
-                        if (blk == 0) { index = 0; break; }
-                        y = (blk << 5) - 1;
+                        if (blk == 0) { li = -base; break; }      // ... down to frame 0: index 0 ends every wave's walk
+                        y = (y & ~31) - 1;
                         cross = true;
                     } else {
-                        y = (blk << 5) + (31 - __clz(m));         // frame at which the path leaves row `index` downwards
-                        // fv[row's register][row's lane] = y: a compare-and-select on the lane number (v_writelane takes its value
-                        // AND its lane from scalar registers, one more than gfx950's constant bus carries)
-                        if (R == 1) fv[0] = (lane == li) ? y : fv[0];
-                        else if (li & 1) fv[R - 1] = (lane == (li >> 1)) ? y : fv[R - 1];
-                        else fv[0] = (lane == (li >> 1)) ? y : fv[0];
-                        --index;
-                        --y;
-                        cross = (y >> 5) != blk;         // (y >= 0 here: the step was at a frame > 0)
+                        const int ys = y - __clz(m);              // frame at which the path leaves this row downwards (>= 1)
+                        if (R == 1) fv[0] = (lane == li) ? ys : fv[0];
+                        else if (li & 1) fv[R - 1] = (lane == (li >> 1)) ? ys : fv[R - 1];
+                        else fv[0] = (lane == (li >> 1)) ? ys : fv[0];
+                        --li;
+                        y = ys - 1;
+                        cross = (ys & 31) == 0;
                     }
                     if (cross) {                         // into the block below: its words are there, fetch the next
                         --blk;
@@ -578,6 +590,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                         }
                     }
                 }
+                index = base + li;
             }
             if (lane == 0) { hand[0] = index; hand[1] = y; }
         }

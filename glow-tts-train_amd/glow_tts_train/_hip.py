@@ -384,15 +384,15 @@ def join_side_streams() -> None:
 def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda.Stream":
     """One extra stream per (device, role): "encoder" (the text-encoder branch), "wgrad" (weight-gradient kernels) and
     "comm" (the DP reducer's collectives)."""
-    if role == "fwd2" and _FWD2_ON_WGRAD:            # (experiment: the second forward chain on the stream the weight gradients use
-        role = "wgrad"                               #  in the backward — idle during the forward — instead of a stream of its own)
+    if role == "fwd2" and _FWD2_ON_WGRAD:            # the decoder's second forward chain runs on the stream the weight gradients use
+        role = "wgrad"                               # in the backward (idle during the forward): one stream fewer — DESIGN.md lesson 38
     key = (torch.device(device).index, role)
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device, priority=priority)
     return _side_streams[key]
 
 
-_FWD2_ON_WGRAD = os.environ.get("GLOWTTS_FWD2_ON_WGRAD", "0") == "1"
+_FWD2_ON_WGRAD = os.environ.get("GLOWTTS_FWD2_ON_WGRAD", "1") != "0"
 
 
 def precreate_streams(device, roles=("fwd2", "encoder", "wgrad", "comm")) -> None:

@@ -1279,7 +1279,7 @@ class FlowStackFn(Function):
         # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
         halves = _FWD_CHAINS if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % _FWD_CHAINS == 0
                                  and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"       # (one-stream profiling passes)
-                                 and (_HALF_BATCH_ENV == "1" or not _process_group_active())) else 1
+                                 ) else 1
         if halves > 1:
             main_s = torch.cuda.current_stream(dev)
             extra = [_hip.side_stream(dev, "fwd%d" % (j + 2)) for j in range(halves - 1)]
@@ -1482,9 +1482,12 @@ _FUSE_FLOWS = os.environ.get("GLOWTTS_FUSE_FLOWS", "1") != "0"    # FlowStackFn:
 _FLOW_BOUNDARY = os.environ.get("GLOWTTS_FLOW_BOUNDARY", "1") != "0"   # ... and with end conv(k) / start conv(k + 1): one launch
 # FlowStackFn forward as two half-batch chains on two streams (even batches, fp32 tensors): 13.71 -> 13.45 ms per step for ~1 ms more
 # host enqueue (twice the decoder's forward launches); GLOWTTS_HALF_BATCH_FWD=0 keeps one chain (a rank whose host is the bottleneck)
-# With a process group (data parallel) the two chains COST 1.8 ms per step (bench.py --rccl-self: 14.9 -> 16.8 ms; cause not isolated —
-# host enqueue is 10.4 ms of the step there, a fifth stream beside RCCL's is the other suspect): unset = two chains only without a
-# process group, 1 = always, 0 = never
+# Round 4 switched the two chains off under a process group (bench.py --rccl-self: 14.9 -> 16.8 ms, "cause not isolated").  Round 5
+# isolated it (DESIGN.md lesson 38): the second chain's stream and the main stream had landed on the SAME hardware queue (HIP maps
+# streams onto GPU_MAX_HW_QUEUES = 4 queues in order of first use, and a process group's streams come first), so the two chains ran one
+# after the other and every event wait of one stalled the other.  The second chain now runs on the weight-gradient stream (idle during
+# the forward; _hip._FWD2_ON_WGRAD) — one stream fewer, 13.87 against 15.72 ms with the reducer attached, 13.29 against 13.36 without —
+# and the chains are on with or without a process group.
 _HALF_BATCH_ENV = os.environ.get("GLOWTTS_HALF_BATCH_FWD", "")
 _HALF_BATCH_FWD = _HALF_BATCH_ENV != "0"
 _FWD_CHAINS = int(os.environ.get("GLOWTTS_FWD_CHAINS", "2"))          # (chains of B / n utterances; 2 measured best)
