@@ -33,7 +33,7 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                    `as_launched_in_the_step`: the block-boundary launch forward / the fused kernel backward) and the decoder
                    alone (8d(ii));
   "other_configs": BASELINE configs[2] (bf16 tensors, B=64, T_mel=1000) and configs[4] (speaker-conditioned, B=48, T_mel=1200,
-                   20 blocks) timed after everything else, 3 warm-up + 5 steps each (N=1 only; never `value`);
+                   20 blocks) timed after everything else, 6 warm-up + 8 steps each on fresh models (N=1 only; never `value`);
   "cpu_baseline" : the CPU oracle (oracle/glow_oracle.py, a port) on this host's cores as BASELINE.md section 3 prescribes:
                    3 warm-up + 10 timed full steps, median, all usable cores, plus a 1-thread run on a shorter sample; the
                    CPU model is stated.
@@ -518,7 +518,7 @@ def build_workload(args, dev, rank):
     return model, opt, batch, cfg
 
 
-def other_configs_leg(args, dev, warm=3, steps=5):
+def other_configs_leg(args, dev, warm=6, steps=8):
     """BASELINE.json configs[2] (bf16 tensors in HBM, B=64, T_mel=1000) and configs[4] (speaker-conditioned couplings, B=48,
     T_mel=1200, 20 flow blocks, 4 speakers, gin 64): the same full training step, `warm` + `steps` steps each on fresh models,
     so that the driver's run times them too.  Never `value`."""

@@ -76,7 +76,7 @@ class Encoder(nn.Module):
                     _, live = convops._enc_layer_table(*mods)
                     counts.append(len(live))
                     params.extend(live)
-                return _enc_stack_apply(x, m2, keep, cfg, layers, counts, *params) * x_mask
+                return _enc_stack_apply(x, m2, keep, cfg, layers, counts, params[0], convops.ParamPack(params)) * x_mask
             pos = 0
             for group, attn, ffn, norm1, norm2 in layers:
                 drops = None

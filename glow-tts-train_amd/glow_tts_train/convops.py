@@ -73,6 +73,23 @@ def _notify(params) -> None:
         fn(params)
 
 
+class ParamPack(tuple):
+    """The parameters of a whole-stack node handed to `Function.apply` as ONE opaque argument (autograd looks at top-level tensor
+    arguments only).  The stack nodes exist in in-place gradient mode only: their backward writes every parameter gradient into
+    `.grad` itself and hands autograd None — yet with the 400-odd parameters as tensor inputs the engine still ran an
+    AccumulateGrad node for each of them, ~1 us apiece on the backward thread (0.5 ms per step at the default model:
+    tools/dp_probe.py's host profile).  One parameter stays a real input (the `anchor`: the node needs an input that requires
+    grad to be part of the graph at all — the mel frames do not)."""
+    __slots__ = ()
+
+
+def _unpack_params(params):
+    """(parameter tensors, number of apply() arguments they took): `*params` is either the tensors themselves or (anchor, ParamPack)."""
+    if len(params) == 2 and isinstance(params[1], ParamPack):
+        return tuple(params[1]), 2
+    return params, len(params)
+
+
 def _rows_ok(x: torch.Tensor) -> bool:
     """(B, C, T) tensor whose rows are dense and T-contiguous inside each utterance (a channel slice qualifies)."""
     return x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == x.shape[2]
@@ -1214,6 +1231,7 @@ class FlowStackFn(Function):
     @staticmethod
     def forward(ctx, x, m2, x_len, drops, cfg, bplans, counts, *params):
         import ctypes
+        params, ctx.n_param_args = _unpack_params(params)
         n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
         fdt = torch.bfloat16 if io & 2 else torch.float32
         adt = torch.bfloat16 if io & 1 else torch.float32
@@ -1473,7 +1491,7 @@ class FlowStackFn(Function):
                      ptr(pk[2]), tab.w_inv, pdy + k * nC * 4, pdl, pl, pdy + (k - 1) * nC * 4, pdo + (k - 1) * nC * 4, ptr(pk[0].grad),
                      ptr(pk[1].grad), ptr(pk[2].grad), B, C, T, n_split, int(sigmoid_scale))
                 _notify(live[:3])
-        return (dxs[0], None, None, None, None, None, None) + (None,) * len(params)
+        return (dxs[0], None, None, None, None, None, None) + (None,) * ctx.n_param_args
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -1558,6 +1576,7 @@ class EncoderStackFn(Function):
     @staticmethod
     def forward(ctx, x, m2, keep, cfg, layers, counts, *params):
         import ctypes
+        params, ctx.n_param_args = _unpack_params(params)
         heads, taps, window, share, blk, eps, p_drop = cfg
         nl = len(layers)
         x = f32(x.contiguous())
@@ -1652,7 +1671,7 @@ class EncoderStackFn(Function):
                     _notify(live)
             else:
                 _notify(live)
-        return (ws[0, (w_dx // 4): (w_dx // 4) + n_ht].view(B, H, T), None, None, None, None, None) + (None,) * len(params)
+        return (ws[0, (w_dx // 4): (w_dx // 4) + n_ht].view(B, H, T), None, None, None, None, None) + (None,) * ctx.n_param_args
 
 
 class EncoderLayerFn(Function):

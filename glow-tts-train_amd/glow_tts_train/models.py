@@ -240,7 +240,8 @@ class FlowSpecDecoder(nn.Module):
                 cfg, bplans, counts, params = stack
                 for f in blocks:
                     f.wn._drop_pre = None
-                x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, *params)
+                # (one parameter as the node's differentiable input, the rest as one opaque argument: convops.ParamPack)
+                x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, params[0], convops.ParamPack(params))
                 if self.n_sqz > 1:
                     x, x_mask = unsqueeze(x, x_mask, self.n_sqz, io_bf16=flow16)
                 elif flow16:
