@@ -512,8 +512,10 @@ static int launch_wrw_tr(ConvWrwParams &p, hipStream_t s) {
     // nbatch times fewer prologues, group reductions and split-K atomics per problem (82 KB per workgroup: 20.7 -> 4.4 MB per
     // problem) for 16 % of the compute units left to the other streams; 15.08 -> 14.98 ms per step (tools/ab_flags.py
     // envs=GLOWTTS_WRW5_BSPLIT:0,GLOWTTS_WRW5_BSPLIT:1; two launches of two problems x 7 splits: 15.01).  Read at every launch.
-    if (p.nbatch > 1 && knob(K_WRW5_BSPLIT) == 1 && compute_units() >= tiles * p.nbatch)
-        splits = compute_units() / (tiles * p.nbatch);
+    if (p.nbatch > 1 && knob(K_WRW5_BSPLIT) == 1 && compute_units() >= tiles * p.nbatch) {
+        const int cus = knob(K_WRW5_CUS);          // -1: every compute unit; a smaller number leaves the rest to the backward's chain
+        splits = ((cus > 0 && cus < compute_units()) ? cus : compute_units()) / (tiles * p.nbatch);
+    }
     if (NG == 1) splits *= knob(K_WRW_TR_NG_SPLITS);      // (one group: workgroups per CU's worth of items; 1 = same grid)
     if (splits > (total + 1) / 2) splits = (total + 1) / 2;      // a workgroup wants an item for each of its two groups
     if (splits < 1) splits = 1;

@@ -395,21 +395,6 @@ def side_stream(device, role: str = "encoder", priority: int = 0) -> "torch.cuda
 _FWD2_ON_WGRAD = os.environ.get("GLOWTTS_FWD2_ON_WGRAD", "1") != "0"
 
 
-def precreate_streams(device, roles=("fwd2", "encoder", "wgrad", "comm")) -> None:
-    """Create the step's side streams in a FIXED order and put one tiny launch on each, before anything else (a process group's
-    communicator, its internal stream) creates streams of its own.  HIP maps streams onto a small number of hardware queues
-    (GPU_MAX_HW_QUEUES, default 4) in the order in which they first submit work; two streams that share a hardware queue execute
-    in order of submission — a chain that waits for an event then stalls every launch queued behind it on that queue, whatever
-    stream it came from.  With the order fixed, the decoder's two forward chains, the text encoder's stream and the weight-gradient
-    stream get queues of their own and what has to share shares with a stream that is idle at the time (DESIGN.md lesson 38)."""
-    dev = torch.device(device)
-    for role in roles:
-        s = side_stream(dev, role)
-        with torch.cuda.stream(s):
-            torch.zeros(1, device=dev).add_(1)
-    torch.cuda.synchronize(dev)
-
-
 def all_side_streams(device):
     """The side streams gradients may come from (the forward-only chains "fwd2.." are joined inside the forward: not among them)."""
     idx = torch.device(device).index

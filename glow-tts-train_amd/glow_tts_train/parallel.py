@@ -70,8 +70,7 @@ class FlowBlockReducer:
 
     def __init__(self, model: torch.nn.Module, optimizer, process_group=None,
                  bucket_key: typing.Callable[[str], str] = default_bucket_key, force: bool = False,
-                 measure: bool = False, comm_thread: typing.Optional[bool] = None,
-                 launch_on_producer: typing.Optional[bool] = None):
+                 measure: bool = False, comm_thread: typing.Optional[bool] = None):
         """`force`: hook the gradients and issue every bucket's collective even in a group of ONE rank (the collective is
         then the identity; it exercises the RCCL launch path, its streams and `finish()` on a single GPU).
         `measure`: record HIP events around the wait in `finish()` — `exposed_comm_ms()` is the time the compute stream
@@ -88,8 +87,6 @@ class FlowBlockReducer:
         the process-group machinery, which releases the interpreter lock).  Buckets are handed over and launched in the same
         order on every rank (a FIFO; the backward's node order is the same everywhere), as the communicator requires."""
         flat = getattr(optimizer, "_optim", optimizer)
-        if hasattr(flat, "flat_g") and flat.flat_g.is_cuda and os.environ.get("GLOWTTS_PRECREATE_STREAMS", "0") == "1":
-            _hip.precreate_streams(flat.flat_g.device)       # before the first collective creates the communicator's stream
         if not hasattr(flat, "flat_g"):
             raise TypeError("FlowBlockReducer needs the flat-buffer optimizer (glow_tts_train.optimize.Adam)")
         self.flat = flat
@@ -106,12 +103,6 @@ class FlowBlockReducer:
         self.launched_in_backward = 0          # buckets whose collective was issued before finish() in the last step
         if comm_thread is None:
             comm_thread = os.environ.get("GLOWTTS_DP_COMM_THREAD", "1") != "0"
-        # (experiment, launcher-thread mode only) issue a bucket's collective from the stream whose announcement completed it instead
-        # of a launch stream of its own: no event-wait packets of a fifth stream in the hardware queues the compute streams share, at
-        # the price of a dependency on whatever that stream has queued by the time the launcher thread gets to the bucket
-        if launch_on_producer is None:
-            launch_on_producer = os.environ.get("GLOWTTS_DP_PRODUCER_STREAM", "0") == "1"
-        self._on_producer = bool(launch_on_producer)
         self._thread_mode = bool(comm_thread) and self._active and flat.flat_g.is_cuda
         self._q: typing.Optional[queue.SimpleQueue] = None
         self._thr: typing.Optional[threading.Thread] = None
@@ -178,15 +169,16 @@ class FlowBlockReducer:
             if isinstance(item, threading.Event):
                 item.set()
                 continue
-            i, waits, ev, early, producer = item
+            i, waits, ev, early = item
             try:
                 b = self.buckets[i]
                 view = self.flat.flat_g[b.lo:b.hi]
-                on_producer = self._on_producer and not self._measure
-                launch = producer if on_producer else comm
-                with torch.cuda.stream(launch):
-                    for e in (waits[1:] if on_producer else waits):       # (waits[0]: the producer stream's own position)
-                        launch.wait_event(e)
+                # (issuing the collective from the stream that completed the bucket instead of a launch stream of its own —
+                #  one stream fewer — was measured 0.3-0.5 ms per step SLOWER: its waits for the other producers' events stall
+                #  that stream's own weight-gradient kernels; tools/dp_probe.py, round 5)
+                with torch.cuda.stream(comm):
+                    for e in waits:
+                        comm.wait_event(e)
                     if ev is not None:
                         ev[1].record(comm)
                     if self._use_avg:
@@ -194,7 +186,7 @@ class FlowBlockReducer:
                     else:
                         view.div_(self.world)
                         work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    if self.backend == "nccl" and not on_producer:
+                    if self.backend == "nccl":
                         work.wait()                  # the LAUNCH stream waits for the collective (no host block): `end` is its end
                     if ev is not None:
                         ev[2].record(comm)
@@ -220,7 +212,7 @@ class FlowBlockReducer:
                 e = torch.cuda.Event()
                 e.record(s)
                 waits.append(e)
-            self._q.put((i, waits, ev, not self._in_finish, cur))
+            self._q.put((i, waits, ev, not self._in_finish))
             self._launched[i] = True
             return
         if view.is_cuda:

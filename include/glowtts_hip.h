@@ -29,6 +29,8 @@
  *                                 GLOWTTS_WRW5_BSPLIT [1]     0 = a batched 5-tap weight-gradient launch sizes its split-K per problem
  *                                                     (one round of workgroups per problem) instead of sharing the compute units
  *                                                     between the problems of the batch (csrc/convwrw_tr.hip)
+ *                                 GLOWTTS_WRW5_CUS    [-1]    compute units a BATCHED 5-tap weight-gradient launch sizes its split-K for
+ *                                                     (-1 = all of the device's)
  *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
  *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip)
  *                                 GLOWTTS_WRW1_CUS    [-1]    compute units the multi-problem 1x1 weight gradient sizes its split-K for

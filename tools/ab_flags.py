@@ -84,7 +84,7 @@ def train_batch(*a):                                         # noqa: F811
 for _ in range(8):
     train_batch(model, opt, batch, cfg.grad_clip, None)
 res = {v: [] for v in vals}
-for blk in range(2 * blocks):
+for blk in range(len(vals) * blocks):
     v = vals[blk % len(vals)]
     apply(v)
     for _ in range(3):

@@ -12,7 +12,6 @@ Variants (alternating blocks of steps):
   inl/2
   thr/1    reducer, collectives issued by the reducer's launcher thread (round 5 default)
   thr/2
-  thrp/2   ... from the stream that completed the bucket instead of a launch stream of its own
 """
 import os
 import sys
@@ -57,7 +56,7 @@ def timed(cls, name):
 for nm in ("_launch", "_on_announce", "_on_hook", "finish"):
     timed(parallel.FlowBlockReducer, nm)
 
-variants = [("none", 1), ("none", 2), ("inl", 2), ("thr", 1), ("thr", 2), ("thrp", 2)]
+variants = [("none", 1), ("none", 2), ("inl", 2), ("thr", 1), ("thr", 2)]
 state = {"reducer": None, "kind": None}
 
 
@@ -70,8 +69,7 @@ def select(kind, chains):
         state["reducer"].remove_hooks()
     convops.set_direct_grads(True if kind == "none" else None)
     state["reducer"] = None if kind == "none" else parallel.FlowBlockReducer(model, opt, force=True, measure=False,
-                                                                            comm_thread=kind.startswith("thr"),
-                                                                            launch_on_producer=(kind == "thrp"))
+                                                                            comm_thread=(kind == "thr"))
     state["kind"] = kind
 
 
