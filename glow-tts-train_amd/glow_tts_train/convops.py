@@ -73,19 +73,6 @@ def _notify(params) -> None:
         fn(params)
 
 
-_pending_mask_event = [None]
-
-
-def pending_mask_event(ev=None):
-    """Hand-over of the event behind which the decoder's dropout keep-masks are complete (models.FlowSpecDecoder.forward draws
-    them on another stream): set by the caller right before the stack node, taken by FlowStackFn.forward."""
-    if ev is not None:
-        _pending_mask_event[0] = ev
-        return None
-    ev, _pending_mask_event[0] = _pending_mask_event[0], None
-    return ev
-
-
 class ParamPack(tuple):
     """The parameters of a whole-stack node handed to `Function.apply` as ONE opaque argument (autograd looks at top-level tensor
     arguments only).  The stack nodes exist in in-place gradient mode only: their backward writes every parameter gradient into
@@ -1304,9 +1291,6 @@ class FlowStackFn(Function):
             if wtab is None or wtab[0] != wkey:
                 wtab = bplans[0]._w_table = (wkey, torch.tensor(wkey, dtype=torch.int64).to(dev))
             call("glowtts_invconv_prepare_multi", ptr(wtab[1]), pw, n_split * n_split + 1, nb, n_split)
-        mask_ev = pending_mask_event()
-        if mask_ev is not None:                                   # the keep-masks were drawn on another stream beside the launches above
-            torch.cuda.current_stream(dev).wait_event(mask_ev)
         # Two half-batch chains on two streams (forward only; fp32 tensors with the boundary launch): every utterance is independent in
         # the forward, and two DIFFERENT kernels sharing the CUs fill each other's prologues and epilogues where two workgroups of
         # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a

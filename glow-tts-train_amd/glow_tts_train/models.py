@@ -22,7 +22,6 @@ from .utils import generate_path, sequence_mask, squeeze, unsqueeze
 
 _actnorm_invconv_apply = _hip.direct_apply(ops.ActNormInvConvFn)
 _flow_stack_apply = _hip.direct_apply(convops.FlowStackFn)
-_MASK_SIDE = os.environ.get("GLOWTTS_MASK_SIDE", "1") != "0"      # decoder keep-masks drawn on the weight-gradient stream (FlowSpecDecoder.forward)
 _FLOW_STACK = __import__("os").environ.get("GLOWTTS_FLOW_STACK", "1") != "0"
 _flow_block_apply = _hip.direct_apply(convops.FlowBlockFn)
 _align_expand_apply = _hip.direct_apply(ops.AlignExpandFn)
@@ -232,22 +231,8 @@ class FlowSpecDecoder(nn.Module):
                     and all(f.wn.n_layers == blocks[0].wn.n_layers and f.wn.hidden_channels == blocks[0].wn.hidden_channels
                             and f.wn.p_dropout == blocks[0].wn.p_dropout and f.wn.training for f in blocks)):
                 wn0 = blocks[0].wn
-                mshape = (len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2))
-                mask_ready = None
-                if _MASK_SIDE and _hip.side_stream_enabled():
-                    # inside a training step the generator launch (236 MB, ~60 us at config 2) runs on the weight-gradient stream —
-                    # idle until the backward, and the stream of the forward's second chain — beside the weight packing at the top
-                    # of the stack, instead of in front of it on the decoder's chain; the chain waits for it after the packing
-                    cur = torch.cuda.current_stream(x.device)
-                    wg = _hip.side_stream(x.device, "wgrad")
-                    wg.wait_stream(cur)
-                    with torch.cuda.stream(wg):
-                        masks = ops.keep_mask(mshape, float(wn0.p_dropout), x.device, "decoder.wn")
-                        mask_ready = torch.cuda.Event()
-                        mask_ready.record(wg)
-                    masks.record_stream(cur)
-                else:
-                    masks = ops.keep_mask(mshape, float(wn0.p_dropout), x.device, "decoder.wn")
+                masks = ops.keep_mask((len(blocks), wn0.n_layers, x.size(0), 2 * wn0.hidden_channels, x.size(2)),
+                                      float(wn0.p_dropout), x.device, "decoder.wn")
                 for k, f in enumerate(blocks):
                     f.wn._drop_pre = masks[k]
             stack = self._stack_args(x, g, io, blocks, m2)
@@ -255,8 +240,6 @@ class FlowSpecDecoder(nn.Module):
                 cfg, bplans, counts, params = stack
                 for f in blocks:
                     f.wn._drop_pre = None
-                if masks is not None and mask_ready is not None:
-                    convops.pending_mask_event(mask_ready)     # the stack waits for it behind its weight-pack launch
                 # (one parameter as the node's differentiable input, the rest as one opaque argument: convops.ParamPack)
                 x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, params[0], convops.ParamPack(params))
                 if self.n_sqz > 1:
@@ -264,8 +247,6 @@ class FlowSpecDecoder(nn.Module):
                 elif flow16:
                     x = x.float()
                 return x, logdet_tot
-            if masks is not None and mask_ready is not None:   # per-block nodes: the chain waits before its first block
-                torch.cuda.current_stream(x.device).wait_event(mask_ready)
             i = 0
             while i < len(self.flows):
                 f = self.flows[i]

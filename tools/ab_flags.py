@@ -59,9 +59,6 @@ def apply(v):
             k, _, val = kv.partition(":")
             from glow_tts_train import _hip
             _hip.set_knob(k, int(val))                     # (the library latches its environment once: glowtts_set_knob flips a switch)
-    elif name == "maskside":                                # decoder keep-masks drawn on the weight-gradient stream (1) or on the chain (0)
-        from glow_tts_train import models as _m
-        _m._MASK_SIDE = v == "1"
     elif name == "chain":                                   # whole step on a high-priority stream (1) or the default stream (0)
         global CHAIN
         CHAIN = v == "1"
