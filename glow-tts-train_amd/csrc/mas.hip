@@ -384,17 +384,19 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
         x = x < Tx ? x : Tx - 1;                   // rows past the lattice read the last row: out of band, never read back
         rowp[r] = val + (size_t)x * Ty;
     }
-    // The cells of the slab being worked on: four frames per register quad and row.  ONE buffer: a quad is re-loaded with the next
-    // slab's frames as soon as its four columns are done, so every load has twelve columns and a barrier to land (two buffers
-    // tied to the parity of the step doubled the unrolled code; in the step the kernel runs once, from a cold instruction cache —
-    // 87 us there against 58 back to back).  UNCONDITIONAL loads (frames past the lattice re-read its last four: columns >= ty are
-    // never worked on): behind a branch per load the compiler can no longer count them and waits for vmcnt(0).
-    float4 c[R][4];
-    auto load_q = [&](int s, int q) {
-        int yq = s * D + 4 * q;
-        yq = yq < Ty - 4 ? yq : Ty - 4;                                                                        // (Ty % 4 == 0, Ty >= 4)
+    float4 ca[R][4], cb[R][4];
+    auto load = [&](float4 (&c)[R][4], int s) {
+        const int y0 = s * D;
 #pragma unroll
-        for (int r = 0; r < R; ++r) c[r][q] = *reinterpret_cast<const float4 *>(rowp[r] + yq);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // UNCONDITIONAL loads (frames past the lattice re-read its last four: columns >= ty are never worked on) — behind a
+                // branch per load the compiler can no longer count them and waits for vmcnt(0), the NEXT slab's loads included
+                int yq = y0 + 4 * q;
+                yq = yq < Ty - 4 ? yq : Ty - 4;                                                                // (Ty % 4 == 0, Ty >= 4)
+                c[r][q] = *reinterpret_cast<const float4 *>(rowp[r] + yq);
+            }
     };
     auto flush = [&](int y) {                      // after column y: store the rows' words of its 32-column block
         const int sh = 31 - (y & 31), blk = y >> 5;
@@ -436,13 +438,9 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
     };
     float *my_ring = ring + w * 64 * 64 + lane;      // (the last wave's ring is never read: an unconditional store beats a branch per column)
     const float *prev_ring = ring + (w > 0 ? w - 1 : 0) * 64 * 64 + 63;
-    auto slab = [&](int s) {
+    auto slab = [&](const float4 (&c)[R][4], int s) {
         const int y0 = s * D;
-        if (y0 + D - 1 < 64 * R * w) {             // every cell of the slab lies above the diagonal for this wave's rows: nothing is read back
-#pragma unroll
-            for (int q = 0; q < 4; ++q) load_q(s + 1, q);
-            return;
-        }
+        if (y0 + D - 1 < 64 * R * w) return;       // every cell of the slab lies above the diagonal for this wave's rows: nothing is read back
         float bnd[D];                              // v[64 w R - 1][y - 1] for the slab's columns (wave 0: the sentinels of core.pyx:24-27)
         if (w > 0) {
 #pragma unroll
@@ -452,28 +450,35 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
             for (int u = 0; u < D; ++u) bnd[u] = kMasNeg;
             if (s == 0) bnd[0] = 0.0f;
         }
-        if (y0 + D <= ty && y0 >= 64 * R * (w + 1)) {
-            // the hot form: the whole slab inside the utterance and beyond this wave's diagonal cells — no test per column
-            float *rb = my_ring + (y0 & 63) * 64;  // columns y0 + 1 .. y0 + 15 of the ring: immediate offsets; y0 + 16 may wrap
-            const unsigned long long nodg[R] = {};
+        float *rb = my_ring + (y0 & 63) * 64;      // columns y0 + 1 .. y0 + 15 of the ring: immediate offsets; y0 + 16 may wrap
+        auto whole = [&](const bool diag) {        // the whole slab lies inside the utterance: no per-column test
 #pragma unroll
             for (int g = 0; g < D / 4; ++g) {
+                unsigned long long dg[4][R];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        dg[u][r] = diag ? __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)(y0 + 4 * g + u), 32) : 0ull;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float cells[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
-                    column(cells, nodg, bnd[4 * g + u], false);
+                    column(cells, dg[u], bnd[4 * g + u], diag);
                     if (4 * g + u < D - 1) rb[(4 * g + u + 1) * 64] = v[R - 1];
                     else my_ring[((y0 + D) & 63) * 64] = v[R - 1];
                 }
-                load_q(s + 1, g);
             }
             const int y = y0 + D - 1;              // (y0 is a multiple of 16: only the slab's last column can end a block)
             if ((y & 31) == 31 || y == ty - 1) flush(y);
-        } else {                                   // the few slabs with diagonal cells, and the utterance's last, partial one
+        };
+        if (y0 + D <= ty) {
+            if (y0 >= 64 * R * (w + 1)) whole(false);
+            else whole(true);
+        } else {                                   // the utterance's last, partial slab
 #pragma unroll
-            for (int g = 0; g < D / 4; ++g) {
+            for (int g = 0; g < D / 4; ++g)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int y = y0 + 4 * g + u;
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                         float cells[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            dg[r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)y, 32);               // x == y
+                            dg[r] = __builtin_amdgcn_uicmp((unsigned)(L * R + r), (unsigned)y, 32);
                             cells[r] = u == 0 ? c[r][g].x : u == 1 ? c[r][g].y : u == 2 ? c[r][g].z : c[r][g].w;
                         }
                         column(cells, dg, bnd[4 * g + u], true);
@@ -490,24 +495,35 @@ __global__ __launch_bounds__(256) void mas_wave_kernel(const float *__restrict__
                         if ((y & 31) == 31 || y == ty - 1) flush(y);
                     }
                 }
-                load_q(s + 1, g);
-            }
         }
     };
 
-    // Step t: wave w works on slab t - w (a skewed pipeline over the slabs)
+    // Step t: wave w works on slab t - w out of buffer (t & 1) while the next slab's cells load into the other one — the roles of
+    // the two buffers are tied to the parity of the STEP, so an unrolled pair of steps has them fixed (tied to the slab's parity the
+    // compiler merged the two cases with a register copy of a whole buffer and a vmcnt(0) per step).
     const int nsteps = nslab > 0 ? nslab + nw - 1 : 0;
-    MAS_TRACE(0);
-    if (w < nw && nslab > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) load_q(0, q);
-    }
-    for (int t = 0; t < nsteps; ++t) {
+    // ring slots and direction words of a step are visible to the next through an LDS-ONLY barrier: __syncthreads() would also wait for
+    // the cell loads just issued (vmcnt(0)), i.e. put a trip to memory into every one of the ~52 steps
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto step = [&](int t, float4 (&cur)[R][4], float4 (&nxt)[R][4]) {
         const int sl = t - w;
-        if (w < nw && sl >= 0 && sl < nslab) slab(sl);
-        // ring slots and direction words of a step are visible to the next through an LDS-ONLY barrier: __syncthreads() would also
-        // wait for the cell loads just issued (vmcnt(0)), i.e. put a trip to memory into every one of the ~52 steps
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (w < nw && sl >= 0 && sl < nslab) {
+            if (sl + 1 < nslab) load(nxt, sl + 1);
+            slab(cur, sl);
+        }
+    };
+    MAS_TRACE(0);
+    if (w < nw && nslab > 0) {                     // slab 0 is worked on in step w
+        if (w & 1) load(cb, 0);
+        else load(ca, 0);
+    }
+    for (int t = 0; t < nsteps; t += 2) {
+        step(t, ca, cb);
+        lds_barrier();
+        if (t + 1 < nsteps) {
+            step(t + 1, cb, ca);
+            lds_barrier();
+        }
     }
     MAS_TRACE(1);
     __syncthreads();
