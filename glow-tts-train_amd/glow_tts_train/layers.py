@@ -133,7 +133,15 @@ class WN(nn.Module):
         m2 = kwargs.get("m2")
         if m2 is None:
             m2 = ops.mask2d(x_mask)
-        cond = self.cond_layer(g) if g is not None else None          # (B, 2H*n_layers, 1): tiny, left to torch
+        # (B, 2H*n_layers, 1): a 1x1 convolution over ONE frame (layers.py:142-143).  On the device it runs on the library's own
+        # convolution kernels like every other contraction of the step (round 5: left to the framework it was MIOpen's Winograd kernel
+        # plus torch's weight-norm kernels, ~10 launches per block — the only library GEMM on the configs[4] training path)
+        if g is None:
+            cond = None
+        elif g.is_cuda and g.dim() == 3:
+            cond = convops.conv1d(self.cond_layer, g.contiguous())
+        else:
+            cond = self.cond_layer(g)
         flat = []
         for in_layer, rs_layer in zip(self.in_layers, self.res_skip_layers):
             flat.extend(self._conv_params(in_layer))
