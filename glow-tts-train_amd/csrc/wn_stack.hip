@@ -85,9 +85,7 @@ static int wn_fwd_impl(const glowtts_wn_layer *layers, int n_layers, const void 
     GLOWTTS_CHECK_ARG(layers && x && mask && acts && ts && skip, "glowtts_wn_fwd: null pointer");
     GLOWTTS_CHECK_ARG(n_layers >= 1 && (n_layers == 1 || xs), "glowtts_wn_fwd: bad layer count / missing xs");
     GLOWTTS_CHECK_ARG(B >= 0 && H > 0 && T >= 0 && taps >= 1 && (taps & 1) && dil_rate >= 1, "glowtts_wn_fwd: bad shape");
-    // (slab_B > B: the call covers B utterances of slabs that hold slab_B — the stack node's part-batch chains.  `cond` is indexed by
-    //  the CALL's batch, layer-major rows (n_layers, B, 2H): the caller hands each chain its own table)
-    GLOWTTS_CHECK_ARG(slab_B >= B, "glowtts_wn_fwd: bad slab batch");
+    GLOWTTS_CHECK_ARG(slab_B >= B && (slab_B == B || !cond), "glowtts_wn_fwd: bad slab batch");
     const long BHT = (long)slab_B * H * T;
     if (!io && !cond && slab_B == B) {        // the layer-resident kernel (csrc/wn_fused.hip): fp32 tensors, bf16x6 arithmetic, H = 192, 5 taps
         const int rc = wn_fused_dispatch(layers, n_layers, static_cast<const float *>(x), mask, drop, drop_scale, static_cast<float *>(xs),

@@ -1226,12 +1226,10 @@ class FlowStackFn(Function):
     `_bwd_io` call each — but the host does per STACK what it did per block: one allocation per kind of activation slab
     ((n_blocks, ...) tensors; a block's buffers are slices addressed by pointer arithmetic), one saved-tensor list, one autograd
     node instead of twelve.  Per block the Python side is the weight pack, the plane binding, the cached table and one C call.
-    fp32 or bf16 tensors (`io` as in FlowBlockFn).  `conds` (round 5): None, or the speaker-conditioning rows of every block
-    (n_blocks, B, 2H * n_layers, 1) = wn.cond_layer(g) stacked (reference layers.py:142-150) — a differentiable input; anything
-    else takes the per-block nodes."""
+    fp32 or bf16 tensors (`io` as in FlowBlockFn), no conditioning input; anything else takes the per-block nodes."""
 
     @staticmethod
-    def forward(ctx, x, m2, x_len, drops, conds, cfg, bplans, counts, *params):
+    def forward(ctx, x, m2, x_len, drops, cfg, bplans, counts, *params):
         import ctypes
         params, ctx.n_param_args = _unpack_params(params)
         n_split, sigmoid_scale, p_drop, dil_rate, n_layers, H, io = cfg
@@ -1273,20 +1271,6 @@ class FlowStackFn(Function):
         boundary = fuse and _FLOW_BOUNDARY and T % 4 == 0 and C <= 192 and C // n_split <= 64 and H <= 192
         prev_tab = None
         stack_pack = _STACK_PACK and nb > 1
-        stack_prep = _STACK_PACK and nb > 1
-        # Two half-batch chains on two streams (forward only; fp32 tensors with the boundary launch): every utterance is independent in
-        # the forward, and two DIFFERENT kernels sharing the CUs fill each other's prologues and epilogues where two workgroups of
-        # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a
-        # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
-        halves = _FWD_CHAINS if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % _FWD_CHAINS == 0
-                                 and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"       # (one-stream profiling passes)
-                                 ) else 1
-        pcd, cond_stride = None, 0
-        if conds is not None:
-            # per block and chain a table of layer-major rows (n_layers, B / halves, 2H): what the gate kernels index by the CALL's batch
-            Bh_ = B // halves
-            cond_l = f32(conds.detach()).reshape(nb, halves, Bh_, n_layers, 2 * H).permute(0, 1, 3, 2, 4).contiguous()
-            pcd, cond_stride = ptr(cond_l), n_layers * Bh_ * 2 * H * 4
         if stack_pack:                                            # every block's weight norm + packing (+ planes) in ONE launch
             st = getattr(bplans[0], "_stack_arena", None)
             if st is None:
@@ -1297,6 +1281,7 @@ class FlowStackFn(Function):
                 o2 += counts[k]
             st.pack([bp.plan for bp in bplans], cps, 2 + 2 * n_layers)
         # W^-1 and log det W of every block's invertible 1x1 convolution: one launch (a table of the weights' addresses, cached)
+        stack_prep = _STACK_PACK and nb > 1
         if stack_prep:
             o2, wkey = 0, []
             for k in range(nb):
@@ -1306,12 +1291,19 @@ class FlowStackFn(Function):
             if wtab is None or wtab[0] != wkey:
                 wtab = bplans[0]._w_table = (wkey, torch.tensor(wkey, dtype=torch.int64).to(dev))
             call("glowtts_invconv_prepare_multi", ptr(wtab[1]), pw, n_split * n_split + 1, nb, n_split)
+        # Two half-batch chains on two streams (forward only; fp32 tensors with the boundary launch): every utterance is independent in
+        # the forward, and two DIFFERENT kernels sharing the CUs fill each other's prologues and epilogues where two workgroups of
+        # one kernel run in lock-step (tools/halfbatch_probe.py: a WN stack's forward 272 -> 245 us).  Same kernels, same slabs — a
+        # call covers B / 2 utterances of every slab (tab.reserved = utterances per layer slab) —, results bit for bit the same.
+        halves = _FWD_CHAINS if (_HALF_BATCH_FWD and boundary and stack_prep and stack_pack and B % _FWD_CHAINS == 0
+                                 and os.environ.get("GLOWTTS_SIDE_STREAM", "1") != "0"       # (one-stream profiling passes)
+                                 ) else 1
         if halves > 1:
             main_s = torch.cuda.current_stream(dev)
             extra = [_hip.side_stream(dev, "fwd%d" % (j + 2)) for j in range(halves - 1)]
             for s2 in extra:
                 s2.wait_stream(main_s)
-                for t_ in (x, m2, x_len, zs, y, out, h0, skip, acts, ts, xs, logdets, winv, drops, cond_l if conds is not None else None):
+                for t_ in (x, m2, x_len, zs, y, out, h0, skip, acts, ts, xs, logdets, winv, drops):
                     if t_ is not None:
                         t_.record_stream(s2)
             chains, Bh = [main_s.cuda_stream] + [s2.cuda_stream for s2 in extra], B // halves
@@ -1343,8 +1335,7 @@ class FlowStackFn(Function):
                                          tab.wf_start, tab.b_start, po + (k - 1) * nC * 4 + oC, py + k * nC * 4 + oC, ph + k * nH * 4 + oH,
                                          pld + (k - 1) * B * 4 + oB, pld + k * B * 4 + oB, Bh, C, H, T, n_split, sig_i)
                         _hip.call_on(st, "glowtts_flow_block_fwd_io", ctypes.addressof(tab),
-                                     (px if k == 0 else pz + (k - 1) * nC * 4) + oC, pm + oM, pl + oB,
-                                     None if pcd is None else pcd + (k * halves + hh) * cond_stride,
+                                     (px if k == 0 else pz + (k - 1) * nC * 4) + oC, pm + oM, pl + oB, None,
                                      None if pdr is None else pdr + k * n_layers * 2 * nH + hb * 2 * H * T, scale, py + k * nC * 4 + oC, None,
                                      ph + k * nH * 4 + oH, pxs + k * nx * nH * 4 + oH if n_layers > 1 else None,
                                      pa + k * n_layers * nH * 4 + oH, pts + k * n_layers * 2 * nH * 4 + 2 * oH, psk + k * nH * 4 + oH,
@@ -1369,8 +1360,7 @@ class FlowStackFn(Function):
                 if fuse and k < nb - 1:
                     flags |= 512 | (2048 if boundary else 0)
                 prev_tab = tab
-                call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl,
-                     None if pcd is None else pcd + k * cond_stride,
+                call("glowtts_flow_block_fwd_io", ctypes.addressof(tab), px if k == 0 else pz + (k - 1) * nC * eF, pm, pl, None,
                      None if pdr is None else pdr + k * n_layers * 2 * nH, scale, py + k * nC * eF,
                      None if py0 is None else py0 + k * (nC // 2) * eA, ph + k * nH * eA,
                      pxs + k * nx * nH * eA if n_layers > 1 else None, pa + k * n_layers * nH * eA,
@@ -1385,7 +1375,6 @@ class FlowStackFn(Function):
                               *([] if y0h is None else [y0h]))
         ctx.cfg, ctx.bplans, ctx.counts, ctx.params, ctx.taps, ctx.scale, ctx.fuse = cfg, bplans, counts, params, taps, scale, fuse
         ctx.boundary = boundary
-        ctx.cond_shape = None if conds is None else tuple(conds.shape)
         return zs[nb - 1], logdets.sum(0)
 
     @staticmethod
@@ -1431,10 +1420,6 @@ class FlowStackFn(Function):
         pdz, pdl = ptr(dz), ptr(dlogdet)
         drs_stride = (nH if two_src else n_layers * 2 * nH) * eA
         side = wgrad.side.cuda_stream if wgrad.enabled else None
-        dcond_l, pdc = None, None
-        if ctx.cond_shape is not None:                   # the gate-backward epilogues ADD the conditioning rows' gradient (layer-major)
-            dcond_l = torch.zeros(nb, n_layers, B, 2 * H, device=dev, dtype=torch.float32)
-            pdc = ptr(dcond_l)
         offs = [0]
         for c in counts:
             offs.append(offs[-1] + c)
@@ -1471,8 +1456,7 @@ class FlowStackFn(Function):
                      pxs + k * nx * nH * eA if n_layers > 1 else None, pa + k * n_layers * nH * eA,
                      pts + k * n_layers * 2 * nH * eA, psk + k * nH * eA, po + k * nC * 4,
                      pdz if k == nb - 1 else pdx + (k + 1) * nC * eF, pdl, pdy + k * nC * eF, pdo + k * nC * eA, pds + k * nH * eA,
-                     pdrs + k * drs_stride, pdxin + k * n_layers * 2 * nH * eA, pdxw + k * n_layers * nH * eA, pdx + k * nC * eF,
-                     None if pdc is None else pdc + k * n_layers * B * 2 * H * 4,
+                     pdrs + k * drs_stride, pdxin + k * n_layers * 2 * nH * eA, pdxw + k * n_layers * nH * eA, pdx + k * nC * eF, None,
                      B, C, H, T, ctx.taps, dil_rate, n_split, int(sigmoid_scale), int(two_src), flags, side if on_side else None)
             finally:
                 bplan.unbind(bound)
@@ -1507,8 +1491,7 @@ class FlowStackFn(Function):
                      ptr(pk[2]), tab.w_inv, pdy + k * nC * 4, pdl, pl, pdy + (k - 1) * nC * 4, pdo + (k - 1) * nC * 4, ptr(pk[0].grad),
                      ptr(pk[1].grad), ptr(pk[2].grad), B, C, T, n_split, int(sigmoid_scale))
                 _notify(live[:3])
-        dconds = None if dcond_l is None else dcond_l.permute(0, 2, 1, 3).reshape(ctx.cond_shape)
-        return (dxs[0], None, None, None, dconds, None, None, None) + (None,) * ctx.n_param_args
+        return (dxs[0], None, None, None, None, None, None) + (None,) * ctx.n_param_args
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -180,9 +180,9 @@ class FlowSpecDecoder(nn.Module):
 
     def _stack_args(self, x, g, io, blocks, m2):
         """Arguments of convops.FlowStackFn when EVERY block of the decoder can share one autograd node: the standard
-        [ActNorm, InvConvNear, CouplingBlock] layout (with or without speaker conditioning), every block eligible for the native
+        [ActNorm, InvConvNear, CouplingBlock] layout, no conditioning input, every block eligible for the native
         executors with one common shape.  GLOWTTS_FLOW_STACK=0 keeps one node per block."""
-        if not _FLOW_STACK or not blocks:
+        if g is not None or not _FLOW_STACK or not blocks:
             return None
         trip = self._blocks()
         if not trip:
@@ -198,7 +198,7 @@ class FlowSpecDecoder(nn.Module):
                  wn.hidden_channels, io)
             if cfg is None:
                 cfg = k
-            elif k != cfg or wn.kernel_size != wn0.kernel_size or wn.gin_channels != wn0.gin_channels:
+            elif k != cfg or wn.kernel_size != wn0.kernel_size:
                 return None
             if not hasattr(c, "_block_plan"):
                 c._block_plan = convops.FlowBlockPlan()
@@ -206,10 +206,7 @@ class FlowSpecDecoder(nn.Module):
             bplans.append(c._block_plan)
             counts.append(len(pk))
             params.extend(pk)
-        conds = None
-        if g is not None:                              # every block's conditioning rows (layers.py:142-143), one small conv each
-            conds = torch.stack([convops.conv1d(c.wn.cond_layer, g.contiguous()) for _, _, c in trip])
-        return cfg, bplans, counts, params, conds
+        return cfg, bplans, counts, params
 
     def forward(self, x, x_mask, g=None, reverse=False):
         io = self._use_bf16(x, g, reverse)
@@ -240,11 +237,11 @@ class FlowSpecDecoder(nn.Module):
                     f.wn._drop_pre = masks[k]
             stack = self._stack_args(x, g, io, blocks, m2)
             if stack is not None:                      # every block in ONE autograd node (convops.FlowStackFn)
-                cfg, bplans, counts, params, conds = stack
+                cfg, bplans, counts, params = stack
                 for f in blocks:
                     f.wn._drop_pre = None
                 # (one parameter as the node's differentiable input, the rest as one opaque argument: convops.ParamPack)
-                x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, conds, cfg, bplans, counts, params[0], convops.ParamPack(params))
+                x, logdet_tot = _flow_stack_apply(x, m2, x_len, masks, cfg, bplans, counts, params[0], convops.ParamPack(params))
                 if self.n_sqz > 1:
                     x, x_mask = unsqueeze(x, x_mask, self.n_sqz, io_bf16=flow16)
                 elif flow16:
@@ -264,7 +261,7 @@ class FlowSpecDecoder(nn.Module):
                     drop, wn._drop_pre = getattr(wn, "_drop_pre", None), None
                     cfg = (nxt.n_split, bool(cpl.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0,
                            wn.dilation_rate, wn.n_layers, wn.hidden_channels, io, i // 3)
-                    cond = convops.conv1d(wn.cond_layer, g.contiguous()) if g is not None else None       # (B, 2H * n_layers, 1)
+                    cond = wn.cond_layer(g) if g is not None else None       # (B, 2H * n_layers, 1): tiny, left to torch
                     x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan, cond,
                                                   *convops.flow_block_params(f, nxt, cpl))
                     i += 3
