@@ -261,7 +261,7 @@ class FlowSpecDecoder(nn.Module):
                     drop, wn._drop_pre = getattr(wn, "_drop_pre", None), None
                     cfg = (nxt.n_split, bool(cpl.sigmoid_scale), float(wn.p_dropout) if wn.training else 0.0,
                            wn.dilation_rate, wn.n_layers, wn.hidden_channels, io, i // 3)
-                    cond = wn.cond_layer(g) if g is not None else None       # (B, 2H * n_layers, 1): tiny, left to torch
+                    cond = convops.conv1d(wn.cond_layer, g.contiguous()) if g is not None else None     # (B, 2H * n_layers, 1)
                     x, logdet = _flow_block_apply(x, m2, x_len, drop, cfg, cpl._block_plan, cond,
                                                   *convops.flow_block_params(f, nxt, cpl))
                     i += 3
