@@ -295,6 +295,11 @@ _conv1d_apply = _hip.direct_apply(Conv1dFn)
 def conv1d(conv: torch.nn.Module, x: torch.Tensor, m2: Optional[torch.Tensor] = None, mask_in: bool = False,
            mask_out: bool = False, link=None) -> torch.Tensor:
     """Run an nn.Conv1d (optionally weight-normed, 'same' padding) through the MFMA kernels."""
+    if x.dim() == 3 and x.shape[2] == 1 and x.shape[0] > 1 and m2 is None and conv.kernel_size[0] == 1:
+        # One frame per utterance (the speaker rows g (B, gin, 1) through WN.cond_layer, reference layers.py:142-143): a 1x1 convolution
+        # treats every frame alike, so the B single-frame utterances are run as ONE utterance of B frames — the kernels tile frames,
+        # and B one-frame tiles made the input gradient of the conditioning layer (M = gin, K = 2H * n_layers) a 192 us launch
+        return conv1d(conv, x.transpose(0, 2).contiguous(), link=link).transpose(0, 2).contiguous()
     if hasattr(conv, "weight_v"):
         v, g = conv.weight_v, conv.weight_g
     else:
