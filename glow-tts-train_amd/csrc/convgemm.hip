@@ -1037,6 +1037,10 @@ extern "C" int glowtts_conv_gate_fwd_io(const void *x, const float *wp, const fl
     p.x = static_cast<const float *>(x); p.wp = wp; p.bias = bias; p.cond = cond; p.drop = drop; p.drop_scale = drop_scale;
     p.y0 = static_cast<float *>(acts); p.y1 = static_cast<float *>(ts); p.xb = io; p.yb = io;
     p.x_bs = (long)H * T; p.B = B; p.Cin = H; p.M = 2 * H; p.H = H; p.T = T; p.taps = taps; p.dil = dil; p.pad = pad;
+    if (io == 0) {                                   // Winograd form where U planes are bound and the switch is on (convwino.hip)
+        const int rc = conv_wino_gate_dispatch(p, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     return dispatch_convgemm<EPI_GATE>(p, (hipStream_t)stream);
 }
 

@@ -493,6 +493,10 @@ int conv_wrw_tr_dispatch(ConvWrwParams &p, int ns, hipStream_t s);
 // fp32 kernel that could read these tensors)
 int conv_bf16_dispatch(ConvGemmParams &p, int epi, bool big, bool n5, bool pipe_ok, hipStream_t s);
 
+// convwino.hip: the gated 5-tap in-conv in Winograd F(4, 5) form from U planes bound to the calling thread; -1 = not handled
+int conv_wino_gate_dispatch(ConvGemmParams &p, hipStream_t s);
+int conv_math_forward();
+
 // convgemm_split.hip: bf16-plane arithmetic for the forward-type kernels; -1 = not handled (mode off / weights not
 // registered / shape not instantiated), otherwise the launch's return code
 int conv_split_dispatch(ConvGemmParams &p, int epi, bool big, int nct, bool pipe_ok, hipStream_t s);   // nct: 16-frame column tiles (5 / 4 / 2)

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "glowtts_chan_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_pack_weight": [_P, _P, _P, _P, _P, _I, _I, _I],
     "glowtts_conv_split_weights": [_P, _L, _P],
+    "glowtts_wino_weights": [_P, _L, _P, _I, _P, _L],
     "glowtts_split_planes": [_P, _L, _P, _I],
     "glowtts_conv_wrw_planes": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _I],
     "glowtts_unpack_weight_grad": [_P, _P, _P, _P, _P, _P, _I, _I, _I],
@@ -159,7 +160,8 @@ class EncLayer(ctypes.Structure):
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
                            "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused",
-                           "glowtts_set_knob", "glowtts_get_knob", "glowtts_mas_spans_supported"])
+                           "glowtts_set_knob", "glowtts_get_knob", "glowtts_mas_spans_supported",
+                           "glowtts_conv_bind_wino", "glowtts_wino_plane_elems"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -202,6 +204,10 @@ def load() -> ctypes.CDLL:
     lib.glowtts_conv_bind_planes.argtypes = [_P, _L, _P]
     lib.glowtts_conv_bind_planes_ns.restype = _I
     lib.glowtts_conv_bind_planes_ns.argtypes = [_P, _L, _P, _I]
+    lib.glowtts_conv_bind_wino.restype = _I
+    lib.glowtts_conv_bind_wino.argtypes = [_P, _L, _P, _L]
+    lib.glowtts_wino_plane_elems.restype = _L
+    lib.glowtts_wino_plane_elems.argtypes = [_L]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -307,6 +313,21 @@ def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] 
     if wp is None:
         lib.glowtts_conv_bind_planes(None, 0, None)
     elif lib.glowtts_conv_bind_planes(wp.data_ptr(), wp.numel(), planes.data_ptr()) != 0:
+        raise RuntimeError(lib.glowtts_last_error().decode())
+
+
+def wino_plane_elems(n: int) -> int:
+    """bf16 elements per plane of the Winograd-domain weights (csrc/convwino.hip) of a packed buffer of `n` floats."""
+    return int(load().glowtts_wino_plane_elems(int(n)))
+
+
+def conv_bind_wino(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] = None):
+    """Bind (None: unbind) the Winograd-domain planes (3 x wino_plane_elems(n) bf16, written by glowtts_wino_weights) of a packed-weight
+    buffer for this thread's next gated in-conv launches (used when the switch GLOWTTS_WINO is on)."""
+    lib = load()
+    if wp is None:
+        lib.glowtts_conv_bind_wino(None, 0, None, 0)
+    elif lib.glowtts_conv_bind_wino(wp.data_ptr(), wp.numel(), planes.data_ptr(), planes.numel() // 3) != 0:
         raise RuntimeError(lib.glowtts_last_error().decode())
 
 

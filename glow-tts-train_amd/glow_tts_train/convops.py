@@ -506,6 +506,9 @@ class WNPackPlan:
             arena, planes = self._plane_home(False)
             if planes is not None:
                 conv_bind_planes(arena, planes)
+                wino = getattr(self.shared, "wino_planes", None) if self.shared is not None else None
+                if wino is not None and getattr(self.shared, "wino_key", None) is arena:
+                    _hip.conv_bind_wino(arena, wino)     # (used by the gated in-conv while the switch GLOWTTS_WINO is on)
                 return True
         return False
 
@@ -513,6 +516,7 @@ class WNPackPlan:
     def unbind(bound: bool):
         if bound:
             conv_bind_planes(None)
+            _hip.conv_bind_wino(None)
 
     def dwp_view(self, i):
         cout, cin, taps, off = self.convs[i][5:9]
@@ -605,9 +609,31 @@ class StackArena:
         if _SPLIT_MATH[0] and plans[0].want_planes:
             call("glowtts_pack_weight_planes_multi", ptr(self.desc), ptr(self.prefix), self.n_conv, self.total_rows, ptr(self.arena),
                  self.arena.numel(), ptr(self.planes_buffer(True)))
+            if _WINO and _hip.get_knob("WINO"):
+                self.wino_weights(plans)
         else:
             call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), self.n_conv, self.total_rows)
 
+    def wino_weights(self, plans):
+        """Winograd-domain planes (csrc/convwino.hip) of every gated 5-tap in-conv of the stack: one launch behind the weight pack."""
+        if getattr(self, "wino_key", None) is not self.arena:
+            rows = []
+            for p in plans:
+                for (_v, _g, wp_f, _b, _inv, cout, cin, taps, _off) in p.convs:
+                    if taps == 5 and cout == 2 * cin and cin % 64 == 0:
+                        rows.append([(wp_f.data_ptr() - self.arena.data_ptr()) // 4, cin // 16, cout])
+            self.wino_table = torch.tensor(rows, dtype=torch.int64).to(self.arena.device) if rows else None
+            self.wino_planes = (torch.zeros(3 * _hip.wino_plane_elems(self.arena.numel()), device=self.arena.device, dtype=torch.int16)
+                                if rows else None)
+            self.wino_key = self.arena
+        if self.wino_table is not None:
+            call("glowtts_wino_weights", ptr(self.arena), self.arena.numel(), ptr(self.wino_table), self.wino_table.shape[0],
+                 ptr(self.wino_planes), self.wino_planes.numel() // 3)
+
+
+# The gated 5-tap in-conv of the flow stack in its Winograd F(4, 5) form (csrc/convwino.hip, DESIGN.md 4k): OPT-IN (measured: the
+# kernel alone 43.5 us against 49-55, see DESIGN); needs the stack's one packed buffer and the bf16x6 arithmetic
+_WINO = os.environ.get("GLOWTTS_WINO", "0") == "1"
 
 # FlowStackFn: one weight-pack launch and one W^-1 / log det W launch for the whole stack (0: one of each per block)
 _STACK_PACK = os.environ.get("GLOWTTS_STACK_PACK", "1") != "0"

@@ -31,6 +31,10 @@
  *                                                     between the problems of the batch (csrc/convwrw_tr.hip)
  *                                 GLOWTTS_WRW5_CUS    [-1]    compute units a BATCHED 5-tap weight-gradient launch sizes its split-K for
  *                                                     (-1 = all of the device's)
+ *                                 GLOWTTS_WINO        [0]     1 = the WN stack's gated 5-tap in-conv in its Winograd F(4, 5) form
+ *                                                     (csrc/convwino.hip) wherever Winograd-domain planes are bound to the launching
+ *                                                     thread (glowtts_conv_bind_wino); results differ from the direct form by the
+ *                                                     fp32 roundings of the transforms (same tolerance against the oracle)
  *                                 GLOWTTS_WRW1_MULTI  [1]     0 = the 1x1 weight gradients of a flow block / transformer layer as separate
  *                                                     launches instead of one multi-problem launch (csrc/convwrw1.hip)
  *                                 GLOWTTS_WRW1_CUS    [-1]    compute units the multi-problem 1x1 weight gradient sizes its split-K for
@@ -589,6 +593,21 @@ int glowtts_encoder_layer_bwd(const glowtts_enc_layer *L, const float *x, const 
  *       ActNorm + InvConv launch) / backward: no ActNorm + InvConv backward at the end (dx is not written); bit 9 = forward: no
  *       affine apply at the end (z is not written) / backward: dy and dout have been written by the caller (no coupling backward) */
 int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *planes, int n_planes);
+
+/* ---- Winograd F(4, 5) form of the gated in-conv (reference layers.py:146 + utils.py:31-38; csrc/convwino.hip) -------------------
+ * out[m][4j + i] = sum_p AT[i][p] (sum_c U[m][c][p] V[c][p][j]): U = G w (8 points from the 5 taps), V = BT d (8 points from the
+ * input frames 4j - 2 .. 4j + 5), points {0, +-1, +-2, +-1/2, inf}: 8 products per (row, channel, 4 frames) where the direct
+ * form needs 20.  U and V are fp32 values, each split into three bf16 planes (six products per fp32 product, fp32 accumulation).
+ *   wino_plane_elems(n) : bf16 elements per plane of the U planes of a packed-weight buffer of n floats
+ *   wino_weights : U planes of the listed convolutions of a packed buffer; table (device, int64) rows = (offset of the convolution's
+ *       packed FORWARD weights in floats, Cin / 16, M); planes = 3 x plane_stride bf16 (caller's memory); after every packing
+ *   conv_bind_wino : bind (wp = NULL: unbind) those planes to the calling thread; glowtts_conv_gate_fwd then takes the
+ *       Winograd kernel when GLOWTTS_WINO = 1, arithmetic mode bf16x6, fp32 tensors, 5 taps, dilation 1, H % 64 == 0, T % 4 == 0,
+ *       16-byte-aligned tensors — and the direct kernels otherwise. */
+long glowtts_wino_plane_elems(long n_floats);
+int glowtts_wino_weights(const float *wp, long n_floats, const long *table, int n_conv, uint16_t *planes, long plane_stride,
+                         glowtts_stream_t stream);
+int glowtts_conv_bind_wino(const float *wp, long n_floats, const uint16_t *planes, long plane_stride);
 int glowtts_conv_fwd_io(const void *x, long x_bs, const float *wp, const float *bias, const float *mask, const void *addend,
                         long addend_bs, void *y, long y_bs, int B, int Cin, int M, int T, int taps, int dil, int pad,
                         int mask_in, int mask_out, int mask_add, int io_x, int io_y, glowtts_stream_t stream);

@@ -436,3 +436,59 @@ def test_multi_problem_1x1_weight_gradient_against_fp64(M, mode, b, t):
         assert err < 2e-5, f"problem {j} {specs[j][:3]}: dW off by {err:.2e} of its largest element ({mode})"
         errb = float((dbias.double() - b_ref).abs().max()) / float(b_ref.abs().max())
         assert errb < 2e-5, f"problem {j}: dbias off by {errb:.2e} ({mode})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,t,drop,cond,want_ts", [(4, 192, 400, True, False, True), (3, 192, 160, False, True, True),
+                                                     (5, 64, 36, True, True, False), (2, 128, 8, False, False, True),
+                                                     (32, 192, 400, True, False, True)])
+def test_winograd_gated_in_conv_against_fp64(M, b, h, t, drop, cond, want_ts):
+    """The gated 5-tap in-conv (reference layers.py:146-153 + utils.py:31-38) in its Winograd F(4, 5) form (csrc/convwino.hip):
+    against fp64 at the accuracy of the native fp32 kernel, with dropout keep bytes, conditioning rows, ragged tile counts
+    (utterances whose tile count is not a multiple of a workgroup's 48, tiles of two utterances in one workgroup), and next to
+    the direct bf16x6 kernel it replaces — which it must NOT equal bit for bit (that would mean the switch did nothing)."""
+    call, ptr = M.hip.call, M.hip.ptr
+    dev = "cuda"
+    torch.manual_seed(b * 977 + h + t)
+    x = torch.randn(b, h, t, device=dev) * torch.exp(torch.randn(1, h, 1, device=dev) * 0.5)
+    v_in = torch.randn(2 * h, h, 5, device=dev) * 0.03
+    b_in = torch.randn(2 * h, device=dev) * 0.1
+    wf_in, _, _ = M.convops.pack_weight(v_in, None)
+    keep = (torch.rand(b, 2 * h, t, device=dev) > 0.1).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    g = torch.randn(b, 2 * h, device=dev) * 0.3 if cond else None
+    table = torch.tensor([[0, h // 16, 2 * h]], dtype=torch.int64, device=dev)
+    n_u = M.hip.wino_plane_elems(wf_in.numel())
+    u_planes = torch.zeros(3 * n_u, device=dev, dtype=torch.int16)
+
+    def gate():
+        acts = torch.full((b, h, t), float("nan"), device=dev)
+        ts = torch.full((b, 2 * h, t), float("nan"), device=dev) if want_ts else None
+        call("glowtts_conv_gate_fwd", ptr(x), ptr(wf_in), ptr(b_in), ptr(g), ptr(keep), scale, ptr(acts), ptr(ts), b, h, t, 5, 1, 2)
+        return torch.cat([acts, ts], 1) if want_ts else acts
+
+    pre = F.conv1d(x.double(), v_in.double(), b_in.double(), padding=2)
+    if drop:
+        pre = pre * keep.double() * scale
+    if cond:
+        pre = pre + g.double()[:, :, None]
+    th, sg = torch.tanh(pre[:, :h]), torch.sigmoid(pre[:, h:])
+    ref = torch.cat([th * sg, th, sg], 1) if want_ts else th * sg
+    out = {}
+    try:
+        for name, mode, wino in (("native", "fp32", 0), ("direct", "bf16x6+wrw", 0), ("winograd", "bf16x6+wrw", 1)):
+            M.convops.set_conv_math(mode)
+            _split(M, wf_in)
+            if wino:
+                call("glowtts_wino_weights", ptr(wf_in), wf_in.numel(), ptr(table), 1, ptr(u_planes), n_u)
+                M.hip.conv_bind_wino(wf_in, u_planes)
+            M.hip.set_knob("WINO", wino)
+            out[name] = gate()
+    finally:
+        M.hip.set_knob("WINO", 0)
+        M.hip.conv_bind_wino(None)
+    err = {k: float((v.double() - ref).abs().max()) for k, v in out.items()}
+    assert torch.isfinite(out["winograd"]).all()
+    assert not torch.equal(out["winograd"], out["direct"]), "the Winograd kernel did not run"
+    assert err["winograd"] <= 4 * err["native"] + 2e-7, err         # gate outputs are O(1): absolute = relative
+    assert err["winograd"] < 2.5e-5, err

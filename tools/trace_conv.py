@@ -52,6 +52,9 @@ if which == "wrw5p":                                   # weight gradient from op
     fns["wrw5p"] = lambda: call("glowtts_conv_wrw_planes", ptr(xp), x.numel(), H * T, ptr(dp), d2.numel(), 2 * H * T, ptr(dwp5),
                                 None, B, H, 2 * H, T, 5, 3)
     os.environ.setdefault("TRACE_CONV_MATH", "fp32")
+if which == "wino":                                    # the gated in-conv in its Winograd form (csrc/convwino.hip)
+    fns["wino"] = fns["gate"]
+    os.environ.setdefault("TRACE_CONV_MATH", "bf16x6+wrw")
 fn = fns[which]
 lib = _hip.load()
 split = os.environ.get("TRACE_CONV_MATH")          # e.g. "bf16x6+wrw": trace the bf16-plane kernels (convgemm_split.hip)
@@ -60,11 +63,19 @@ if split:
     _planes = {}
     for w in (wf_in, wb_in, wf_rs, wb_rs):          # bind the one buffer the chosen kernel uses
         _planes[w.data_ptr()] = torch.empty(3 * w.numel(), device=dev, dtype=torch.int16)
-    _use = {"gate": wf_in, "resskip": wf_rs, "bwd_data5": wb_in, "bwd_data1": wb_rs, "gate_bwd": wb_rs}.get(which)
+    _use = {"gate": wf_in, "wino": wf_in, "resskip": wf_rs, "bwd_data5": wb_in, "bwd_data1": wb_rs, "gate_bwd": wb_rs}.get(which)
     if _use is not None:
         call("glowtts_conv_split_weights", ptr(_use), _use.numel(), ptr(_planes[_use.data_ptr()]))
         _hip.conv_bind_planes(_use, _planes[_use.data_ptr()])
 rd = lib.glowtts_debug_trace_read_split if (split or which == "wrw5p") else lib.glowtts_debug_trace_read
+if which == "wino":
+    n_u = _hip.wino_plane_elems(wf_in.numel())
+    u_planes = torch.zeros(3 * n_u, device=dev, dtype=torch.int16)
+    table = torch.tensor([[0, H // 16, 2 * H]], dtype=torch.int64, device=dev)
+    call("glowtts_wino_weights", ptr(wf_in), wf_in.numel(), ptr(table), 1, ptr(u_planes), n_u)
+    _hip.conv_bind_wino(wf_in, u_planes)
+    _hip.set_knob("WINO", 1)
+    rd = lib.glowtts_debug_trace_read_wino
 if which == "wrw5" and split and "wrw" in split and os.environ.get("GLOWTTS_WRW_TR", "1") != "0":
     rd = lib.glowtts_debug_trace_read_tr            # the frame-major / transposed-read kernel (convwrw_tr.hip)
 rd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
