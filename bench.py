@@ -136,7 +136,8 @@ _PMC_KERNEL = {
     # the launch the step makes for a WN stack's four 5-tap weight gradients: one round of 216 workgroups (the pre-net's single
     # 5-tap problems have the same grid size: tools/rocpd_summary.py separates the two duration classes)
     ("glowtts_conv_wrw[M384 K192x5 N32x400]", "bf16x6+wrw"): "convwrw_tr_kernel<3,5,4,false,2> grid=110592#long",
-    ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,1,5,0,3> grid=122880",
+    # the gated in-conv in its Winograd F(4, 5) form (csrc/convwino.hip): 201 workgroups of 256 threads for the whole batch
+    ("glowtts_conv_gate_fwd[M384 K192x5 N32x400]", "bf16x6+wrw"): "wino_gate_fwd_kernel<0> grid=51456",
     ("glowtts_conv_fwd[M192 K384x5 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,4,5,0,3> grid=122880",
     ("glowtts_conv_gate_bwd[M192 K384x1 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,1,5,5,1,0,3> grid=122880",
     ("glowtts_conv_res_skip_fwd[M384 K192x1 N32x400]", "bf16x6+wrw"): "convgemm_split_kernel<3,2,5,2,1,0,3> grid=122880",
@@ -344,6 +345,55 @@ def batched_wrw_time(tag, dev, n=4, iters=20):
     return {"problems_per_launch": n, "us_per_problem": round(us, 2),
             "frac_pipe": round(6.0 * flop / (us * 1e-6) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
             "note": "one glowtts_conv_wrw_batch launch per WN stack in the timed step; alone, back-to-back, distinct operands"}
+
+
+def wino_gate_time(tag, dev, iters=40):
+    """The gated in-conv of `tag`'s shape as the timed step launches it when the Winograd form is on (csrc/convwino.hip): the
+    instrumented pass drives every convolution through the per-operator path, which has no Winograd-domain planes and therefore times
+    the DIRECT kernel.  Weights packed, split and transformed as the flow stack's arena does, then HIP events around `iters`
+    back-to-back launches with dropout keep bytes (as in the step).  None when the launches did not take the Winograd kernel."""
+    import re as _re
+
+    from glow_tts_train import _hip, convops
+    from glow_tts_train._hip import call, ptr
+
+    m_, k_, taps_, b_, t_ = (int(v) for v in _re.match(r"\w+\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)\]", tag).groups())
+    h_ = k_
+    x = torch.randn(b_, h_, t_, device=dev)
+    wf, _, _ = convops.pack_weight(torch.randn(m_, k_, taps_, device=dev) * 0.03, None)
+    bias = torch.zeros(m_, device=dev)
+    keep = (torch.rand(b_, m_, t_, device=dev) > 0.05).to(torch.uint8)
+    acts, ts = torch.empty(b_, h_, t_, device=dev), torch.empty(b_, m_, t_, device=dev)
+    planes = torch.empty(3 * wf.numel(), device=dev, dtype=torch.int16)
+    call("glowtts_conv_split_weights", ptr(wf), wf.numel(), ptr(planes))
+    n_u = _hip.wino_plane_elems(wf.numel())
+    u = torch.zeros(3 * n_u, device=dev, dtype=torch.int16)
+    table = torch.tensor([[0, k_ // 16, m_]], dtype=torch.int64, device=dev)
+    call("glowtts_wino_weights", ptr(wf), wf.numel(), ptr(table), 1, ptr(u), n_u)
+    _hip.conv_bind_planes(wf.reshape(-1), planes)
+    _hip.conv_bind_wino(wf.reshape(-1), u)
+    try:
+        def run():
+            call("glowtts_conv_gate_fwd", ptr(x), ptr(wf), ptr(bias), None, ptr(keep), 1.0 / 0.95, ptr(acts), ptr(ts), b_, h_, t_, taps_, 1,
+                 (taps_ - 1) // 2)
+
+        before = _hip.wino_launches()
+        for _ in range(5):
+            run()
+        if _hip.wino_launches() - before != 5:
+            return None
+        cur = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(iters):
+            run()
+        e1.record(cur)
+        torch.cuda.synchronize()
+    finally:
+        _hip.conv_bind_planes(None)
+        _hip.conv_bind_wino(None)
+    return {"us_per_launch": round(1e3 * e0.elapsed_time(e1) / iters, 2),
+            "note": "the Winograd F(4,5) kernel alone, back to back, with dropout keep bytes; the instrumented pass times the direct kernel"}
 
 
 def wrw1_multi_time(args, dev, iters=20):
@@ -795,10 +845,12 @@ def main():
         Ts = T_mel // cfg.model.n_sqz
         alg = algorithmic_bytes(B, C, H, Ts, T_text, opt._optim.numel_padded)
         n_inst = 3
+        wino_before = _hip.wino_launches()
         _hip.enable_timing()
         for _ in range(n_inst):
             train_batch(model, opt, batch, cfg.grad_clip, None)
         times = _hip.disable_timing()
+        wino_used = wino_before > 0                        # the timed steps ran the gated in-conv in its Winograd form (csrc/convwino.hip)
         log("instrumented pass done")
         dec = decoder_alone(model, batch, cfg, n_iter=5)
         log(f"decoder alone: fwd {dec['fwd_ms']:.2f} ms, bwd {dec['bwd_ms']:.2f} ms")
@@ -854,14 +906,44 @@ def main():
                 return wrw == "wrw" and (taps_ == 1 or (taps_ in (3, 5) and M_ % 32 == 0))
             return False
 
+        def winograd(tag):
+            """Does this launch run in the Winograd F(4, 5) form (csrc/convwino.hip)?  The gated 5-tap in-conv of the flow stack when
+            the library launched that kernel during this process (the counter says so) and the shape is the kernel's: 8 products per
+            (row, channel, 4 frames) instead of 20, i.e. 0.4 of the direct form's MFMAs for the same result."""
+            m_ = re.match(r"glowtts_conv_gate_fwd\[M(\d+) K(\d+)x(\d+) N(\d+)x(\d+)", tag)
+            return bool(m_ and wino_used and int(m_.group(3)) == 5 and int(m_.group(2)) % 64 == 0 and int(m_.group(5)) % 4 == 0
+                        and default_math.startswith("bf16x6"))
+
+        def pipe_mult(tag):                        # MFMA flops the pipe really does per algorithmic (fp32, direct-form) flop
+            return (6.0 * 8.0 / 20.0 if winograd(tag) else 6.0) if on_bf16_pipe(tag) else 1.0
+
+        # The instrumented pass drives every convolution through the per-operator path (no flow-stack arena, hence no Winograd-domain
+        # planes): its row for the gated in-conv is the DIRECT kernel.  Where the timed step launches the Winograd form, the row is
+        # re-priced with that kernel timed alone (the direct kernel's time stays beside it).
+        wino_t = {}
+        for tag, row in mfma.items():
+            if winograd(tag):
+                try:
+                    wt = wino_gate_time(tag, dev)
+                except Exception as exc:
+                    wt = None
+                    log(f"Winograd gate timing failed ({type(exc).__name__}: {exc})")
+                if wt is not None:
+                    wino_t[tag] = wt
+                    row["direct_kernel_mean_us"] = row["mean_us"]
+                    us = wt["us_per_launch"]
+                    row.update(mean_us=us, total_ms_per_step=round(row["launches_per_step"] * us / 1e3, 3),
+                               TFLOPs=round(row["alg_GFLOP"] / us * 1e3, 2), GBps=round(row["alg_MB"] / us * 1e3, 1),
+                               hbm_frac=round(row["alg_MB"] / us * 1e3 / HBM_PEAK_GBS, 4), form=wt["note"])
+        wino_used = bool(wino_t)
         for tag, row in mfma.items():              # which roof bounds each contraction, and how close it is to that roof
             split = on_bf16_pipe(tag)
             peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-            t_mfma = (6.0 if split else 1.0) * row["alg_GFLOP"] / peak            # us at the pipe's peak (GFLOP / TFLOP/s = ms*1e-3)
+            t_mfma = pipe_mult(tag) * row["alg_GFLOP"] / peak            # us at the pipe's peak (GFLOP / TFLOP/s = ms*1e-3)
             t_hbm = row["alg_MB"] / HBM_PEAK_GBS                                    # MB / (GB/s) = ms*1e-3 likewise
-            row.update(pipe="bf16 MFMA x6" if split else "fp32 MFMA",
+            row.update(pipe=("bf16 MFMA x6, Winograd F(4,5): 0.4 of the direct form's products" if winograd(tag) else "bf16 MFMA x6") if split else "fp32 MFMA",
                        mfma_frac_algorithmic=round(row["TFLOPs"] / peak, 4),
-                       mfma_frac_pipe=round((6.0 if split else 1.0) * row["TFLOPs"] / peak, 4),
+                       mfma_frac_pipe=round(pipe_mult(tag) * row["TFLOPs"] / peak, 4),
                        bound="hbm" if t_hbm > t_mfma else "mfma",
                        frac_of_bound=round(max(t_hbm, t_mfma) * 1e3 / row["mean_us"], 4))
         # ---- which launch is the dominant one: arg-max of (launches per step x mean duration) over the table of launches THE STEP
@@ -883,6 +965,7 @@ def main():
             us = row["mean_us"]
             if tag == wrw5_tag and bt is not None:
                 us = bt["us_per_problem"]
+
             as_launched[tag] = {"launches_per_step": row["launches_per_step"], "us_per_launch_or_problem": round(us, 2),
                                 "total_ms_per_step": round(row["launches_per_step"] * us / 1e3, 3)}
         for tag, row in hbm.items():
@@ -896,7 +979,7 @@ def main():
             row = mfma[tag]
             split = on_bf16_pipe(tag)
             peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-            mult = 6.0 if split else 1.0
+            mult = pipe_mult(tag)
             tf = problems * row["alg_GFLOP"] * 1e9 / (mean_us * 1e-6) / 1e12          # fp32-equivalent TFLOP/s
             alg_mb = problems * row["alg_MB"]
             hbm_frac = alg_mb * 1e6 / (mean_us * 1e-6) / 1e9 / HBM_PEAK_GBS
@@ -905,7 +988,8 @@ def main():
                  "achieved": round(mult * tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": mult * tf / peak,
                  "traffic": pe.get("traffic_bytes"), "pmc_source": pe.get("source"), "pmc_key": pe.get("pmc_key"),
                  "mfma_busy_measured": pe.get("mfma_util"),
-                 "pipe": "bf16 MFMA, 6 products per fp32 product (bf16x6)" if split else "fp32 MFMA",
+                 "pipe": ("bf16 MFMA, Winograd F(4,5) form: 8 of the direct form's 20 products per 4 frames, six bf16 MFMAs each"
+                          if winograd(tag) else "bf16 MFMA, 6 products per fp32 product (bf16x6)") if split else "fp32 MFMA",
                  "frac_algorithmic": round(tf / peak, 4), "frac_pipe": round(mult * tf / peak, 4),
                  "mean_us": round(mean_us, 2), "alg_GFLOP": round(problems * row["alg_GFLOP"], 3), "alg_MB": round(alg_mb, 2),
                  "hbm_frac_on_algorithmic_bytes": round(hbm_frac, 4),

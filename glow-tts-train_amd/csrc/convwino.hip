@@ -17,6 +17,7 @@
 // 3 x (2 channels x 8 frames), transforms, splits and stores into the OTHER of two LDS images while the MFMAs read this one.
 #include "convgemm_common.hpp"
 #include "split_planes.hpp"
+#include <atomic>
 #include <type_traits>
 
 namespace glowtts {
@@ -100,6 +101,19 @@ __device__ __forceinline__ float vsub(float a, float b) { float r; asm volatile(
 __device__ __forceinline__ float vmulk(float k, float a) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a)); return r; }
 __device__ __forceinline__ unsigned vcvtpk(float a, float b) { unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vlo(unsigned w) { float r; asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(w)); return r; }
+__device__ __forceinline__ float vmul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vaddk(float k, float a) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "s"(k), "v"(a)); return r; }
+__device__ __forceinline__ float vexp2(float a) { float r; asm volatile("v_exp_f32 %0, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float vrcp(float a) { float r; asm volatile("v_rcp_f32 %0, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float vtanh_from_rcp(float a) { float r; asm volatile("v_fma_f32 %0, %1, 2.0, -1.0" : "=v"(r) : "v"(a)); return r; }
+template <int J> __device__ __forceinline__ float vubyte(unsigned w) {
+    float r;
+    if (J == 0) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(w));
+    if (J == 1) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(w));
+    if (J == 2) asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(w));
+    if (J == 3) asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(w));
+    return r;
+}
 __device__ __forceinline__ float vhi(unsigned w) { float r; asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(w)); return r; }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
@@ -430,36 +444,89 @@ __global__ __launch_bounds__(256, 1) void wino_gate_fwd_kernel(ConvGemmParams p,
             if (p.cond) { ct[cb][reg] = p.cond[(long)b * 2 * p.H + ch]; cs[cb][reg] = p.cond[(long)b * 2 * p.H + p.H + ch]; }
         }
     }
+    // Per column block the 8 accumulator rows of a lane (4 registers x tanh / sigmoid) go through the output transform and the
+    // gate IN LOCKSTEP, stage by stage, as pinned instructions (see vadd above): 8 to 32 independent instructions per stage where
+    // the compiler's order was one row at a time — a chain of ~40 dependent instructions, two transcendentals deep, twelve times.
+    const float kT = -2.f * 1.4426950408889634f, kS = -1.4426950408889634f;
 #pragma unroll
     for (int cb = 0; cb < WINO_CB; ++cb) {
         if (eb[cb] < 0) continue;
         const int b = eb[cb], t0 = et0[cb];
+        float y[8][4];                                   // row = reg * 2 + r
+        {
+            float m[8][WINO_P], s12[8], d12[8], s34[8], d34[8], s56[8], d56[8], ta_[8], tb_[8], tc_[8], td_[8], te_[8], tf_[8], tg_[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int q = 0; q < WINO_P; ++q) m[w][q] = acc[w & 1][q][cb][w >> 1];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s12[w] = vadd(m[w][1], m[w][2]); d12[w] = vsub(m[w][1], m[w][2]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s34[w] = vadd(m[w][3], m[w][4]); d34[w] = vsub(m[w][3], m[w][4]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s56[w] = vadd(m[w][5], m[w][6]); d56[w] = vsub(m[w][5], m[w][6]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { ta_[w] = vadd(m[w][0], s12[w]); tb_[w] = vadd(s34[w], s56[w]); tc_[w] = vmulk(2.f, d34[w]); td_[w] = vmulk(4.f, s34[w]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { te_[w] = vmulk(8.f, d34[w]); tf_[w] = vmulk(0.5f, d56[w]); tg_[w] = vmulk(0.25f, s56[w]); d56[w] = vmulk(0.125f, d56[w]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { y[w][0] = vadd(ta_[w], tb_[w]); tc_[w] = vadd(d12[w], tc_[w]); td_[w] = vadd(s12[w], td_[w]); te_[w] = vadd(d12[w], te_[w]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { y[w][1] = vadd(tc_[w], tf_[w]); y[w][2] = vadd(td_[w], tg_[w]); te_[w] = vadd(te_[w], d56[w]); }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) y[w][3] = vadd(te_[w], m[w][7]);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[w][j] = vadd(y[w][j], (w & 1) ? bs[w >> 1] : bt[w >> 1]);
+        if (p.drop) {                                    // dropout on the pre-activation (layers.py:147): keep byte -> 0 / 1 -> x scale
+            float f[8][4];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const unsigned kk = (w & 1) ? ksg[cb][w >> 1] : kt[cb][w >> 1];
+                f[w][0] = vubyte<0>(kk); f[w][1] = vubyte<1>(kk); f[w][2] = vubyte<2>(kk); f[w][3] = vubyte<3>(kk);
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[w][j] = vmulk(p.drop_scale, f[w][j]);
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[w][j] = vmul(y[w][j], f[w][j]);
+        }
+        if (p.cond) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[w][j] = vadd(y[w][j], (w & 1) ? cs[cb][w >> 1] : ct[cb][w >> 1]);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[w][j] = vmulk((w & 1) ? kS : kT, y[w][j]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[w][j] = vexp2(y[w][j]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[w][j] = vaddk(1.f, y[w][j]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[w][j] = vrcp(y[w][j]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[reg * 2][j] = vtanh_from_rcp(y[reg * 2][j]);      // tanh = 2 / (1 + e^-2x) - 1
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int ch = tile_m * 64 + wave * 16 + lk * 4 + reg;
-            float y[2][4];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float m0 = acc[r][0][cb][reg], m1 = acc[r][1][cb][reg], m2 = acc[r][2][cb][reg], m3 = acc[r][3][cb][reg],
-                            m4 = acc[r][4][cb][reg], m5 = acc[r][5][cb][reg], m6 = acc[r][6][cb][reg], m7 = acc[r][7][cb][reg];
-                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4, s56 = m5 + m6, d56 = m5 - m6;
-                y[r][0] = (m0 + s12) + (s34 + s56);
-                y[r][1] = (d12 + 2.f * d34) + 0.5f * d56;
-                y[r][2] = (s12 + 4.f * s34) + 0.25f * s56;
-                y[r][3] = ((d12 + 8.f * d34) + 0.125f * d56) + m7;
-            }
             const long ot = ((long)b * 2 * p.H + ch) * p.T + t0, os = ot + (long)p.H * p.T;
-            float th[4], sg[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float pt_ = y[0][j] + bt[reg], ps_ = y[1][j] + bs[reg];
-                if (p.drop) {       // dropout on the pre-activation (layers.py:147)
-                    pt_ = ((kt[cb][reg] >> (8 * j)) & 0xffu) ? pt_ * p.drop_scale : 0.f;
-                    ps_ = ((ksg[cb][reg] >> (8 * j)) & 0xffu) ? ps_ * p.drop_scale : 0.f;
-                }
-                th[j] = fast_tanh(pt_ + ct[cb][reg]);
-                sg[j] = fast_sigmoid(ps_ + cs[cb][reg]);
-            }
+            const float *th = y[reg * 2], *sg = y[reg * 2 + 1];
             *reinterpret_cast<float4 *>(p.y0 + ((long)b * p.H + ch) * p.T + t0) = make_float4(th[0] * sg[0], th[1] * sg[1], th[2] * sg[2], th[3] * sg[3]);
             if (p.y1) {
                 *reinterpret_cast<float4 *>(p.y1 + ot) = make_float4(th[0], th[1], th[2], th[3]);
@@ -480,6 +547,7 @@ struct WinoBinding {
     long stride = 0;
 };
 static thread_local WinoBinding t_wino;
+static std::atomic<long> g_wino_launches{0};      // launches of the Winograd kernel so far (tests / bench.py ask: did it run?)
 
 // -1 = not handled (switch off, no U planes bound for these weights, shape or alignment outside the kernel's)
 int conv_wino_gate_dispatch(ConvGemmParams &p, hipStream_t s) {
@@ -513,6 +581,7 @@ int conv_wino_gate_dispatch(ConvGemmParams &p, hipStream_t s) {
         GLOWTTS_LAUNCH_CHECK("glowtts_conv_gate_fwd (Winograd)");
     }
 #endif
+    g_wino_launches.fetch_add(1, std::memory_order_relaxed);
     hipLaunchKernelGGL(wino_gate_fwd_kernel<0>, grid, dim3(256), lds, s, p, U, w.stride);
     GLOWTTS_LAUNCH_CHECK("glowtts_conv_gate_fwd (Winograd)");
 }
@@ -520,6 +589,8 @@ int conv_wino_gate_dispatch(ConvGemmParams &p, hipStream_t s) {
 }  // namespace glowtts
 
 using namespace glowtts;
+
+extern "C" long glowtts_wino_launches(void) { return g_wino_launches.load(std::memory_order_relaxed); }
 
 extern "C" long glowtts_wino_plane_elems(long n) { return wino_u_offset(n) + 8; }
 

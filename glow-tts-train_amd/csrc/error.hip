@@ -24,7 +24,7 @@ struct KnobDef { const char *name; int dflt; };
 static const KnobDef kKnobs[K_COUNT] = {
     {"CONV_ROW_ADJ", 1}, {"CONV32_1X1", 1}, {"WRW1_PIPE", 1}, {"WRW1_MULTI", 1}, {"WRW1_CUS", -1}, {"WRW1_XCD", 1}, {"WN_FUSED", 0},
     {"WRW_BATCH", 1}, {"WRW5_BSPLIT", 1}, {"WRW_TR", -1}, {"WRW_TR_MT", 4}, {"WRW_TR_NG", 2}, {"WRW_TR_NG_SPLITS", 1},
-    {"WRW_TR_PRIO", 2}, {"WRW_TR3", 1}, {"WRW_TR3_MT", 2}, {"MAS_WAVES", 1}, {"WRW5_CUS", -1}, {"WINO", 0},
+    {"WRW_TR_PRIO", 2}, {"WRW_TR3", 1}, {"WRW_TR3_MT", 2}, {"MAS_WAVES", 1}, {"WRW5_CUS", -1}, {"WINO", 1},
 #ifdef GLOWTTS_TRACE
     {"BND_EXP", 0}, {"WRW1_EXP", 0},
 #endif

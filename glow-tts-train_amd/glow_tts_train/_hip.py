@@ -161,7 +161,7 @@ class EncLayer(ctypes.Structure):
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["glowtts_last_error", "glowtts_abi_version", "glowtts_conv_math",
                            "glowtts_conv_bind_planes", "glowtts_conv_bind_planes_ns", "glowtts_wn_fused",
                            "glowtts_set_knob", "glowtts_get_knob", "glowtts_mas_spans_supported",
-                           "glowtts_conv_bind_wino", "glowtts_wino_plane_elems"])
+                           "glowtts_conv_bind_wino", "glowtts_wino_plane_elems", "glowtts_wino_launches"])
 
 _lib: Optional[ctypes.CDLL] = None
 _fn_cache: dict = {}
@@ -208,6 +208,8 @@ def load() -> ctypes.CDLL:
     lib.glowtts_conv_bind_wino.argtypes = [_P, _L, _P, _L]
     lib.glowtts_wino_plane_elems.restype = _L
     lib.glowtts_wino_plane_elems.argtypes = [_L]
+    lib.glowtts_wino_launches.restype = _L
+    lib.glowtts_wino_launches.argtypes = []
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I
@@ -314,6 +316,11 @@ def conv_bind_planes(wp: Optional[torch.Tensor], planes: Optional[torch.Tensor] 
         lib.glowtts_conv_bind_planes(None, 0, None)
     elif lib.glowtts_conv_bind_planes(wp.data_ptr(), wp.numel(), planes.data_ptr()) != 0:
         raise RuntimeError(lib.glowtts_last_error().decode())
+
+
+def wino_launches() -> int:
+    """Launches of the Winograd form of the gated in-conv (csrc/convwino.hip) by this process so far."""
+    return int(load().glowtts_wino_launches())
 
 
 def wino_plane_elems(n: int) -> int:

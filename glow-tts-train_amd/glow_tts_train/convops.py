@@ -631,9 +631,10 @@ class StackArena:
                  ptr(self.wino_planes), self.wino_planes.numel() // 3)
 
 
-# The gated 5-tap in-conv of the flow stack in its Winograd F(4, 5) form (csrc/convwino.hip): OPT-IN (measured: the
-# kernel alone 43.5 us against 49-55, see DESIGN); needs the stack's one packed buffer and the bf16x6 arithmetic
-_WINO = os.environ.get("GLOWTTS_WINO", "0") == "1"
+# The gated 5-tap in-conv of the flow stack in its Winograd F(4, 5) form (csrc/convwino.hip): 35.4 us against 48.4 for the
+# direct bf16x6 kernel alone at the benchmark's shape, 13.60 -> 13.41 ms per step with the two-chain forward (13.87 -> 13.48 with one
+# chain).  Needs the stack's one packed buffer (FlowStackFn) and the bf16x6 arithmetic; GLOWTTS_WINO=0 keeps the direct kernels.
+_WINO = os.environ.get("GLOWTTS_WINO", "1") != "0"
 
 # FlowStackFn: one weight-pack launch and one W^-1 / log det W launch for the whole stack (0: one of each per block)
 _STACK_PACK = os.environ.get("GLOWTTS_STACK_PACK", "1") != "0"

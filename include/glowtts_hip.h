@@ -31,7 +31,7 @@
  *                                                     between the problems of the batch (csrc/convwrw_tr.hip)
  *                                 GLOWTTS_WRW5_CUS    [-1]    compute units a BATCHED 5-tap weight-gradient launch sizes its split-K for
  *                                                     (-1 = all of the device's)
- *                                 GLOWTTS_WINO        [0]     1 = the WN stack's gated 5-tap in-conv in its Winograd F(4, 5) form
+ *                                 GLOWTTS_WINO        [1]     1 = the WN stack's gated 5-tap in-conv in its Winograd F(4, 5) form
  *                                                     (csrc/convwino.hip) wherever Winograd-domain planes are bound to the launching
  *                                                     thread (glowtts_conv_bind_wino); results differ from the direct form by the
  *                                                     fp32 roundings of the transforms (same tolerance against the oracle)
@@ -605,6 +605,7 @@ int glowtts_conv_bind_planes_ns(const float *wp, long n_floats, const uint16_t *
  *       Winograd kernel when GLOWTTS_WINO = 1, arithmetic mode bf16x6, fp32 tensors, 5 taps, dilation 1, H % 64 == 0, T % 4 == 0,
  *       16-byte-aligned tensors — and the direct kernels otherwise. */
 long glowtts_wino_plane_elems(long n_floats);
+long glowtts_wino_launches(void);        /* launches of the Winograd kernel by this process so far (tests, bench.py) */
 int glowtts_wino_weights(const float *wp, long n_floats, const long *table, int n_conv, uint16_t *planes, long plane_stride,
                          glowtts_stream_t stream);
 int glowtts_conv_bind_wino(const float *wp, long n_floats, const uint16_t *planes, long plane_stride);

@@ -492,3 +492,49 @@ def test_winograd_gated_in_conv_against_fp64(M, b, h, t, drop, cond, want_ts):
     assert not torch.equal(out["winograd"], out["direct"]), "the Winograd kernel did not run"
     assert err["winograd"] <= 4 * err["native"] + 2e-7, err         # gate outputs are O(1): absolute = relative
     assert err["winograd"] < 2.5e-5, err
+
+
+@pytest.mark.gpu
+def test_flow_stack_takes_the_winograd_gated_in_conv_and_can_be_told_not_to(M):
+    """The flow stack's forward launches the Winograd form of the gated in-conv by default (one launch per WN layer and forward
+    chain; `glowtts_wino_launches` counts them), `glowtts_set_knob("WINO", 0)` puts the direct kernels back, and the two agree to
+    the rounding of the transforms (z, log-det and every gradient within the tolerances of the arithmetic-mode comparison)."""
+    from glow_tts_train import models
+
+    torch.manual_seed(5)
+    b, t, blocks, layers = 4, 64, 2, 4
+    dec = models.FlowSpecDecoder(80, hidden_channels=192, kernel_size=5, dilation_rate=1, n_blocks=blocks, n_layers=layers,
+                                 p_dropout=0.0, n_split=4, n_sqz=2).cuda().train()
+    y0 = torch.randn(b, 80, t, device="cuda")
+    lens = torch.tensor([t, t - 8, t - 20, t // 2], device="cuda")
+    mask = (torch.arange(t, device="cuda")[None] < lens[:, None]).float()[:, None]
+    with torch.no_grad():
+        for f in dec.flows:
+            if hasattr(f, "end"):
+                f.end.weight.normal_(0, 0.02)
+    for p in dec.parameters():                           # (the stack node writes gradients in place: they must exist)
+        p.grad = torch.zeros_like(p)
+    res = {}
+    try:
+        for wino in (1, 0):
+            M.hip.set_knob("WINO", wino)
+            for p in dec.parameters():
+                p.grad.zero_()
+            y = (y0 * mask).clone().requires_grad_(True)
+            before = M.hip.wino_launches()
+            z, ld = dec(y, mask)
+            launched = M.hip.wino_launches() - before
+            (z.square().sum() + ld.sum()).backward()
+            res[wino] = (z.detach(), ld.detach(), y.grad.clone(), {k: p.grad.clone() for k, p in dec.named_parameters()}, launched)
+    finally:
+        M.hip.set_knob("WINO", 1)
+    assert res[1][4] in (blocks * layers, 2 * blocks * layers), res[1][4]        # one or two forward chains
+    assert res[0][4] == 0
+    z1, l1, g1, p1, _ = res[1]
+    z0, l0, g0, p0, _ = res[0]
+    assert not torch.equal(z1, z0)
+    assert float((z1 - z0).abs().max()) <= 2e-5 * max(1.0, float(z0.abs().max()))
+    assert float((l1 - l0).abs().max()) <= 1e-4 * max(1.0, float(l0.abs().max()))
+    assert float((g1 - g0).abs().max()) <= 1e-4 * float(g0.abs().max())
+    for k in p0:
+        assert float((p1[k] - p0[k]).abs().max()) <= 2e-4 * max(1e-3, float(p0[k].abs().max())), k
