@@ -428,10 +428,11 @@ class WNPackPlan:
     norm + packing of all 2*n_layers convolutions is ONE launch per forward and their un-packing ONE launch per backward
     (the tables hold raw device pointers, valid as long as the parameter storage does not move: checked by key)."""
 
-    def __init__(self, want_planes: bool = False):
+    def __init__(self, want_planes: bool = False, wino: bool = False):
         self.key = None
         self.gkey = None
         self.want_planes = want_planes       # only a WN stack's convolutions have bf16-plane kernels (convgemm_split.hip)
+        self.wino = wino                     # a flow block's plan: its gated in-convs also get Winograd-domain planes (convwino.hip)
         self.shared = None                   # StackArena this plan's packed weights live in (one pack launch per stack), or None
 
     @staticmethod
@@ -497,6 +498,8 @@ class WNPackPlan:
             arena, planes = self._plane_home(True)
             call("glowtts_pack_weight_planes_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows,
                  ptr(arena), arena.numel(), ptr(planes))
+            if self.shared is None and self.wino and _WINO and _hip.get_knob("WINO"):
+                _wino_update(self, arena, [self])     # (a block with its own packed buffer: the per-block path, e.g. configs[4])
         else:
             call("glowtts_pack_weight_multi", ptr(self.desc), ptr(self.prefix), len(self.convs), self.total_rows)
 
@@ -506,8 +509,9 @@ class WNPackPlan:
             arena, planes = self._plane_home(False)
             if planes is not None:
                 conv_bind_planes(arena, planes)
-                wino = getattr(self.shared, "wino_planes", None) if self.shared is not None else None
-                if wino is not None and getattr(self.shared, "wino_key", None) is arena:
+                owner = self.shared if self.shared is not None else self
+                wino = getattr(owner, "wino_planes", None)
+                if wino is not None and getattr(owner, "wino_key", None) is arena:
                     _hip.conv_bind_wino(arena, wino)     # (used by the gated in-conv while the switch GLOWTTS_WINO is on)
                 return True
         return False
@@ -616,19 +620,25 @@ class StackArena:
 
     def wino_weights(self, plans):
         """Winograd-domain planes (csrc/convwino.hip) of every gated 5-tap in-conv of the stack: one launch behind the weight pack."""
-        if getattr(self, "wino_key", None) is not self.arena:
-            rows = []
-            for p in plans:
-                for (_v, _g, wp_f, _b, _inv, cout, cin, taps, _off) in p.convs:
-                    if taps == 5 and cout == 2 * cin and cin % 64 == 0:
-                        rows.append([(wp_f.data_ptr() - self.arena.data_ptr()) // 4, cin // 16, cout])
-            self.wino_table = torch.tensor(rows, dtype=torch.int64).to(self.arena.device) if rows else None
-            self.wino_planes = (torch.zeros(3 * _hip.wino_plane_elems(self.arena.numel()), device=self.arena.device, dtype=torch.int16)
-                                if rows else None)
-            self.wino_key = self.arena
-        if self.wino_table is not None:
-            call("glowtts_wino_weights", ptr(self.arena), self.arena.numel(), ptr(self.wino_table), self.wino_table.shape[0],
-                 ptr(self.wino_planes), self.wino_planes.numel() // 3)
+        _wino_update(self, self.arena, plans)
+
+
+def _wino_update(owner, arena, plans):
+    """(Re)make the Winograd-domain planes of the gated 5-tap in-convs packed in `arena` (a flow stack's buffer or one block's own):
+    table of (offset, Cin / 16, M) rows built once per buffer, one `glowtts_wino_weights` launch per packing."""
+    if getattr(owner, "wino_key", None) is not arena:
+        rows = []
+        for p in plans:
+            for (_v, _g, wp_f, _b, _inv, cout, cin, taps, _off) in p.convs:
+                if taps == 5 and cout == 2 * cin and cin % 64 == 0:
+                    rows.append([(wp_f.data_ptr() - arena.data_ptr()) // 4, cin // 16, cout])
+        owner.wino_table = torch.tensor(rows, dtype=torch.int64).to(arena.device) if rows else None
+        owner.wino_planes = (torch.zeros(3 * _hip.wino_plane_elems(arena.numel()), device=arena.device, dtype=torch.int16)
+                             if rows else None)
+        owner.wino_key = arena
+    if owner.wino_table is not None:
+        call("glowtts_wino_weights", ptr(arena), arena.numel(), ptr(owner.wino_table), owner.wino_table.shape[0],
+             ptr(owner.wino_planes), owner.wino_planes.numel() // 3)
 
 
 # The gated 5-tap in-conv of the flow stack in its Winograd F(4, 5) form (csrc/convwino.hip, DESIGN.md 4k): 35.4 us against 48.4 for the
@@ -986,7 +996,7 @@ class FlowBlockPlan:
     un-pack launch per backward (the per-op path used two of each: the coupling's ConvGroup and the WN stack's plan)."""
 
     def __init__(self):
-        self.plan = WNPackPlan(want_planes=True)
+        self.plan = WNPackPlan(want_planes=True, wino=True)
         self._key = None
 
     def bind(self, io: bool):
