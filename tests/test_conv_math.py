@@ -485,11 +485,20 @@ def test_winograd_gated_in_conv_against_fp64(M, b, h, t, drop, cond, want_ts):
             M.hip.set_knob("WINO", wino)
             out[name] = gate()
     finally:
-        M.hip.set_knob("WINO", 0)
+        M.hip.set_knob("WINO", 1)                        # (the package default)
         M.hip.conv_bind_wino(None)
     err = {k: float((v.double() - ref).abs().max()) for k, v in out.items()}
     assert torch.isfinite(out["winograd"]).all()
     assert not torch.equal(out["winograd"], out["direct"]), "the Winograd kernel did not run"
+    try:                                                 # no atomics anywhere in it: launch-to-launch bit-identical
+        M.convops.set_conv_math("bf16x6+wrw")
+        _split(M, wf_in)
+        M.hip.conv_bind_wino(wf_in, u_planes)
+        M.hip.set_knob("WINO", 1)
+        assert torch.equal(gate(), out["winograd"])
+    finally:
+        M.hip.set_knob("WINO", 1)
+        M.hip.conv_bind_wino(None)
     assert err["winograd"] <= 4 * err["native"] + 2e-7, err         # gate outputs are O(1): absolute = relative
     assert err["winograd"] < 2.5e-5, err
 
