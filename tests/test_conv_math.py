@@ -500,7 +500,7 @@ def test_winograd_gated_in_conv_against_fp64(M, b, h, t, drop, cond, want_ts):
         M.hip.set_knob("WINO", 1)
         M.hip.conv_bind_wino(None)
     assert err["winograd"] <= 4 * err["native"] + 2e-7, err         # gate outputs are O(1): absolute = relative
-    assert err["winograd"] < 2.5e-5, err
+    assert err["winograd"] < 2e-5, err            # (the bound the full-size per-launch test holds the direct kernels to)
 
 
 @pytest.mark.gpu
