@@ -57,7 +57,7 @@ def run(n):
         call("glowtts_conv_gate_fwd", ptr(xs[i % len(xs)]), ptr(sets[i % NW]), ptr(b_in), None, ptr(keep), 1.0 / 0.95, ptr(acts), ptr(ts), b, h, t, 5, 1, 2)
 
 
-variants = (0, 1, 0, 1) + ((3, 7, 17) if 'trace' in os.environ.get('GLOWTTS_HIP_LIB', '') else ())
+variants = (0, 1, 0, 1) + ((3, 7, 15, 17) if 'trace' in os.environ.get('GLOWTTS_HIP_LIB', '') else ())
 for wino in variants:
     _hip.set_knob("WINO", wino)
     run(10)
