@@ -177,7 +177,7 @@ enum Knob {
     K_CONV_ROW_ADJ, K_CONV32_1X1, K_WRW1_PIPE, K_WRW1_MULTI, K_WRW1_CUS, K_WRW1_XCD, K_WN_FUSED, K_WRW_BATCH, K_WRW5_BSPLIT,
     K_WRW_TR, K_WRW_TR_MT, K_WRW_TR_NG, K_WRW_TR_NG_SPLITS, K_WRW_TR_PRIO, K_WRW_TR3, K_WRW_TR3_MT, K_MAS_WAVES, K_WRW5_CUS, K_WINO,
 #ifdef GLOWTTS_TRACE
-    K_BND_EXP, K_WRW1_EXP,
+    K_BND_EXP, K_WRW1_EXP, K_CONV_EXP,
 #endif
     K_COUNT
 };

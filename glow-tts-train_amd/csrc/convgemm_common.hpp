@@ -52,6 +52,7 @@ struct ConvGemmParams {
     int xb;                  // 1: x / x2 are bf16 tensors (same element indexing; convgemm_split.hip NS = 1 only)
     int yb;                  // 1: the epilogue's tensors y0, y1, r0, r1 are bf16 (bias, mask, cond stay fp32)
     int wg_order;            // convgemm_split.hip: 1 = the row tiles of a frame tile take consecutive slots of ONE XCD (set by the launcher)
+    int exp;                 // tuning build only (GLOWTTS_CONV_EXP, tools/microbench_conv.py): bits that make the kernel SKIP pieces
 };
 
 // ---- element access of the epilogues: fp32 tensors, or bf16 tensors behind the same float* fields (p.yb) ------------

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         wvo[r] = row_ok(lr) ? (grow(lr) * 16 + lk * 4) * 2 : wbytes;
     }
     const int wtap = G * p.M * 32, wgrp = p.M * 32;  // bytes
-    i32x4 a[3][RTW][NSA];
+    i32x4 a[3][RTW][NSA] = {};
     auto wload = [&](int c, int s, int slot) {       // weights of step s of chunk c (s may run past the chunk: next chunk)
+        if ((GLOWTTS_EXP_BITS(p.exp) & 4) && (c > 0 || s > 2)) return;       // (timing experiment: no weight loads after the first three)
         if (s >= S) { s -= S; c += 1; }
         const int g = c * KG + 2 * (s / TAPS), tap = s % TAPS;
         const int so0 = g < G ? tap * wtap + g * wgrp : wbytes;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
     constexpr int F0 = HI / 8, LH0 = HI - 8 * F0;
     constexpr int FR = XB ? 0 : F0 + (LH0 >= 5 ? 1 : 0), LH = (XB || LH0 >= 5) ? 0 : LH0, QR = (LH + 1) / 2;
     static_assert(NFQ % 4 == 0, "frame quads in fours");
-    f32x4 xf[FR > 0 ? FR : 1][4], xq[QR > 0 ? QR : 1];
+    f32x4 xf[FR > 0 ? FR : 1][4] = {}, xq[QR > 0 ? QR : 1] = {};
     unsigned xfo[FR > 0 ? FR : 1], xqo[QR > 0 ? QR : 1];
     int xfd[FR > 0 ? FR : 1], xqd[QR > 0 ? QR : 1], xfq[FR > 0 ? FR : 1], xqq[QR > 0 ? QR : 1];
     const unsigned rowb = (unsigned)p.T * 4u;
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         const int t = ts + tid;
         Ms[tid] = (t >= 0 && t < p.T) ? mk[t] : 0.f;
     }
-    auto xload = [&](int c) {
+    auto xload = [&](int c, int part = -1) {           // part: -1 = everything, r < FR = round r, FR = the quarter pieces
+        if (GLOWTTS_EXP_BITS(p.exp) & 1) return;         // (timing experiment: no activation loads)
         const bool second = p.x2 != nullptr && c * KG * 16 >= p.x_split;
         const int cbase = c * KG * 16 - (second ? p.x_split : 0);
         if constexpr (XB) {
@@ -229,16 +231,24 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
         } else {
 #pragma unroll
             for (int r = 0; r < FR; ++r)
+                if (part < 0 || part == r) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xf[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        second ? xrs2 : xrs, (int)(xfo[r] + i * rowb)   /* an out-of-range offset stays out of range */, cbase * p.T * ES, 0));
+                    for (int i = 0; i < 4; ++i) {
+                        int vo = (int)(xfo[r] + i * rowb);   /* an out-of-range offset stays out of range */
+                        int so = cbase * p.T * ES;
+                        if (GLOWTTS_EXP_BITS(p.exp) & 128) { vo &= 0xff0; so = 0; }     // (timing experiment: every load hits the same 4 KB)
+                        xf[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? xrs2 : xrs, vo, so, 0));
+                    }
+                }
+            if (part < 0 || part == FR) {
 #pragma unroll
-            for (int r = 0; r < QR; ++r)
-                xq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? xrs2 : xrs, (int)xqo[r], cbase * p.T * ES, 0));
+                for (int r = 0; r < QR; ++r)
+                    xq[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(second ? xrs2 : xrs, (int)xqo[r], cbase * p.T * ES, 0));
+            }
         }
     };
     auto xstore = [&]() {
+        if (GLOWTTS_EXP_BITS(p.exp) & 2) return;         // (timing experiment: no split / LDS stores)
         if constexpr (XB) {
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi)
@@ -340,18 +350,30 @@ __global__ __launch_bounds__(256, 2) void convgemm_split_kernel(ConvGemmParams p
                 __builtin_amdgcn_sched_barrier(0);
             }
             wload(c, s + 3, s % 3);                 // refill the slot just consumed: three steps of lead
-            if (s == 0 && more) xload(c + 1);
+            if (more) {
+#ifdef GLOWTTS_TRACE
+                const int e = p.exp;
+                if (e & 16) { if (s == S / 2) xload(c + 1); }                       // (experiments on WHEN the next chunk's loads are issued)
+                else if (e & 32) { if (s == S - 4) xload(c + 1); }
+                else if (e & 64) { if (s % 2 == 0 && s / 2 <= FR) xload(c + 1, s / 2); }
+                else if (s == 0) xload(c + 1);
+#else
+                if (s == 0) xload(c + 1);
+#endif
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         GLOWTTS_TRACE_POINT(2 + 2 * (c & 3));
-        __syncthreads();
+        __syncthreads();      // (an LDS-only barrier here — the weight ring's loads stay in flight across it — measured: no gain, round 5)
         if (more) {
             xstore();
             __syncthreads();
         }
         GLOWTTS_TRACE_POINT(3 + 2 * (c & 3));
     }
-    if (p.vec_epilogue) {
+    if (GLOWTTS_EXP_BITS(p.exp) & 8) {                   // (timing experiment: no epilogue: one store keeps the accumulators alive)
+        if (acc[0][0][0] == 1234.5f) p.y0[0] = acc[RTW - 1][NCT - 1][1];
+    } else if (p.vec_epilogue) {
         conv_epilogue_lds<RTW, NCT, EPI, YB>(p, acc, smem, b, t0, tile_m, wave, lane);
     } else {
         conv_epilogue<RTW, NCT, EPI, YB>(p, acc, b, t0, tile_m, wave, lane);
@@ -874,6 +896,7 @@ static int launch_split(ConvGemmParams &p, const unsigned short *planes, long st
                      aligned16(p.drop) && (p.y_bs % 4 == 0) && (p.r_bs % 4 == 0) && (EPI != EPI_GATE || p.H % 4 == 0);
     static LdsLimit attr_max_e;   // per device: raised only when a launch needs more than any earlier one
     if (int rc_ = attr_max_e.ensure(reinterpret_cast<const void *>(&convgemm_split_kernel<NS, RTW, NCT, EPI, TAPS, IOB, NSA>), lds, "glowtts_conv (split)")) return rc_;
+    p.exp = GLOWTTS_EXP_BITS(knob(K_CONV_EXP));
     const int ntile_t = (p.T + NT - 1) / NT;
     const int rows = (EPI == EPI_GATE) ? p.H : p.M;
     const int per = (EPI == EPI_GATE) ? 64 : WGR;

@@ -26,7 +26,7 @@ static const KnobDef kKnobs[K_COUNT] = {
     {"WRW_BATCH", 1}, {"WRW5_BSPLIT", 1}, {"WRW_TR", -1}, {"WRW_TR_MT", 4}, {"WRW_TR_NG", 2}, {"WRW_TR_NG_SPLITS", 1},
     {"WRW_TR_PRIO", 2}, {"WRW_TR3", 1}, {"WRW_TR3_MT", 2}, {"MAS_WAVES", 1}, {"WRW5_CUS", -1}, {"WINO", 1},
 #ifdef GLOWTTS_TRACE
-    {"BND_EXP", 0}, {"WRW1_EXP", 0},
+    {"BND_EXP", 0}, {"WRW1_EXP", 0}, {"CONV_EXP", 0},
 #endif
 };
 static std::atomic<int> g_knob[K_COUNT];

@@ -61,6 +61,9 @@
  *                                                     reduction (tools/boundary_bench.py)
  *                                 GLOWTTS_WRW1_EXP    [0]     csrc/convwrw1.hip: bit 0 = no atomics, 2 = no MFMAs, 3 = no loads after the first
  *                                                     step (tools/wrw1_bench.py)
+ *                                 GLOWTTS_CONV_EXP    [0]     csrc/convgemm_split.hip: bit 0 = no activation loads, 1 = no split / LDS stores,
+ *                                                     2 = no weight loads after the first three, 3 = no epilogue, 4-6 = WHEN the next chunk's
+ *                                                     activation loads are issued (tools/conv_exp.py)
  *       per device            : high-water marks of kernel LDS limits (hipFuncSetAttribute called once per kernel);
  *       per thread            : event rings of the timing mode, bf16-plane bindings (glowtts_conv_bind_planes);
  *   - activations are fp32, contiguous (B, C, T) with T fastest (the reference layout); masks are fp32 (B, T)

@@ -483,7 +483,7 @@ def test_tuning_switches_are_latched_listed_and_settable():
     shipped_part, _, trace_part = table.partition("#ifdef GLOWTTS_TRACE")
     shipped = re.findall(r'\{"([A-Z0-9_]+)",', shipped_part)
     trace_only = re.findall(r'\{"([A-Z0-9_]+)",', trace_part)
-    assert len(shipped) >= 10 and sorted(trace_only) == ["BND_EXP", "WRW1_EXP"]
+    assert len(shipped) >= 10 and sorted(trace_only) == ["BND_EXP", "CONV_EXP", "WRW1_EXP"]
     common = open(os.path.join(csrc, "common.hpp")).read()
     enum = common[common.index("enum Knob {"):common.index("K_COUNT", common.index("enum Knob {"))]
     assert re.findall(r"\bK_([A-Z0-9_]+)", enum) == shipped + trace_only, "enum Knob and the name table must have one order"
