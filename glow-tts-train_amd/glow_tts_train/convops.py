@@ -979,7 +979,7 @@ class WNFn(Function):
              len(plan.convs), plan.total_rows, B, H, T, taps, dil_rate, int(two_src),
              wgrad.side.cuda_stream if wgrad.enabled else None)
         if wgrad.enabled:
-            for t in (x, xs, acts, d_rs, d_xin, dx, dskip):   # read by the weight-gradient stream after this call returns
+            for t in (x, xs, acts, d_rs, d_xin, dx, dskip, m2):   # read by the weight-gradient stream after this call returns (m2: see FlowBlockFn)
                 if t is not None:
                     t.record_stream(wgrad.side)
             with torch.cuda.stream(wgrad.side):         # listeners (the DP reducer) must wait on the stream that un-packs
@@ -1251,7 +1251,13 @@ class FlowBlockFn(Function):
         live = [p for p in params if p is not None]
         _mark_direct(live, True)
         if wgrad.enabled:
-            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn):     # read by the second stream after this returns
+            # ... the MASK included: the start conv's weight gradient multiplies its d operand by it (the only 1x1 weight gradient that
+            # does).  It is a small tensor made in the forward, freed when the last block's backward returns — and the caching allocator
+            # then hands its memory to the next small allocation on the main stream while the side stream, a block or two behind, has
+            # not run that launch yet: the start conv of the last side-stream block(s) came out with a weight AND bias gradient of
+            # zero, once in ~200 steps in native-fp32 arithmetic (where the side stream lags most), 3 of ~25 full test-suite runs
+            # (round 5; tools/race_hunt_c5.py)
+            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, m2):     # read by the second stream after this returns
                 if t is not None:
                     t.record_stream(wgrad.side)
             with torch.cuda.stream(wgrad.side):          # every gradient of the block is complete at this point of THAT stream
@@ -1466,7 +1472,7 @@ class FlowStackFn(Function):
         for c in counts:
             offs.append(offs[-1] + c)
         if wgrad.enabled:                                # read by the second stream after this returns
-            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, zs):
+            for t in (y, y0h, h0, xs, acts, skip, dout, dskip, d_rs, d_xin, dx_wn, zs, m2):    # (m2: see FlowBlockFn.backward)
                 if t is not None:
                     t.record_stream(wgrad.side)
         # between blocks (fp32 tensors): start conv backward-data(k) + ActNorm / InvConv backward(k) + coupling backward(k - 1) + end conv
@@ -1688,8 +1694,9 @@ class EncoderStackFn(Function):
         for c in counts:
             offs.append(offs[-1] + c)
         if wgrad.enabled:
-            for t in (x, buf, ws, dx_out):
-                t.record_stream(wgrad.side)
+            for t in (x, buf, ws, dx_out, m2, keep):         # (masks too: see FlowBlockFn.backward)
+                if t is not None:
+                    t.record_stream(wgrad.side)
         for l in range(nl - 1, -1, -1):
             group, attn, ffn, norm1, norm2 = layers[l]
             tab, live = _enc_layer_table(group, attn, ffn, norm1, norm2)
@@ -1801,8 +1808,9 @@ class EncoderLayerFn(Function):
             WNPackPlan.unbind(bound)
         _mark_direct(live, True)
         if wgrad.enabled:
-            for t in (x, buf, ws, dx2):                  # read by the second stream after this returns
-                t.record_stream(wgrad.side)
+            for t in (x, buf, ws, dx2, m2):              # read by the second stream after this returns (the mask too: see FlowBlockFn.backward)
+                if t is not None:
+                    t.record_stream(wgrad.side)
             with torch.cuda.stream(wgrad.side):
                 _notify(live)
         else:
